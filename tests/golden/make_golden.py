@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Regenerates the golden vectors in this directory from the reference checkout.
+
+Run in the build container only (``/root/reference`` must exist; it never
+travels to the GPU box):  ``python tests/golden/make_golden.py``
+
+The reference modules are imported unmodified.  Their only missing import,
+``torch_geometric.data``, is satisfied in memory by this repository's own
+attribute-bag ``Data`` / ``Batch`` classes; nothing is written to the reference
+tree (``sys.dont_write_bytecode``).  Only tensors (inputs and the reference's
+outputs) are stored, as ``.npz`` files.
+
+What is captured
+  gen_weights.npz          AIGGenerator state_dict after torch.manual_seed(123)
+  gen_<case>.npz           template, z, candidate_k -> edge_index / edge_attr / x,
+                           and for the small cases h_cond plus every target's
+                           candidate list and logits
+  cons_<case>.npz          graph -> enforce_aig_constraints output, penalty dict,
+                           validate_strict_aig strings, resync_attrs output
+  pad_<case>.npz           pad_data / unpad_data outputs
+  topk_kat.npz             torch.topk(largest=True, sorted=True) indices for crafted
+                           tied rows, C = 1..512, k in {1,2}
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from gan_amd.data import Data, Batch
+from gan_amd.synth import synth_aig
+
+REF = os.environ.get("AIG_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+    tgd.Data, tgd.Batch, tg.data = Data, Batch, tgd
+    sys.modules["torch_geometric"], sys.modules["torch_geometric.data"] = tg, tgd
+    sys.path.insert(0, REF)
+    from models.generator import AIGGenerator
+    from models import constraints
+    from utilities import data_process
+    import AIGgan
+    return AIGGenerator, constraints, data_process, AIGgan
+
+
+def np_of(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: v for k, v in arrays.items() if v is not None})
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------- templates
+def template_cases(data_process):
+    """name -> (template Data, candidate_k, keep_intermediates)"""
+    cases = {}
+    cases["c17_fwd_k4"] = (synth_aig(5, 6, 2, seed=1, window=8), 4, True)
+    cases["n243_fwd_k16"] = (synth_aig(30, 200, 13, seed=2, window=64), 16, True)
+    cases["n486_dataset_k64"] = (synth_aig(60, 400, 26, seed=3, window=128, orientation="dataset"), 64, True)
+    t = synth_aig(60, 400, 26, seed=4, window=128)
+    del t.node_depth
+    cases["n486_nodepth_k64"] = (t, 64, False)
+    # Q1: a template that kept its padding (pad rows are type 0 = PI, depth -1, largest ids)
+    t = data_process.pad_data(synth_aig(30, 200, 13, seed=5, window=64, orientation="dataset"), 300, 500)
+    cases["n243_padded300_k64"] = (Data(x=t.x, node_depth=t.node_depth), 64, False)
+    cases["n300_shuffled_k16"] = (synth_aig(40, 230, 30, seed=6, window=50, shuffle_ids=True), 16, True)
+    # PO / AND nodes ahead of every PI and no depth: empty-seen and no-candidate fallbacks
+    x = torch.tensor([[1, 0], [2, 0], [1, 0], [0, 0], [2, 0], [0, 0], [2, 0], [1, 0], [2, 0], [2, 0]],
+                     dtype=torch.float32)
+    cases["pofirst_nodepth_k4"] = (Data(x=x), 4, True)
+    # same but depth puts a PO first among equals
+    cases["pofirst_depth_k4"] = (Data(x=x.clone(), node_depth=torch.tensor(
+        [0, 0, 1, 1, 1, 2, 2, 3, 3, 3], dtype=torch.float32)), 4, True)
+    cases["n2300_fwd_k64"] = (synth_aig(200, 2000, 100, seed=7, window=512), 64, False)
+    cases["n700_fwd_k512"] = (synth_aig(80, 580, 40, seed=8, window=256), 512, False)
+    cases["n700_dataset_k256"] = (synth_aig(80, 580, 40, seed=9, window=256, orientation="dataset"), 256, False)
+    # few ties: second feature replaced by a random float
+    t = synth_aig(60, 400, 26, seed=10, window=128)
+    g = torch.Generator().manual_seed(10)
+    t.x[:, 1] = torch.rand(t.x.size(0), generator=g)
+    cases["n486_distinct_k64"] = (t, 64, True)
+    # node_depth as int64 (what pad_data produces)
+    t = synth_aig(30, 200, 13, seed=11, window=64)
+    t.node_depth = t.node_depth.long()
+    cases["n243_longdepth_k32"] = (t, 32, False)
+    return cases
+
+
+def run_generator(AIGGenerator, state, tpl, K, z, keep):
+    G = AIGGenerator(node_in_dim=2, hidden_dim=128, z_dim=128, candidate_k=K)
+    G.load_state_dict(state)
+    G.eval()
+    rec = {"tgt": [], "cand": [], "logit": []}
+    orig = G._score_candidates
+
+    def spy(h_cond, zz, src_idx, tgt_idx):
+        logits, edge_in = orig(h_cond, zz, src_idx, tgt_idx)
+        if keep:
+            rec["tgt"].append(int(tgt_idx))
+            rec["cand"].append(np_of(src_idx).astype(np.int64))
+            rec["logit"].append(np_of(logits).astype(np.float32))
+            rec["h_cond"] = np_of(h_cond)
+        return logits, edge_in
+
+    G._score_candidates = spy
+    with torch.no_grad():
+        out = G(tpl, z)
+    return out, rec
+
+
+def main():
+    torch.set_num_threads(1)
+    AIGGenerator, C, DP, AIGgan = import_reference()
+
+    # ------------------------------------------------------------------ weights
+    torch.manual_seed(123)
+    G0 = AIGGenerator(node_in_dim=2, hidden_dim=128, z_dim=128, candidate_k=64)
+    state = {k: v.clone() for k, v in G0.state_dict().items()}
+    save("gen_weights", **{k: np_of(v) for k, v in state.items()})
+
+    # ------------------------------------------------------------------ generator + constraints on its output
+    raw_graphs = {}
+    for ci, (name, (tpl, K, keep)) in enumerate(template_cases(DP).items()):
+        print(f"[gen] {name}")
+        g = torch.Generator().manual_seed(1000 + ci)
+        z = torch.randn(128, generator=g)
+        out, rec = run_generator(AIGGenerator, state, tpl, K, z, keep)
+        nd = getattr(tpl, "node_depth", None)
+        arrays = dict(
+            x=np_of(tpl.x), node_depth=None if nd is None else np_of(nd), z=np_of(z),
+            candidate_k=np.int64(K),
+            out_edge_index=np_of(out.edge_index), out_edge_attr=np_of(out.edge_attr), out_x=np_of(out.x),
+        )
+        if keep and rec["tgt"]:
+            arrays["h_cond"] = rec["h_cond"]
+            arrays["rec_tgt"] = np.asarray(rec["tgt"], dtype=np.int64)
+            arrays["rec_off"] = np.cumsum([0] + [len(c) for c in rec["cand"]]).astype(np.int64)
+            arrays["rec_cand"] = np.concatenate(rec["cand"])
+            arrays["rec_logit"] = np.concatenate(rec["logit"])
+        save("gen_" + name, **arrays)
+        raw_graphs["raw_" + name] = out
+
+    # ------------------------------------------------------------------ constraint cases
+    cons = dict(raw_graphs)
+    rng = np.random.default_rng(77)
+    for j in range(24):
+        n = int(rng.integers(3, 60))
+        e = int(rng.integers(0, 4 * n))
+        types_ = rng.choice([0, 1, 2], size=n, p=[0.3, 0.2, 0.5])
+        x = np.stack([types_, rng.integers(0, 3, n)], 1).astype(np.float32)
+        src = rng.integers(0, n, e)
+        dst = rng.integers(0, n, e)
+        if e > 4:  # force some duplicates / self loops
+            src[: e // 6] = src[e // 6: 2 * (e // 6)]
+            dst[: e // 6] = dst[e // 6: 2 * (e // 6)]
+            dst[-1] = src[-1]
+        inv = rng.integers(0, 2, e)
+        d = Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.stack([src, dst]).astype(np.int64)),
+                 edge_attr=torch.from_numpy(inv.astype(np.int64)).view(-1, 1))
+        mode = j % 4
+        if mode == 0:
+            d.node_depth = torch.from_numpy(rng.integers(-1, 6, n).astype(np.int64))
+        elif mode == 1:
+            d.node_depth = torch.from_numpy((rng.random(n) * 6 - 1).astype(np.float32))
+        elif mode == 2:
+            d.node_depth = None
+        # mode 3: attribute absent
+        cons[f"junk{j:02d}"] = d
+    # no PI at all, a single AND, only POs, empty edge list
+    cons["only_and"] = Data(x=torch.tensor([[2, 0], [2, 0], [2, 0], [1, 0]], dtype=torch.float32),
+                            edge_index=torch.tensor([[0, 1, 2, 1], [1, 2, 3, 0]]), edge_attr=torch.tensor([[1], [0], [1], [1]]))
+    cons["no_edges"] = Data(x=torch.tensor([[0, 1], [2, 2], [1, 0]], dtype=torch.float32),
+                            edge_index=torch.zeros((2, 0), dtype=torch.long), edge_attr=torch.zeros((0, 1), dtype=torch.long))
+    cons["one_pi_two_and"] = Data(x=torch.tensor([[0, 0], [2, 0], [2, 0], [1, 0]], dtype=torch.float32),
+                                  edge_index=torch.tensor([[0, 0, 1, 2], [1, 2, 2, 3]]), edge_attr=torch.tensor([[1], [1], [0], [1]]))
+    # a valid AIG in forward orientation (validator should return no violation)
+    v = synth_aig(6, 20, 4, seed=21, window=12)
+    v.edge_attr = v.edge_attr.long()
+    cons["valid_fwd"] = v
+    # out-of-range endpoints (only enforce tolerates them)
+    oob = Data(x=torch.tensor([[0, 0], [0, 0], [2, 0], [2, 0], [1, 0]], dtype=torch.float32),
+               edge_index=torch.tensor([[0, 1, 7, 2, 3, -1, 0], [2, 2, 3, 3, 9, 4, 3]]),
+               edge_attr=torch.tensor([[1], [0], [1], [1], [0], [1], [0]]))
+    cons["oob_enforce_only"] = oob
+
+    for name, d in cons.items():
+        print(f"[cons] {name}")
+        nd = getattr(d, "node_depth", None)
+        arrays = dict(x=np_of(d.x), edge_index=np_of(d.edge_index), edge_attr=np_of(d.edge_attr),
+                      node_depth=None if nd is None else np_of(nd),
+                      has_depth_attr=np.int64(hasattr(d, "node_depth")))
+        if name != "oob_enforce_only":
+            pen = C.aig_constraint_penalties(d.clone())
+            for k, val in pen.items():
+                arrays["pen_" + k] = np.float32(float(val))
+            errs = C.validate_strict_aig(d.clone(), check_all_on_path=True)
+            arrays["val_n"] = np.int64(len(errs))
+            arrays["val_text"] = np.array("\n".join(errs))
+            errs2 = C.validate_strict_aig(d.clone(), check_all_on_path=False)
+            arrays["val_n_nopath"] = np.int64(len(errs2))
+        fixed = C.enforce_aig_constraints(d.clone())
+        arrays.update(enf_edge_index=np_of(fixed.edge_index), enf_edge_attr=np_of(fixed.edge_attr),
+                      enf_node_depth=np_of(fixed.node_depth), enf_x=np_of(fixed.x))
+        pen2 = C.aig_constraint_penalties(fixed.clone())
+        arrays["enf_pen_total"] = np.float32(float(pen2["total"]))
+        errs3 = C.validate_strict_aig(fixed.clone(), check_all_on_path=True)
+        arrays["enf_val_n"] = np.int64(len(errs3))
+        arrays["enf_val_text"] = np.array("\n".join(errs3))
+        rs = AIGgan.resync_attrs(fixed.clone())
+        arrays.update(rs_x=np_of(rs.x), rs_node_depth=np_of(rs.node_depth))
+        save("cons_" + name, **arrays)
+
+    # ------------------------------------------------------------------ pad / unpad
+    t = synth_aig(5, 6, 2, seed=1, window=8, orientation="dataset")
+    p = DP.pad_data(t, 20, 30)
+    u = DP.unpad_data(p)
+    p2 = Data(x=p.x, edge_index=p.edge_index, edge_attr=p.edge_attr, node_depth=p.node_depth)  # lost _orig_*
+    u2 = DP.unpad_data(p2)
+    save("pad_c17", x=np_of(t.x), edge_index=np_of(t.edge_index), edge_attr=np_of(t.edge_attr),
+         node_depth=np_of(t.node_depth),
+         pad_x=np_of(p.x), pad_edge_index=np_of(p.edge_index), pad_edge_attr=np_of(p.edge_attr),
+         pad_node_depth=np_of(p.node_depth),
+         unpad_x=np_of(u.x), unpad_edge_index=np_of(u.edge_index), unpad_edge_attr=np_of(u.edge_attr),
+         unpad_node_depth=np_of(u.node_depth),
+         unpad2_x=np_of(u2.x), unpad2_edge_index=np_of(u2.edge_index))
+
+    # ------------------------------------------------------------------ torch.topk tie table
+    print("[topk] KAT table")
+    rng = np.random.default_rng(5)
+    vals, offs, k1, k2, meta = [], [0], [], [], []
+    level_sets = {0: [0.5], 1: [0.25, 0.75], 2: [-1.0, 0.0, 2.0], 3: list(np.linspace(-1, 1, 9))}
+    for C_ in range(1, 513):
+        for pat in range(5):
+            if pat < 4:
+                row = rng.choice(np.asarray(level_sets[pat], dtype=np.float32), size=C_)
+            else:
+                row = rng.standard_normal(C_).astype(np.float32)
+            row = row.astype(np.float32)
+            t_ = torch.from_numpy(row)
+            i1 = torch.topk(t_, 1, largest=True).indices.numpy()
+            i2 = torch.topk(t_, 2, largest=True).indices.numpy() if C_ >= 2 else np.array([-1, -1])
+            vals.append(row)
+            offs.append(offs[-1] + C_)
+            k1.append(int(i1[0]))
+            k2.append([int(i2[0]), int(i2[1])])
+            meta.append([C_, pat])
+    save("topk_kat", values=np.concatenate(vals), offsets=np.asarray(offs, dtype=np.int64),
+         top1=np.asarray(k1, dtype=np.int64), top2=np.asarray(k2, dtype=np.int64),
+         meta=np.asarray(meta, dtype=np.int64))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
