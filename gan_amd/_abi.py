@@ -1,0 +1,99 @@
+"""ctypes binding of libaig_hip.so (declarations: include/aig_abi.h).
+
+There is no CPU fallback: if the shared library is missing or a tensor is not on a
+HIP device, the call fails with an error instead of computing somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaig_hip.so")
+
+P = C.c_void_p
+I64 = C.c_int64
+SZ = C.c_size_t
+INT = C.c_int
+
+
+class GenWeights(C.Structure):
+    """Mirror of ``aig_gen_weights``."""
+    _fields_ = [(n, P) for n in (
+        "enc0_w", "enc0_b", "enc2_w", "enc2_b", "proj0_w", "proj0_b", "proj2_w", "proj2_b",
+        "sc0_w", "sc0_b", "sc2_w", "sc2_b", "at0_w", "at0_b", "at2_w", "at2_b")]
+
+
+# name -> (restype, argtypes); every symbol of include/aig_abi.h appears here
+SIGNATURES = {
+    "aig_abi_version": (INT, []),
+    "aig_last_error": (C.c_char_p, []),
+    "aig_gen_order_ws_bytes": (SZ, [I64]),
+    "aig_gen_order": (INT, [I64, P, INT, P, P, P, P, P, SZ, P]),
+    "aig_gen_candidates_ws_bytes": (SZ, [I64, I64]),
+    "aig_gen_candidates": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "aig_gen_node_proj_ws_bytes": (SZ, [I64]),
+    "aig_gen_node_proj": (INT, [I64, P, P, C.POINTER(GenWeights), P, P, P, SZ, P]),
+    "aig_gen_score": (INT, [I64, I64, P, P, P, P, P, P, P, P, P]),
+    "aig_topk_select_ws_bytes": (SZ, [I64, I64]),
+    "aig_topk_select": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
+    "aig_gen_emit": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "aig_gat_csr_ws_bytes": (SZ, [I64, I64]),
+    "aig_gat_csr": (INT, [I64, I64] + [P] * 10 + [P, SZ, P]),
+    "aig_gat_fwd": (INT, [I64] + [P] * 14 + [P]),
+    "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
+    "aig_gat_bwd": (INT, [I64, I64] + [P] * 22 + [P, SZ, P]),
+    "aig_level_plan_ws_bytes": (SZ, [I64, I64]),
+    "aig_level_plan": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
+    "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),
+    "aig_level_pool_fwd": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, SZ, P]),
+}
+
+_lib = None
+
+
+class AigAbiError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AigAbiError(
+                f"{LIB_PATH} is missing: the HIP kernels are not built and gan_amd has no other compute path")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().aig_last_error().decode("utf-8", "replace")
+        raise AigAbiError(f"{what or 'libaig_hip'} failed ({rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device address of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AigAbiError("gan_amd kernels take tensors on a HIP device; got a CPU tensor")
+    if not t.is_contiguous():
+        raise AigAbiError("gan_amd kernels take contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -1,0 +1,465 @@
+// Edge-aware graph attention layer of the critic (GATConv with edge_dim=1, heads=4, 32 channels
+// per head, concat) as CSR-by-target gather / segmented-softmax / aggregate kernels, forward and
+// backward.  Everything here is HBM/L2-bound: rows of 512 B are gathered by source id, each target
+// owned by half a wavefront (32 lanes x float4), no floating-point atomics anywhere, so results
+// are bitwise reproducible run to run.
+#include <climits>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace aig {
+namespace {
+
+constexpr int H = AIG_HIDDEN;  // heads * channels = 128
+constexpr int HEADS = 4;
+constexpr int THREADS = 256;
+constexpr int HW_PER_BLOCK = THREADS / 32;  // half-waves (one target each) per block
+constexpr float NEG_SLOPE = 0.2f;
+constexpr float SOFTMAX_EPS = 1e-16f;
+
+// ------------------------------------------------------------------------------------------ CSR
+__global__ void k_csr_keys(int n, int E, const long long* __restrict__ ei, unsigned* __restrict__ key, int* __restrict__ ids) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        long long s = ei[e], d = ei[(size_t)E + e];
+        bool ok = s != d && s >= 0 && s < n && d >= 0 && d < n;  // self loops are replaced, strays dropped
+        key[e] = ok ? (unsigned)d : (unsigned)n;
+        ids[e] = e;
+    }
+}
+
+__device__ __forceinline__ int lower_bound_u(const unsigned* __restrict__ a, int len, unsigned v) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_csr_ptr(int n, int E, const unsigned* __restrict__ sorted_key, int* __restrict__ ptr) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += gridDim.x * blockDim.x)
+        ptr[v] = lower_bound_u(sorted_key, E, (unsigned)v);
+}
+
+__global__ void k_csr_fill(int n, int E, const long long* __restrict__ ei, const float* __restrict__ ea,
+                           const unsigned* __restrict__ sorted_key, const int* __restrict__ sorted_eid,
+                           int* __restrict__ csr_src, float* __restrict__ csr_ea, int* __restrict__ csr_eid,
+                           unsigned* __restrict__ key_src, int* __restrict__ ids) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E; p += gridDim.x * blockDim.x) {
+        unsigned k = sorted_key[p];
+        int eid = sorted_eid[p];
+        unsigned ks = (unsigned)n;
+        if (k < (unsigned)n) {
+            int s = (int)ei[eid];
+            csr_src[p] = s;
+            csr_ea[p] = ea ? ea[eid] : 0.f;
+            csr_eid[p] = eid;
+            ks = (unsigned)s;
+        }
+        key_src[p] = ks;
+        ids[p] = p;
+    }
+}
+
+__global__ void k_csc_fill(int E, const int* __restrict__ row_ptr_n, const unsigned* __restrict__ sorted_dst,
+                           const int* __restrict__ csc_pos, int* __restrict__ csc_dst) {
+    const int ek = row_ptr_n[0];
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < ek; q += gridDim.x * blockDim.x)
+        csc_dst[q] = (int)sorted_dst[csc_pos[q]];
+}
+
+// self-loop attribute = mean attribute of the edges entering the node (add_self_loops fill 'mean')
+__global__ void k_loop_attr(int n, const int* __restrict__ row_ptr, const float* __restrict__ csr_ea,
+                            float* __restrict__ loop_ea) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        int b = row_ptr[v], e = row_ptr[v + 1];
+        float s = 0.f;
+        for (int p = b; p < e; ++p) s += csr_ea[p];
+        loop_ea[v] = e > b ? s / (float)(e - b) : 0.f;
+    }
+}
+
+int key_bits(int64_t n) {
+    int b = 1;
+    while ((1ll << b) <= n) ++b;
+    return b;
+}
+
+size_t sort_temp_bytes(int64_t E, int bits) {
+    size_t bytes = 0;
+    unsigned* k = nullptr;
+    int* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)E, 0, bits, hipStream_t(0));
+    return bytes;
+}
+
+// ------------------------------------------------------------------------------------------ block -> node range
+// Blocks b, b+8, b+16, ... share an XCD (and its L2) under round-robin dispatch, so logical block
+// ids are dealt such that one XCD walks one contiguous eighth of the nodes.  Affinity only.
+__device__ __forceinline__ int logical_block(int b, int nb) { return (b & 7) * (nb >> 3) + (b >> 3); }
+
+struct NodeRange {
+    int begin, end;
+};
+__device__ __forceinline__ NodeRange block_nodes(int n) {
+    int nb = gridDim.x;  // multiple of 8
+    int lb = logical_block(blockIdx.x, nb);
+    int chunk = (n + nb - 1) / nb;
+    int b = lb * chunk, e = min(n, b + chunk);
+    return {b, e};
+}
+
+__device__ __forceinline__ float head_sum(float v) {  // sum over the 8 lanes of one head, result in all 8
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : NEG_SLOPE * x; }
+
+// a_s[i,h] = <xw[i,h,:], att_src[h,:]>, a_d likewise
+__global__ __launch_bounds__(THREADS) void k_gat_node_alpha(int n, const float* __restrict__ xw,
+                                                            const float* __restrict__ att_src,
+                                                            const float* __restrict__ att_dst,
+                                                            float* __restrict__ a_s, float* __restrict__ a_d) {
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    const float4 as4 = reinterpret_cast<const float4*>(att_src)[l], ad4 = reinterpret_cast<const float4*>(att_dst)[l];
+    NodeRange r = block_nodes(n);
+    for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
+        float4 x = reinterpret_cast<const float4*>(xw + (size_t)i * H)[l];
+        float s = head_sum(dot4(x, as4)), d = head_sum(dot4(x, ad4));
+        if ((l & 7) == 0) {
+            a_s[i * HEADS + h] = s;
+            a_d[i * HEADS + h] = d;
+        }
+    }
+}
+
+// out[i] = elu( sum_e alpha_e * xw[src_e] + bias ),  alpha = softmax_e leaky_relu(a_s[src]+a_d[i]+ea*ce)
+// over the edges entering i plus its self loop (taken last).  alpha is kept for the backward pass.
+__global__ __launch_bounds__(THREADS) void k_gat_aggregate(
+    int n, const float* __restrict__ xw, const float* __restrict__ a_s, const float* __restrict__ a_d,
+    const float* __restrict__ ce, const float* __restrict__ bias, const int* __restrict__ row_ptr,
+    const int* __restrict__ csr_src, const float* __restrict__ csr_ea, const float* __restrict__ loop_ea,
+    float* __restrict__ out, float* __restrict__ alpha_e, float* __restrict__ alpha_loop) {
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    const float ceh = ce[h];
+    const float4 b4 = reinterpret_cast<const float4*>(bias)[l];
+    const float4* xw4 = reinterpret_cast<const float4*>(xw);
+    NodeRange r = block_nodes(n);
+    for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
+        const int beg = row_ptr[i], end = row_ptr[i + 1];
+        const float adi = a_d[i * HEADS + h];
+        const float e_loop = lrelu(a_s[i * HEADS + h] + adi + loop_ea[i] * ceh);
+        float m = e_loop;
+        for (int p = beg; p < end; ++p) m = fmaxf(m, lrelu(a_s[csr_src[p] * HEADS + h] + adi + csr_ea[p] * ceh));
+        float den = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = beg;
+        for (; p + 4 <= end; p += 4) {  // four row gathers in flight
+            int s0 = csr_src[p], s1 = csr_src[p + 1], s2 = csr_src[p + 2], s3 = csr_src[p + 3];
+            float4 r0 = xw4[(size_t)s0 * 32 + l], r1 = xw4[(size_t)s1 * 32 + l], r2 = xw4[(size_t)s2 * 32 + l],
+                   r3 = xw4[(size_t)s3 * 32 + l];
+            float w0 = expf(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m);
+            float w1 = expf(lrelu(a_s[s1 * HEADS + h] + adi + csr_ea[p + 1] * ceh) - m);
+            float w2 = expf(lrelu(a_s[s2 * HEADS + h] + adi + csr_ea[p + 2] * ceh) - m);
+            float w3 = expf(lrelu(a_s[s3 * HEADS + h] + adi + csr_ea[p + 3] * ceh) - m);
+            den += w0; acc.x += w0 * r0.x; acc.y += w0 * r0.y; acc.z += w0 * r0.z; acc.w += w0 * r0.w;
+            den += w1; acc.x += w1 * r1.x; acc.y += w1 * r1.y; acc.z += w1 * r1.z; acc.w += w1 * r1.w;
+            den += w2; acc.x += w2 * r2.x; acc.y += w2 * r2.y; acc.z += w2 * r2.z; acc.w += w2 * r2.w;
+            den += w3; acc.x += w3 * r3.x; acc.y += w3 * r3.y; acc.z += w3 * r3.z; acc.w += w3 * r3.w;
+        }
+        {   // tail of up to three edges and the self loop, loads issued together
+            const int rem = end - p;
+            int s0 = rem > 0 ? csr_src[p] : i, s1 = rem > 1 ? csr_src[p + 1] : i, s2 = rem > 2 ? csr_src[p + 2] : i;
+            float4 r0 = xw4[(size_t)s0 * 32 + l], r1 = xw4[(size_t)s1 * 32 + l], r2 = xw4[(size_t)s2 * 32 + l],
+                   rl = xw4[(size_t)i * 32 + l];
+            float w0 = rem > 0 ? expf(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m) : 0.f;
+            float w1 = rem > 1 ? expf(lrelu(a_s[s1 * HEADS + h] + adi + csr_ea[p + 1] * ceh) - m) : 0.f;
+            float w2 = rem > 2 ? expf(lrelu(a_s[s2 * HEADS + h] + adi + csr_ea[p + 2] * ceh) - m) : 0.f;
+            float wl = expf(e_loop - m);
+            den += w0; acc.x += w0 * r0.x; acc.y += w0 * r0.y; acc.z += w0 * r0.z; acc.w += w0 * r0.w;
+            den += w1; acc.x += w1 * r1.x; acc.y += w1 * r1.y; acc.z += w1 * r1.z; acc.w += w1 * r1.w;
+            den += w2; acc.x += w2 * r2.x; acc.y += w2 * r2.y; acc.z += w2 * r2.z; acc.w += w2 * r2.w;
+            den += wl; acc.x += wl * rl.x; acc.y += wl * rl.y; acc.z += wl * rl.z; acc.w += wl * rl.w;
+        }
+        const float inv = 1.f / (den + SOFTMAX_EPS);
+        float4 o;
+        o.x = acc.x * inv + b4.x; o.y = acc.y * inv + b4.y; o.z = acc.z * inv + b4.z; o.w = acc.w * inv + b4.w;
+        o.x = o.x > 0.f ? o.x : expm1f(o.x); o.y = o.y > 0.f ? o.y : expm1f(o.y);
+        o.z = o.z > 0.f ? o.z : expm1f(o.z); o.w = o.w > 0.f ? o.w : expm1f(o.w);
+        reinterpret_cast<float4*>(out + (size_t)i * H)[l] = o;
+        if ((l & 7) == 0) {  // attention coefficients, one per head
+            for (int q = beg; q < end; ++q)
+                alpha_e[(size_t)q * HEADS + h] = expf(lrelu(a_s[csr_src[q] * HEADS + h] + adi + csr_ea[q] * ceh) - m) * inv;
+            alpha_loop[i * HEADS + h] = expf(e_loop - m) * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// Target side.  g = g_out * elu'(out);  dalpha_e = <g_h, xw[src_e]_h>;  softmax and leaky-relu
+// derivatives give d_raw_e (per edge and head) and d_a_d[i]; per-block partial sums of g (bias
+// gradient) and of d_raw*ea (edge-coefficient gradient) go to `partial`.
+__global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
+    int n, const float* __restrict__ g_out, const float* __restrict__ out, const float* __restrict__ xw,
+    const float* __restrict__ a_s, const float* __restrict__ a_d, const float* __restrict__ ce,
+    const int* __restrict__ row_ptr, const int* __restrict__ csr_src, const float* __restrict__ csr_ea,
+    const float* __restrict__ loop_ea, const float* __restrict__ alpha_e, const float* __restrict__ alpha_loop,
+    float* __restrict__ g_pre, float* __restrict__ d_raw_e, float* __restrict__ d_raw_loop,
+    float* __restrict__ d_a_d, float* __restrict__ partial /*[grid][H + HEADS]*/) {
+    __shared__ float red[HW_PER_BLOCK][H + HEADS];
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    const float ceh = ce[h];
+    const float4* xw4 = reinterpret_cast<const float4*>(xw);
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dce = 0.f;
+    NodeRange r = block_nodes(n);
+    for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
+        float4 o = reinterpret_cast<const float4*>(out + (size_t)i * H)[l];
+        float4 g = reinterpret_cast<const float4*>(g_out + (size_t)i * H)[l];
+        g.x *= o.x > 0.f ? 1.f : o.x + 1.f; g.y *= o.y > 0.f ? 1.f : o.y + 1.f;
+        g.z *= o.z > 0.f ? 1.f : o.z + 1.f; g.w *= o.w > 0.f ? 1.f : o.w + 1.f;
+        reinterpret_cast<float4*>(g_pre + (size_t)i * H)[l] = g;
+        gsum.x += g.x; gsum.y += g.y; gsum.z += g.z; gsum.w += g.w;
+        const int beg = row_ptr[i], end = row_ptr[i + 1];
+        const float adi = a_d[i * HEADS + h];
+        // pass A: sdot = sum_e alpha_e * dalpha_e (self loop included)
+        const float al_loop = alpha_loop[i * HEADS + h];
+        const float da_loop = head_sum(dot4(g, xw4[(size_t)i * 32 + l]));
+        float sdot = al_loop * da_loop;
+        for (int p = beg; p < end; ++p) {
+            float da = head_sum(dot4(g, xw4[(size_t)csr_src[p] * 32 + l]));
+            sdot += alpha_e[(size_t)p * HEADS + h] * da;
+        }
+        // pass B: d_raw = alpha (dalpha - sdot) * lrelu'(raw)
+        float dad = 0.f;
+        for (int p = beg; p < end; ++p) {
+            const int s = csr_src[p];
+            float da = head_sum(dot4(g, xw4[(size_t)s * 32 + l]));
+            float raw = a_s[s * HEADS + h] + adi + csr_ea[p] * ceh;
+            float dr = alpha_e[(size_t)p * HEADS + h] * (da - sdot) * (raw > 0.f ? 1.f : NEG_SLOPE);
+            dad += dr;
+            dce += (l & 7) == 0 ? dr * csr_ea[p] : 0.f;
+            if ((l & 7) == 0) d_raw_e[(size_t)p * HEADS + h] = dr;
+        }
+        {
+            float raw = a_s[i * HEADS + h] + adi + loop_ea[i] * ceh;
+            float dr = al_loop * (da_loop - sdot) * (raw > 0.f ? 1.f : NEG_SLOPE);
+            dad += dr;
+            dce += (l & 7) == 0 ? dr * loop_ea[i] : 0.f;
+            if ((l & 7) == 0) {
+                d_raw_loop[i * HEADS + h] = dr;
+                d_a_d[i * HEADS + h] = dad;
+            }
+        }
+    }
+    // block partials, summed over the 8 half-waves in fixed order
+    reinterpret_cast<float4*>(&red[hw][0])[l] = gsum;
+    if ((l & 7) == 0) red[hw][H + h] = dce;
+    __syncthreads();
+    if (threadIdx.x < H + HEADS) {
+        float s = 0.f;
+        for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
+        partial[(size_t)blockIdx.x * (H + HEADS) + threadIdx.x] = s;
+    }
+}
+
+// Source side.  d_xw[j] = sum_{e: src=j} alpha_e g_pre[dst_e] + alpha_loop g_pre[j]
+//                        + d_a_s[j] att_src + d_a_d[j] att_dst,   d_a_s[j] = sum d_raw over out-edges.
+// Per-block partials of d_att_src / d_att_dst follow the same pattern as above.
+__global__ __launch_bounds__(THREADS) void k_gat_bwd_src(
+    int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
+    const float* __restrict__ att_dst, const int* __restrict__ col_ptr, const int* __restrict__ csc_pos,
+    const int* __restrict__ csc_dst, const float* __restrict__ alpha_e, const float* __restrict__ alpha_loop,
+    const float* __restrict__ d_raw_e, const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d,
+    float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
+    __shared__ float red[HW_PER_BLOCK][2 * H];
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    const float4 as4 = reinterpret_cast<const float4*>(att_src)[l], ad4 = reinterpret_cast<const float4*>(att_dst)[l];
+    const float4* g4 = reinterpret_cast<const float4*>(g_pre);
+    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
+    NodeRange r = block_nodes(n);
+    for (int j = r.begin + hw; j < r.end; j += HW_PER_BLOCK) {
+        const int beg = col_ptr[j], end = col_ptr[j + 1];
+        float das = d_raw_loop[j * HEADS + h];
+        const float al = alpha_loop[j * HEADS + h];
+        float4 gj = g4[(size_t)j * 32 + l];
+        float4 acc = make_float4(al * gj.x, al * gj.y, al * gj.z, al * gj.w);
+        int q = beg;
+        for (; q + 2 <= end; q += 2) {
+            int p0 = csc_pos[q], p1 = csc_pos[q + 1];
+            float4 r0 = g4[(size_t)csc_dst[q] * 32 + l], r1 = g4[(size_t)csc_dst[q + 1] * 32 + l];
+            float a0 = alpha_e[(size_t)p0 * HEADS + h], a1 = alpha_e[(size_t)p1 * HEADS + h];
+            das += d_raw_e[(size_t)p0 * HEADS + h];
+            das += d_raw_e[(size_t)p1 * HEADS + h];
+            acc.x += a0 * r0.x; acc.y += a0 * r0.y; acc.z += a0 * r0.z; acc.w += a0 * r0.w;
+            acc.x += a1 * r1.x; acc.y += a1 * r1.y; acc.z += a1 * r1.z; acc.w += a1 * r1.w;
+        }
+        if (q < end) {
+            int p0 = csc_pos[q];
+            float4 r0 = g4[(size_t)csc_dst[q] * 32 + l];
+            float a0 = alpha_e[(size_t)p0 * HEADS + h];
+            das += d_raw_e[(size_t)p0 * HEADS + h];
+            acc.x += a0 * r0.x; acc.y += a0 * r0.y; acc.z += a0 * r0.z; acc.w += a0 * r0.w;
+        }
+        const float dad = d_a_d[j * HEADS + h];
+        acc.x += das * as4.x + dad * ad4.x; acc.y += das * as4.y + dad * ad4.y;
+        acc.z += das * as4.z + dad * ad4.z; acc.w += das * as4.w + dad * ad4.w;
+        reinterpret_cast<float4*>(d_xw + (size_t)j * H)[l] = acc;
+        float4 x = reinterpret_cast<const float4*>(xw + (size_t)j * H)[l];
+        ps.x += das * x.x; ps.y += das * x.y; ps.z += das * x.z; ps.w += das * x.w;
+        pd.x += dad * x.x; pd.y += dad * x.y; pd.z += dad * x.z; pd.w += dad * x.w;
+    }
+    reinterpret_cast<float4*>(&red[hw][0])[l] = ps;
+    reinterpret_cast<float4*>(&red[hw][H])[l] = pd;
+    __syncthreads();
+    {
+        float s = 0.f;
+        for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
+        partial[(size_t)blockIdx.x * (2 * H) + threadIdx.x] = s;
+    }
+}
+
+// out[c] = sum_b partial[b][c], b ascending
+__global__ void k_reduce_cols(int nb, int width, const float* __restrict__ partial, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * width + c];
+    out[c] = s;
+}
+
+int grid_blocks(int64_t n) {
+    int64_t g = (n + 63) / 64;         // at least 8 targets per half-wave before adding blocks
+    g = (g + 7) / 8 * 8;
+    if (g > 2048) g = 2048;
+    if (g < 8) g = 8;
+    return (int)g;
+}
+
+}  // namespace
+}  // namespace aig
+
+using namespace aig;
+
+extern "C" size_t aig_gat_csr_ws_bytes(int64_t n, int64_t E) {
+    if (E <= 0) return 256;
+    return 4 * align_up((size_t)E * 4) + align_up(sort_temp_bytes(E, key_bits(n))) + 256;
+}
+
+extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_attr,
+                           int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
+                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, void* ws, size_t ws_bytes,
+                           void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0 && E < INT_MAX, "aig_gat_csr: bad sizes n=%lld E=%lld", (long long)n,
+                (long long)E);
+    AIG_REQUIRE(row_ptr && col_ptr && (n == 0 || loop_ea), "aig_gat_csr: null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (E == 0) {
+        AIG_HIP_CHECK(hipMemsetAsync(row_ptr, 0, (size_t)(n + 1) * 4, s));
+        AIG_HIP_CHECK(hipMemsetAsync(col_ptr, 0, (size_t)(n + 1) * 4, s));
+        if (n) AIG_HIP_CHECK(hipMemsetAsync(loop_ea, 0, (size_t)n * 4, s));
+        return AIG_OK;
+    }
+    AIG_REQUIRE(edge_index && csr_src && csr_ea && csr_eid && csc_pos && csc_dst && ws, "aig_gat_csr: null pointer");
+    if (ws_bytes < aig_gat_csr_ws_bytes(n, E))
+        return fail(AIG_EWORKSPACE, "aig_gat_csr: workspace %zu < %zu", ws_bytes, aig_gat_csr_ws_bytes(n, E));
+    const int bits = key_bits(n);
+    Carver c(ws);
+    unsigned* key = c.take<unsigned>(E);
+    unsigned* skey = c.take<unsigned>(E);
+    int* ids = c.take<int>(E);
+    int* seid = c.take<int>(E);
+    size_t tb = sort_temp_bytes(E, bits);
+    void* temp = c.take<char>(tb);
+    const int g = grid_for(E, 256, 4096), gn = grid_for(n + 1, 256, 4096);
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    hipLaunchKernelGGL(k_csr_keys, dim3(g), dim3(256), 0, s, (int)n, (int)E, ei, key, ids);
+    AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, seid, (size_t)E, 0, bits, s));
+    hipLaunchKernelGGL(k_csr_ptr, dim3(gn), dim3(256), 0, s, (int)n, (int)E, skey, row_ptr);
+    // key <- source of each kept edge (in target-sorted order), ids <- that position
+    hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, (int)n, (int)E, ei, edge_attr, skey, seid, csr_src, csr_ea,
+                       csr_eid, key, ids);
+    AIG_LAUNCH_CHECK();
+    // seid is free again: reuse it for the sorted source keys
+    unsigned* ssrc = reinterpret_cast<unsigned*>(seid);
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, ssrc, ids, csc_pos, (size_t)E, 0, bits, s));
+    hipLaunchKernelGGL(k_csr_ptr, dim3(gn), dim3(256), 0, s, (int)n, (int)E, ssrc, col_ptr);
+    hipLaunchKernelGGL(k_csc_fill, dim3(g), dim3(256), 0, s, (int)E, row_ptr + n, skey, csc_pos, csc_dst);
+    hipLaunchKernelGGL(k_loop_attr, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, (int)n, row_ptr, csr_ea, loop_ea);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* att_src, const float* att_dst, const float* ce,
+                           const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                           const float* loop_ea, float* a_s, float* a_d, float* out, float* alpha_e,
+                           float* alpha_loop, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat_fwd: n=%lld out of range", (long long)n);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(xw && att_src && att_dst && ce && bias && row_ptr && loop_ea && a_s && a_d && out && alpha_loop,
+                "aig_gat_fwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int g = grid_blocks(n);
+    hipLaunchKernelGGL(k_gat_node_alpha, dim3(g), dim3(THREADS), 0, s, (int)n, xw, att_src, att_dst, a_s, a_d);
+    hipLaunchKernelGGL(k_gat_aggregate, dim3(g), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d, ce, bias, row_ptr, csr_src,
+                       csr_ea, loop_ea, out, alpha_e, alpha_loop);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {
+    return align_up((size_t)(n > 0 ? n : 1) * H * 4) /*g_pre*/ + align_up((size_t)(E > 0 ? E : 1) * HEADS * 4) +
+           2 * align_up((size_t)(n > 0 ? n : 1) * HEADS * 4) + align_up((size_t)2049 * 2 * H * 4) + 256;
+}
+
+extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
+                           const float* att_src, const float* att_dst, const float* ce, const float* a_s,
+                           const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                           const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
+                           const int32_t* csc_dst, const float* alpha_e, const float* alpha_loop, float* d_xw,
+                           float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, void* ws,
+                           size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0, "aig_gat_bwd: bad sizes");
+    AIG_REQUIRE(d_att_src && d_att_dst && d_ce && d_bias, "aig_gat_bwd: null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        AIG_HIP_CHECK(hipMemsetAsync(d_att_src, 0, H * 4, s));
+        AIG_HIP_CHECK(hipMemsetAsync(d_att_dst, 0, H * 4, s));
+        AIG_HIP_CHECK(hipMemsetAsync(d_ce, 0, HEADS * 4, s));
+        AIG_HIP_CHECK(hipMemsetAsync(d_bias, 0, H * 4, s));
+        return AIG_OK;
+    }
+    AIG_REQUIRE(g_out && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
+                    alpha_loop && d_xw && ws,
+                "aig_gat_bwd: null pointer");
+    if (ws_bytes < aig_gat_bwd_ws_bytes(n, E))
+        return fail(AIG_EWORKSPACE, "aig_gat_bwd: workspace %zu < %zu", ws_bytes, aig_gat_bwd_ws_bytes(n, E));
+    Carver c(ws);
+    float* g_pre = c.take<float>((size_t)n * H);
+    float* d_raw_e = c.take<float>((size_t)(E > 0 ? E : 1) * HEADS);
+    float* d_raw_loop = c.take<float>((size_t)n * HEADS);
+    float* d_a_d = c.take<float>((size_t)n * HEADS);
+    float* partial = c.take<float>((size_t)2049 * 2 * H);
+    const int g = grid_blocks(n);
+    hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
+                       csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial);
+    AIG_LAUNCH_CHECK();
+    // bias gradient = first H columns, edge-coefficient gradient = last HEADS columns
+    hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(H + HEADS), 0, s, g, H + HEADS, partial, partial + (size_t)g * (H + HEADS));
+    AIG_HIP_CHECK(hipMemcpyAsync(d_bias, partial + (size_t)g * (H + HEADS), H * 4, hipMemcpyDeviceToDevice, s));
+    AIG_HIP_CHECK(hipMemcpyAsync(d_ce, partial + (size_t)g * (H + HEADS) + H, HEADS * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_gat_bwd_src, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, col_ptr,
+                       csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw, partial);
+    AIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(2 * H), 0, s, g, 2 * H, partial, partial + (size_t)g * 2 * H);
+    AIG_HIP_CHECK(hipMemcpyAsync(d_att_src, partial + (size_t)g * 2 * H, H * 4, hipMemcpyDeviceToDevice, s));
+    AIG_HIP_CHECK(hipMemcpyAsync(d_att_dst, partial + (size_t)g * 2 * H + H, H * 4, hipMemcpyDeviceToDevice, s));
+    return AIG_OK;
+}

@@ -1,0 +1,362 @@
+// Generator wiring kernels: candidate scores, tie-exact top-k select, edge assembly.
+#include <climits>
+
+#include "common.h"
+
+namespace aig {
+namespace {
+
+constexpr int H = AIG_HIDDEN;
+
+// ------------------------------------------------------------------------------------------ scores
+// One wave per slot; lane i scores candidate i (and i+64, ... for wider windows):
+//   logit = b2 + sum_j w2[j] * relu(A[cand][j] + B[target][j]),   j ascending.
+// The target row and w2 are wave-uniform, so they come through scalar loads; every candidate row
+// runs the same instruction sequence, hence equal candidate rows give bit-equal logits.
+__global__ __launch_bounds__(256) void k_score(int n, int K, const int* __restrict__ order,
+                                               const int* __restrict__ cnt, const int* __restrict__ cand,
+                                               const float* __restrict__ A, const float* __restrict__ B,
+                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                               float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    int r = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (r >= n) return;
+    const int c = cnt[r];
+    if (c <= 0) return;
+    const int v = __builtin_amdgcn_readfirstlane(order[r]);
+    const float4* Bv = reinterpret_cast<const float4*>(B + static_cast<size_t>(v) * H);
+    const float4* W = reinterpret_cast<const float4*>(w2);
+    const float bias = b2[0];
+    const size_t row0 = static_cast<size_t>(r) * K;
+    for (int base = 0; base < c; base += 64) {
+        const int i = base + lane;
+        const bool active = i < c;
+        const int ci = cand[row0 + (active ? i : 0)];
+        const float4* Ar = reinterpret_cast<const float4*>(A + static_cast<size_t>(ci) * H);
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < H / 4; ++j) {
+            float4 a = Ar[j], b = Bv[j], w = W[j];
+            acc = fmaf(fmaxf(a.x + b.x, 0.f), w.x, acc);
+            acc = fmaf(fmaxf(a.y + b.y, 0.f), w.y, acc);
+            acc = fmaf(fmaxf(a.z + b.z, 0.f), w.z, acc);
+            acc = fmaf(fmaxf(a.w + b.w, 0.f), w.w, acc);
+        }
+        if (active) logits[row0 + i] = acc + bias;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ select
+// ATen's CPU top-k comparator (largest=True): NaN ranks first, then the larger value.
+__device__ __forceinline__ bool gt(float x, float y) { return (isnan(x) && !isnan(y)) || (x > y); }
+
+// Per-thread view of a row while std::nth_element's steps are replayed on it.  Only the permutation
+// moves: position p holds the original index idx[p]; values stay put.  Both live in LDS, laid out
+// [element][thread] so that neighbouring threads touch neighbouring banks.
+template <int STRIDE>
+struct RowView {
+    unsigned char* idx;  // idx[p * STRIDE]
+    const float* val;    // val[i * (STRIDE + 1)]  (padded against the transposing fill)
+    __device__ __forceinline__ int I(int p) const { return idx[p * STRIDE]; }
+    __device__ __forceinline__ float V(int p) const { return val[I(p) * (STRIDE + 1)]; }
+    __device__ __forceinline__ float Vi(int i) const { return val[i * (STRIDE + 1)]; }
+    __device__ __forceinline__ void set(int p, int i) { idx[p * STRIDE] = static_cast<unsigned char>(i); }
+    __device__ __forceinline__ void swap(int p, int q) {
+        int a = I(p), b = I(q);
+        set(p, b);
+        set(q, a);
+    }
+};
+
+// libstdc++ heap primitives on positions [first, first+len), value carried as an original index
+template <int S>
+__device__ void push_heap_(RowView<S>& q, int first, int hole, int top, int vi) {
+    const float vv = q.Vi(vi);
+    int parent = (hole - 1) / 2;
+    while (hole > top && gt(q.V(first + parent), vv)) {
+        q.set(first + hole, q.I(first + parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    q.set(first + hole, vi);
+}
+template <int S>
+__device__ void adjust_heap_(RowView<S>& q, int first, int hole, int len, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (gt(q.V(first + child), q.V(first + child - 1))) --child;
+        q.set(first + hole, q.I(first + child));
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        q.set(first + hole, q.I(first + child - 1));
+        hole = child - 1;
+    }
+    push_heap_(q, first, hole, top, vi);
+}
+template <int S>
+__device__ void heap_select_(RowView<S>& q, int first, int middle, int last) {
+    const int len = middle - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            int vi = q.I(first + parent);
+            adjust_heap_(q, first, parent, len, vi);
+            if (parent == 0) break;
+            --parent;
+        }
+    }
+    for (int i = middle; i < last; ++i) {
+        if (gt(q.V(i), q.V(first))) {  // pop_heap(first, middle, i)
+            int vi = q.I(i);
+            q.set(i, q.I(first));
+            adjust_heap_(q, first, 0, len, vi);
+        }
+    }
+}
+
+// std::nth_element(first=0, nth, last=c) of libstdc++: introselect with median-of-three pivots,
+// a depth limit of 2*floor(log2 c) that falls back to heap-select, and a final insertion sort on
+// ranges of at most three elements.
+template <int S>
+__device__ void nth_element_(RowView<S>& q, int nth, int c) {
+    int first = 0, last = c;
+    int depth = 2 * (31 - __clz(c));
+    while (last - first > 3) {
+        if (depth == 0) {
+            heap_select_(q, first, nth + 1, last);
+            q.swap(first, nth);
+            return;
+        }
+        --depth;
+        // median of (first+1, mid, last-1) moved to first
+        const int a = first + 1, b = first + (last - first) / 2, cpos = last - 1;
+        const float va = q.V(a), vb = q.V(b), vc = q.V(cpos);
+        int m;
+        if (gt(va, vb)) m = gt(vb, vc) ? b : (gt(va, vc) ? cpos : a);
+        else m = gt(va, vc) ? a : (gt(vb, vc) ? cpos : b);
+        q.swap(first, m);
+        // unguarded partition of [first+1, last) around the pivot at first
+        const float pv = q.V(first);
+        int lo = first + 1, hi = last;
+        while (true) {
+            while (gt(q.V(lo), pv)) ++lo;
+            --hi;
+            while (gt(pv, q.V(hi))) --hi;
+            if (!(lo < hi)) break;
+            q.swap(lo, hi);
+            ++lo;
+        }
+        if (lo <= nth) first = lo; else last = lo;
+    }
+    // insertion sort of [first, last)
+    for (int i = first + 1; i < last; ++i) {
+        const int vi = q.I(i);
+        const float vv = q.Vi(vi);
+        if (gt(vv, q.V(first))) {
+            for (int p = i; p > first; --p) q.set(p, q.I(p - 1));
+            q.set(first, vi);
+        } else {
+            int p = i;
+            while (gt(vv, q.V(p - 1))) {
+                q.set(p, q.I(p - 1));
+                --p;
+            }
+            q.set(p, vi);
+        }
+    }
+}
+
+// One thread per row.  Rows with k*64 <= c replay std::partial_sort, whose heap of k <= 2 entries
+// fits in registers and whose scan never re-reads a displaced element; shorter rows (c < 128)
+// replay std::nth_element on an LDS copy.
+constexpr int SEL_THREADS = 128;
+constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets two blocks share a CU
+
+__global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, const float* __restrict__ logits,
+                                                             const int* __restrict__ cnt,
+                                                             const int* __restrict__ want, int* __restrict__ sel) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* val = reinterpret_cast<float*>(smem);                               // [SEL_CAP][SEL_THREADS+1]
+    unsigned char* idx = smem + SEL_CAP * (SEL_THREADS + 1) * sizeof(float);   // [SEL_CAP][SEL_THREADS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row_base = blockIdx.x * SEL_THREADS;
+
+    // cooperative fill: each wave copies the short rows of its own 64 threads, coalesced along the row
+    for (int t = 0; t < 64; ++t) {
+        const int slot = wave * 64 + t, r = row_base + slot;
+        if (r >= rows) break;
+        const int c = cnt[r], k = min(want[r], c);
+        if (k <= 0 || k * 64 <= c) continue;
+        for (int j = lane; j < c; j += 64) val[j * (SEL_THREADS + 1) + slot] = logits[static_cast<size_t>(r) * ld + j];
+    }
+    __syncthreads();
+
+    const int r = row_base + tid;
+    if (r >= rows) return;
+    const int c = cnt[r], k = min(want[r], c);
+    int s0 = -1, s1 = -1;
+    if (k > 0) {
+        if (k * 64 <= c) {
+            const float* row = logits + static_cast<size_t>(r) * ld;
+            if (k == 1) {
+                // heap of one: an element replaces the top only when strictly ahead of it
+                int top = 0;
+                float tv = row[0];
+                for (int i = 1; i < c; ++i) {
+                    float v = row[i];
+                    if (gt(v, tv)) { top = i; tv = v; }
+                }
+                s0 = top;
+            } else {
+                // heap of two kept as (top, other): top is the entry every newcomer is compared with
+                int top, oth;
+                float tv, ov;
+                {   // make_heap on positions 0,1
+                    float v0 = row[0], v1 = row[1];
+                    if (gt(v1, v0)) { top = 0; tv = v0; oth = 1; ov = v1; }
+                    else { top = 1; tv = v1; oth = 0; ov = v0; }
+                }
+                for (int i = 2; i < c; ++i) {
+                    float v = row[i];
+                    if (gt(v, tv)) {  // pop_heap: newcomer and the old `other` re-form the heap
+                        if (gt(ov, v)) { top = i; tv = v; }
+                        else { top = oth; tv = ov; oth = i; ov = v; }
+                    }
+                }
+                s0 = oth;  // sort_heap moves the top to the back
+                s1 = top;
+            }
+        } else {
+            RowView<SEL_THREADS> q{idx + tid, val + tid};
+            for (int j = 0; j < c; ++j) q.set(j, j);
+            nth_element_(q, k - 1, c);
+            // std::sort of the first k-1 <= 1 elements changes nothing
+            s0 = q.I(0);
+            if (k == 2) s1 = q.I(1);
+        }
+    }
+    sel[2 * r] = s0;
+    sel[2 * r + 1] = s1;
+}
+
+constexpr size_t SEL_LDS = SEL_CAP * (SEL_THREADS + 1) * sizeof(float) + SEL_CAP * SEL_THREADS;
+
+// ------------------------------------------------------------------------------------------ emit
+__device__ __forceinline__ int inv_bit(const float* __restrict__ A2, const float* __restrict__ B2,
+                                       const float* __restrict__ w, float bias, int s, int v) {
+    const float4* a = reinterpret_cast<const float4*>(A2 + static_cast<size_t>(s) * H);
+    const float4* b = reinterpret_cast<const float4*>(B2 + static_cast<size_t>(v) * H);
+    const float4* ww = reinterpret_cast<const float4*>(w);
+    float acc = 0.f;
+    for (int j = 0; j < H / 4; ++j) {
+        float4 x = a[j], y = b[j], z = ww[j];
+        acc = fmaf(fmaxf(x.x + y.x, 0.f), z.x, acc);
+        acc = fmaf(fmaxf(x.y + y.y, 0.f), z.y, acc);
+        acc = fmaf(fmaxf(x.z + y.z, 0.f), z.z, acc);
+        acc = fmaf(fmaxf(x.w + y.w, 0.f), z.w, acc);
+    }
+    return (acc + bias) > 0.f ? 1 : 0;  // sigmoid(l) > 0.5
+}
+
+__global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, const int* __restrict__ order,
+                       const int* __restrict__ want, const int* __restrict__ cnt, const int* __restrict__ cand,
+                       const int* __restrict__ fb, const int* __restrict__ eoff, const int* __restrict__ sel,
+                       const float* __restrict__ A2, const float* __restrict__ B2, const float* __restrict__ w2a,
+                       const float* __restrict__ b2a, long long* __restrict__ edge_index,
+                       long long* __restrict__ edge_attr, float* __restrict__ x_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int v = order[r];
+    const int off = eoff[r], ne = eoff[r + 1] - off;
+    int invs = 0;
+    if (ne > 0) {
+        const int c = cnt[r];
+        int s[2], b[2];
+        if (c == 0) {
+            s[0] = s[1] = fb[r];
+            b[0] = b[1] = 0;
+        } else {
+            const float bias = b2a[0];
+            s[0] = cand[static_cast<size_t>(r) * K + sel[2 * r]];
+            b[0] = inv_bit(A2, B2, w2a, bias, s[0], v);
+            if (min(want[r], c) == 2) {
+                s[1] = cand[static_cast<size_t>(r) * K + sel[2 * r + 1]];
+                b[1] = inv_bit(A2, B2, w2a, bias, s[1], v);
+            } else {  // fewer candidates than fan-ins: the first pick is repeated
+                s[1] = s[0];
+                b[1] = b[0];
+            }
+        }
+        for (int j = 0; j < ne; ++j) {
+            edge_index[off + j] = s[j];
+            edge_index[E + off + j] = v;
+            edge_attr[off + j] = b[j];
+            invs += b[j];
+        }
+    }
+    x_out[2 * v] = x[2 * v];
+    x_out[2 * v + 1] = static_cast<float>(invs);
+}
+
+}  // namespace
+}  // namespace aig
+
+using namespace aig;
+
+extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* cnt, const int32_t* cand,
+                             const float* projA, const float* projB, const float* w2, const float* b2,
+                             float* logits, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1, "aig_gen_score: bad sizes n=%lld K=%lld", (long long)n, (long long)K);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(order && cnt && cand && projA && projB && w2 && b2 && logits, "aig_gen_score: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t blocks = (n * 64 + 255) / 256;
+    hipLaunchKernelGGL(k_score, dim3((unsigned)blocks), dim3(256), 0, s, (int)n, (int)K, order, cnt, cand, projA, projB,
+                       w2, b2, logits);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" size_t aig_topk_select_ws_bytes(int64_t, int64_t) { return 256; }
+
+extern "C" int aig_topk_select(int64_t rows, int64_t ld, const float* logits, const int32_t* cnt,
+                               const int32_t* want, int32_t* sel, void*, size_t, void* stream) {
+    AIG_REQUIRE(rows >= 0 && rows < INT_MAX && ld >= 1 && ld < INT_MAX, "aig_topk_select: bad sizes rows=%lld ld=%lld",
+                (long long)rows, (long long)ld);
+    if (rows == 0) return AIG_OK;
+    AIG_REQUIRE(logits && cnt && want && sel, "aig_topk_select: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_topk_select),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEL_LDS));
+        attr_set = true;
+    }
+    int64_t blocks = (rows + SEL_THREADS - 1) / SEL_THREADS;
+    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)blocks), dim3(SEL_THREADS), SEL_LDS, s, (int)rows, (int)ld, logits,
+                       cnt, want, sel);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order,
+                            const int32_t* want, const int32_t* cnt, const int32_t* cand, const int32_t* fb,
+                            const int32_t* eoff, const int32_t* sel, const float* projA2, const float* projB2,
+                            const float* w2a, const float* b2a, int64_t* edge_index, int64_t* edge_attr,
+                            float* x_out, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1 && E >= 0, "aig_gen_emit: bad sizes");
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(x && order && want && cnt && cand && fb && eoff && sel && projA2 && projB2 && w2a && b2a && x_out,
+                "aig_gen_emit: null pointer");
+    AIG_REQUIRE(E == 0 || (edge_index && edge_attr), "aig_gen_emit: null edge output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int)n, (int)K, (long long)E, x,
+                       order, want, cnt, cand, fb, eoff, sel, projA2, projB2, w2a, b2a,
+                       reinterpret_cast<long long*>(edge_index), reinterpret_cast<long long*>(edge_attr), x_out);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}

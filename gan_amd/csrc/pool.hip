@@ -1,0 +1,228 @@
+// Level-wise readout of the critic: per depth level mean || max of the node embeddings, empty
+// levels count as zero vectors, then the mean over levels 0..L (models/discriminator.py:64-91).
+//
+//   mean part  = sum_i w_i h_i,            w_i = 1 / ((L+1) * |level(i)|)
+//   max part   = 1/(L+1) * sum_l max_{i in l} h_i
+//
+// One pass over h in level-sorted order: each half-wave walks a fixed chunk of sorted rows, keeps a
+// running max (with the smallest node id among equals) and flushes it with a packed 64-bit integer
+// atomic max when the level changes - order independent, hence reproducible.  The weighted sum uses
+// per-block partials added in block order.  No floating-point atomics.
+#include <climits>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace aig {
+namespace {
+
+constexpr int H = AIG_HIDDEN;
+constexpr int THREADS = 256;
+constexpr int HW_PER_BLOCK = THREADS / 32;
+constexpr int ROWS_PER_HW = 32;  // sorted rows walked by one half-wave
+
+__global__ void k_level_keys(int n, int L, const long long* __restrict__ depth, unsigned* __restrict__ key,
+                             int* __restrict__ ids) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        long long d = depth ? depth[i] : 0;
+        key[i] = (d >= 0 && d <= L) ? (unsigned)d : (unsigned)(L + 1);  // negative depth = ignored node
+        ids[i] = i;
+    }
+}
+
+__global__ void k_level_ptr(int n, int L, const unsigned* __restrict__ skey, int* __restrict__ lvl_ptr) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= L + 1; v += gridDim.x * blockDim.x) {
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (skey[mid] < (unsigned)v) lo = mid + 1; else hi = mid;
+        }
+        lvl_ptr[v] = lo;
+    }
+}
+
+// node_level[i] (or -1) and w[i]
+__global__ void k_level_weights(int n, int L, const unsigned* __restrict__ skey, const int* __restrict__ perm,
+                                const int* __restrict__ lvl_ptr, int* __restrict__ node_level,
+                                float* __restrict__ w) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        unsigned l = skey[p];
+        int i = perm[p];
+        if (l <= (unsigned)L) {
+            node_level[i] = (int)l;
+            w[i] = 1.f / ((float)(L + 1) * (float)(lvl_ptr[l + 1] - lvl_ptr[l]));
+        } else {
+            node_level[i] = -1;
+            w[i] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long pack_max(float v, int idx) {
+    unsigned b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // order-preserving
+    return ((unsigned long long)b << 32) | (unsigned)(~(unsigned)idx);  // larger = smaller node id
+}
+__device__ __forceinline__ float unpack_val(unsigned long long p) {
+    unsigned b = (unsigned)(p >> 32);
+    b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+    return __uint_as_float(b);
+}
+
+__global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* __restrict__ h,
+                                                       const int* __restrict__ perm,
+                                                       const int* __restrict__ node_level,
+                                                       const float* __restrict__ w,
+                                                       unsigned long long* __restrict__ table /*[L+1][H]*/,
+                                                       float* __restrict__ partial /*[grid][H]*/) {
+    __shared__ float red[HW_PER_BLOCK][H];
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int item = blockIdx.x * HW_PER_BLOCK + hw;
+    const int p0 = item * ROWS_PER_HW, p1 = min(nvalid, p0 + ROWS_PER_HW);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 mi = make_int4(0, 0, 0, 0);
+    int cur = -1;
+    auto flush = [&]() {
+        unsigned long long* t = table + (size_t)cur * H + l * 4;
+        atomicMax(t + 0, pack_max(mx.x, mi.x));
+        atomicMax(t + 1, pack_max(mx.y, mi.y));
+        atomicMax(t + 2, pack_max(mx.z, mi.z));
+        atomicMax(t + 3, pack_max(mx.w, mi.w));
+    };
+    for (int p = p0; p < p1; ++p) {
+        const int i = perm[p];
+        const int lev = node_level[i];
+        const float wi = w[i];
+        const float4 v = reinterpret_cast<const float4*>(h + (size_t)i * H)[l];
+        sum.x += wi * v.x; sum.y += wi * v.y; sum.z += wi * v.z; sum.w += wi * v.w;
+        if (lev != cur) {
+            if (cur >= 0) flush();
+            cur = lev;
+            mx = v;
+            mi = make_int4(i, i, i, i);
+        } else {  // rows of a level arrive by ascending node id: strict > keeps the first maximum
+            if (v.x > mx.x) { mx.x = v.x; mi.x = i; }
+            if (v.y > mx.y) { mx.y = v.y; mi.y = i; }
+            if (v.z > mx.z) { mx.z = v.z; mi.z = i; }
+            if (v.w > mx.w) { mx.w = v.w; mi.w = i; }
+        }
+    }
+    if (cur >= 0) flush();
+    reinterpret_cast<float4*>(&red[hw][0])[l] = sum;
+    __syncthreads();
+    if (threadIdx.x < H) {
+        float s = 0.f;
+        for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
+        partial[(size_t)blockIdx.x * H + threadIdx.x] = s;
+    }
+}
+
+// out[0:H] = sum of partials; out[H:2H] = 1/(L+1) sum over non-empty levels of the level max;
+// argmax[l*H + f] = node holding that max (-1 for an empty level).  One block, H threads.
+__global__ void k_pool_finish(int nb, int L, const float* __restrict__ partial,
+                              const unsigned long long* __restrict__ table, const int* __restrict__ lvl_ptr,
+                              float* __restrict__ out, int* __restrict__ argmax) {
+    const int f = threadIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * H + f];
+    out[f] = s;
+    float m = 0.f;
+    for (int l = 0; l <= L; ++l) {
+        const bool has = lvl_ptr[l + 1] > lvl_ptr[l];
+        unsigned long long t = table[(size_t)l * H + f];
+        if (has) m += unpack_val(t);
+        argmax[(size_t)l * H + f] = has ? (int)(~(unsigned)(t & 0xFFFFFFFFull)) : -1;
+    }
+    out[H + f] = m / (float)(L + 1);
+}
+
+int key_bits(int64_t n) {
+    int b = 1;
+    while ((1ll << b) <= n) ++b;
+    return b;
+}
+size_t sort_temp_bytes(int64_t n, int bits) {
+    size_t bytes = 0;
+    unsigned* k = nullptr;
+    int* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, bits, hipStream_t(0));
+    return bytes;
+}
+
+}  // namespace
+}  // namespace aig
+
+using namespace aig;
+
+extern "C" size_t aig_level_plan_ws_bytes(int64_t n, int64_t L) {
+    if (n <= 0) return 256;
+    return 3 * align_up((size_t)n * 4) + align_up(sort_temp_bytes(n, key_bits(L + 1))) + 256;
+}
+
+extern "C" int aig_level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
+                              int32_t* node_level, float* w, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && L < INT_MAX - 2, "aig_level_plan: bad sizes n=%lld L=%lld",
+                (long long)n, (long long)L);
+    AIG_REQUIRE(lvl_ptr, "aig_level_plan: null lvl_ptr");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        AIG_HIP_CHECK(hipMemsetAsync(lvl_ptr, 0, (size_t)(L + 2) * 4, s));
+        return AIG_OK;
+    }
+    AIG_REQUIRE(perm && node_level && w && ws, "aig_level_plan: null pointer");
+    if (ws_bytes < aig_level_plan_ws_bytes(n, L))
+        return fail(AIG_EWORKSPACE, "aig_level_plan: workspace %zu < %zu", ws_bytes, aig_level_plan_ws_bytes(n, L));
+    const int bits = key_bits(L + 1);
+    Carver c(ws);
+    unsigned* key = c.take<unsigned>(n);
+    unsigned* skey = c.take<unsigned>(n);
+    int* ids = c.take<int>(n);
+    size_t tb = sort_temp_bytes(n, bits);
+    void* temp = c.take<char>(tb);
+    const int g = grid_for(n, 256, 4096);
+    hipLaunchKernelGGL(k_level_keys, dim3(g), dim3(256), 0, s, (int)n, (int)L, reinterpret_cast<const long long*>(depth),
+                       key, ids);
+    AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, perm, (size_t)n, 0, bits, s));
+    hipLaunchKernelGGL(k_level_ptr, dim3(grid_for(L + 2, 256, 4096)), dim3(256), 0, s, (int)n, (int)L, skey, lvl_ptr);
+    hipLaunchKernelGGL(k_level_weights, dim3(g), dim3(256), 0, s, (int)n, (int)L, skey, perm, lvl_ptr, node_level, w);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L) {
+    size_t items = (size_t)((n > 0 ? n : 1) + ROWS_PER_HW - 1) / ROWS_PER_HW;
+    size_t blocks = (items + HW_PER_BLOCK - 1) / HW_PER_BLOCK;
+    return align_up((size_t)(L + 1) * H * 8) + align_up(blocks * H * 4) + 256;
+}
+
+extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const float* h, const int32_t* perm,
+                                  const int32_t* lvl_ptr, const int32_t* node_level, const float* w, float* out,
+                                  int32_t* argmax, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && nvalid >= 0 && nvalid <= n, "aig_level_pool_fwd: bad sizes");
+    AIG_REQUIRE(out && argmax && lvl_ptr && ws, "aig_level_pool_fwd: null pointer");
+    if (ws_bytes < aig_level_pool_fwd_ws_bytes(n, L))
+        return fail(AIG_EWORKSPACE, "aig_level_pool_fwd: workspace %zu < %zu", ws_bytes,
+                    aig_level_pool_fwd_ws_bytes(n, L));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Carver c(ws);
+    unsigned long long* table = c.take<unsigned long long>((size_t)(L + 1) * H);
+    AIG_HIP_CHECK(hipMemsetAsync(table, 0, (size_t)(L + 1) * H * 8, s));
+    int blocks = 0;
+    float* partial = nullptr;
+    if (nvalid > 0) {
+        AIG_REQUIRE(h && perm && node_level && w, "aig_level_pool_fwd: null pointer");
+        int64_t items = (nvalid + ROWS_PER_HW - 1) / ROWS_PER_HW;
+        blocks = (int)((items + HW_PER_BLOCK - 1) / HW_PER_BLOCK);
+        partial = c.take<float>((size_t)blocks * H);
+        hipLaunchKernelGGL(k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, h, perm, node_level, w, table,
+                           partial);
+        AIG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_pool_finish, dim3(1), dim3(H), 0, s, blocks, (int)L, partial, table, lvl_ptr, out, argmax);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}

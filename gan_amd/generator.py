@@ -1,0 +1,174 @@
+"""Template-conditioned AIG generator on MI355X kernels.
+
+Drop-in for ``models.generator.AIGGenerator`` of the reference (models/generator.py:10-217):
+same constructor arguments, same sub-module names (so state dicts interchange), same
+``forward(template, z) -> Data`` with ``x`` (template dtype), ``edge_index`` int64 [2,E],
+``edge_attr`` int64 [E,1] and a clone of ``node_depth``.
+
+How the per-node Python loop of the reference maps to kernels:
+
+* the processing order and every target's candidate window depend on the template only
+  (types, node_depth, candidate_k), never on earlier picks, so they are computed once per
+  template (``GeneratorPlan``) by a radix sort and a wave-parallel walk;
+* ``edge_scorer.0`` / ``edge_attr_pred.0`` act on ``[h_src | h_tgt | z]``: their weight splits
+  into a source block, a target block and a z block, so the hidden layer of a pair is
+  ``relu(A[src] + B[tgt])`` with ``A``/``B`` computed once per node on the f32 matrix cores;
+* scoring, ATen-exact top-k and edge assembly are one kernel each over all targets.
+
+Like the reference, the output carries no gradient: every emitted tensor is integer-valued
+or a copy, so ``loss_G.backward()`` never reaches these parameters (train.py:297-299).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .data import Data
+
+PI, PO, AND = 0, 1, 2
+
+
+class GeneratorPlan:
+    """Order, candidate windows and edge offsets of one template for one candidate_k."""
+
+    __slots__ = ("n", "K", "E", "types", "order", "rank", "want", "cnt", "cand", "fb", "eoff", "key")
+
+    @staticmethod
+    def build(x: torch.Tensor, node_depth: Optional[torch.Tensor], K: int) -> "GeneratorPlan":
+        lib = _abi.lib()
+        dev = x.device
+        n = int(x.size(0))
+        p = GeneratorPlan()
+        p.n, p.K = n, int(K)
+        i32 = dict(dtype=torch.int32, device=dev)
+        p.types, p.order, p.rank = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n, **i32)
+        kind, dptr = 0, None
+        if node_depth is not None and node_depth.numel() == n:
+            nd = node_depth.to(dev)
+            if nd.dtype.is_floating_point:
+                nd, kind = nd.to(torch.float32).contiguous(), 1
+            else:
+                nd, kind = nd.to(torch.int64).contiguous(), 2
+            dptr = _abi.ptr(nd)
+        ws = _abi.workspace(lib.aig_gen_order_ws_bytes(n), dev)
+        _abi.check(lib.aig_gen_order(n, _abi.ptr(x), kind, dptr, _abi.ptr(p.types), _abi.ptr(p.order),
+                                     _abi.ptr(p.rank), _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_gen_order")
+        p.want, p.cnt, p.fb = torch.empty(n, **i32), torch.empty(n, **i32), torch.empty(n, **i32)
+        p.cand = torch.empty((max(n, 1), p.K), **i32)
+        p.eoff = torch.empty(n + 1, **i32)
+        ws2 = _abi.workspace(lib.aig_gen_candidates_ws_bytes(n, p.K), dev)
+        _abi.check(lib.aig_gen_candidates(n, p.K, _abi.ptr(p.types), _abi.ptr(p.order), _abi.ptr(p.rank),
+                                          _abi.ptr(p.want), _abi.ptr(p.cnt), _abi.ptr(p.cand), _abi.ptr(p.fb),
+                                          _abi.ptr(p.eoff), _abi.ptr(ws2), ws2.numel(), _abi.stream()),
+                   "aig_gen_candidates")
+        p.E = int(p.eoff[n].item())  # the one host read per template: sizes the output tensors
+        return p
+
+
+def _plan_key(x: torch.Tensor, nd: Optional[torch.Tensor], K: int):
+    return (K, x.data_ptr(), x._version, tuple(x.shape),
+            None if nd is None else (nd.data_ptr(), nd._version, nd.dtype))
+
+
+class AIGGenerator(nn.Module):
+    def __init__(self, node_in_dim: int = 2, hidden_dim: int = 128, z_dim: int = 128, candidate_k: int = 512,
+                 device: torch.device = torch.device("cpu")):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.z_dim = z_dim
+        self.candidate_k = candidate_k
+        self.device = device
+        self.node_enc = nn.Sequential(nn.Linear(node_in_dim, hidden_dim), nn.ReLU(),
+                                      nn.Linear(hidden_dim, hidden_dim), nn.ReLU())
+        self.node_proj = nn.Sequential(nn.Linear(hidden_dim + z_dim, hidden_dim), nn.ReLU(),
+                                       nn.Linear(hidden_dim, hidden_dim), nn.ReLU())
+        self.edge_scorer = nn.Sequential(nn.Linear(hidden_dim * 2 + z_dim, hidden_dim), nn.ReLU(),
+                                         nn.Linear(hidden_dim, 1))
+        self.edge_attr_pred = nn.Sequential(nn.Linear(hidden_dim * 2 + z_dim, hidden_dim), nn.ReLU(),
+                                            nn.Linear(hidden_dim, 1))
+        if (node_in_dim, hidden_dim, z_dim) != (2, 128, 128):
+            raise NotImplementedError(
+                "the MI355X kernels are built for node_in_dim=2, hidden_dim=128, z_dim=128 (the reference defaults)")
+
+    # ------------------------------------------------------------------ plumbing
+    def _weights(self) -> _abi.GenWeights:
+        def p(t):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise _abi.AigAbiError("generator parameters must be contiguous float32 tensors on a HIP device")
+            return t.data_ptr()
+        w = _abi.GenWeights()
+        w.enc0_w, w.enc0_b = p(self.node_enc[0].weight), p(self.node_enc[0].bias)
+        w.enc2_w, w.enc2_b = p(self.node_enc[2].weight), p(self.node_enc[2].bias)
+        w.proj0_w, w.proj0_b = p(self.node_proj[0].weight), p(self.node_proj[0].bias)
+        w.proj2_w, w.proj2_b = p(self.node_proj[2].weight), p(self.node_proj[2].bias)
+        w.sc0_w, w.sc0_b = p(self.edge_scorer[0].weight), p(self.edge_scorer[0].bias)
+        w.sc2_w, w.sc2_b = p(self.edge_scorer[2].weight), p(self.edge_scorer[2].bias)
+        w.at0_w, w.at0_b = p(self.edge_attr_pred[0].weight), p(self.edge_attr_pred[0].bias)
+        w.at2_w, w.at2_b = p(self.edge_attr_pred[2].weight), p(self.edge_attr_pred[2].bias)
+        return w
+
+    def plan_for(self, template: Data, x: torch.Tensor, nd: Optional[torch.Tensor]) -> GeneratorPlan:
+        """Cached on the template object; rebuilt when its tensors or candidate_k change."""
+        key = _plan_key(x, nd, int(self.candidate_k))
+        plan = template.__dict__.get("_gen_plan")
+        if plan is None or plan.key != key:
+            plan = GeneratorPlan.build(x, nd, int(self.candidate_k))
+            plan.key = key
+            template.__dict__["_gen_plan"] = plan
+        return plan
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, template: Data, z: torch.Tensor, return_debug: bool = False) -> Data:
+        lib = _abi.lib()
+        dev = template.x.device if hasattr(template, "x") else self.device
+        if dev.type != "cuda":
+            raise _abi.AigAbiError("AIGGenerator.forward needs the template on a HIP device (no CPU path exists)")
+        if z.dim() == 2 and z.size(0) == 1:
+            z = z.squeeze(0)
+        z = z.to(dev).float().contiguous()
+        x_src = template.x
+        x_in = x_src if (x_src.dtype == torch.float32 and x_src.is_contiguous()) else x_src.float().contiguous()
+        n = int(x_in.size(0))
+        nd = getattr(template, "node_depth", None)
+        nd_dev = nd.to(dev) if nd is not None else None
+        plan = self.plan_for(template, x_in, nd_dev)
+        K, E = plan.K, plan.E
+        st = _abi.stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        proj = torch.empty((4, max(n, 1), 128), **f32)
+        h_cond = torch.empty((max(n, 1), 128), **f32) if return_debug else None
+        ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), dev)
+        w = self._weights()
+        _abi.check(lib.aig_gen_node_proj(n, _abi.ptr(x_in), _abi.ptr(z), C.byref(w), _abi.ptr(h_cond),
+                                         _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st), "aig_gen_node_proj")
+        logits = torch.empty((max(n, 1), K), **f32)
+        if return_debug:
+            logits.fill_(float("nan"))
+        _abi.check(lib.aig_gen_score(n, K, _abi.ptr(plan.order), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
+                                     _abi.ptr(proj[0]), _abi.ptr(proj[1]), _abi.ptr(self.edge_scorer[2].weight),
+                                     _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), "aig_gen_score")
+        sel = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
+        _abi.check(lib.aig_topk_select(n, K, _abi.ptr(logits), _abi.ptr(plan.cnt), _abi.ptr(plan.want),
+                                       _abi.ptr(sel), None, 0, st), "aig_topk_select")
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+        edge_attr = torch.empty((E, 1), dtype=torch.int64, device=dev)
+        x_out = torch.empty((n, 2), **f32)
+        _abi.check(lib.aig_gen_emit(n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
+                                    _abi.ptr(plan.cnt), _abi.ptr(plan.cand), _abi.ptr(plan.fb), _abi.ptr(plan.eoff),
+                                    _abi.ptr(sel), _abi.ptr(proj[2]), _abi.ptr(proj[3]),
+                                    _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias),
+                                    _abi.ptr(edge_index) if E else None, _abi.ptr(edge_attr) if E else None,
+                                    _abi.ptr(x_out), st), "aig_gen_emit")
+        if x_src.dtype != torch.float32:
+            x_out = x_out.to(x_src.dtype)
+        out = Data(x=x_out, edge_index=edge_index, edge_attr=edge_attr,
+                   node_depth=(nd.clone().to(dev) if nd is not None else None))
+        if return_debug:
+            out._debug = {"plan": plan, "h_cond": h_cond, "logits": logits, "sel": sel, "proj": proj}
+        return out

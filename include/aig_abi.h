@@ -1,0 +1,184 @@
+/*
+ * aig_abi.h - C ABI of libaig_hip.so, the MI355X (gfx950) kernels behind the AIG-GAN hot path.
+ *
+ * The reference (tyjcj/GAN) is pure Python and has no FFI layer; its boundary for this path is
+ * the Python API of models/generator.py, models/discriminator.py, models/constraints.py and
+ * AIGgan.py.  Each entry point below names the reference lines whose work it takes over.  The
+ * Python modules under gan_amd/ keep the reference's signatures and call these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t; work is enqueued on it and the call returns without
+ *     synchronising unless stated; no entry point allocates or frees device memory:
+ *     outputs and workspaces belong to the caller (sizes from the *_ws_bytes queries);
+ *   - return value 0 = success, negative = error (AIG_E*), never an exception or abort;
+ *     aig_last_error() gives the message of the calling thread's last failure;
+ *   - node ids, ranks and offsets are int32 inside the library (N < 2^31); edge_index tensors
+ *     at the boundary keep the reference's int64.
+ */
+#ifndef AIG_ABI_H
+#define AIG_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIG_OK 0
+#define AIG_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported value) */
+#define AIG_EWORKSPACE (-2)  /* workspace too small */
+#define AIG_EHIP (-3)        /* a HIP runtime call or kernel launch failed */
+#define AIG_ELIMIT (-4)      /* size beyond a documented limit */
+
+#define AIG_MAX_CANDIDATE_K 1024 /* candidate window limit of the generator kernels */
+#define AIG_HIDDEN 128           /* hidden width the kernels are built for (reference default) */
+
+int aig_abi_version(void);
+const char* aig_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generator: plan (depends on the template only, not on z)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Processing order - models/generator.py:70-82 (_build_order) and :110-112 (types).
+ *   x          float32 [n,2] template features; types[i] = (int)x[i,0]
+ *   depth_kind 0: no usable node_depth (key = 0 for a PI, i otherwise); 1: float32; 2: int64
+ *   order[r]   node processed r-th (stable sort by (depth, index)); rank[order[r]] = r */
+size_t aig_gen_order_ws_bytes(int64_t n);
+int aig_gen_order(int64_t n, const float* x, int depth_kind, const void* depth,
+                  int32_t* types, int32_t* order, int32_t* rank,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* Candidate windows - models/generator.py:131-158 and the edge counts of :142-154,:178-182.
+ * Slot r describes the node order[r]:
+ *   want[r]   0 for a PI (not a target), 2 for an AND, 1 for anything else
+ *   cnt[r]    number of candidates = min(K, #{u : rank[u] < r, type[u] != PO})
+ *   cand[r*K .. r*K+cnt[r])  those candidates, the K largest ids, ascending
+ *   fb[r]     largest id among nodes with rank < r when cnt[r] == 0 and the slot is a target, else -1
+ *   eoff[r]   exclusive prefix sum of the edges emitted per slot (want[r] if cnt[r] > 0 or fb[r] >= 0);
+ *             eoff[n] = total edge count E */
+size_t aig_gen_candidates_ws_bytes(int64_t n, int64_t K);
+int aig_gen_candidates(int64_t n, int64_t K, const int32_t* types, const int32_t* order, const int32_t* rank,
+                       int32_t* want, int32_t* cnt, int32_t* cand, int32_t* fb, int32_t* eoff,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generator: per-sample kernels
+ * ------------------------------------------------------------------------------------------- */
+
+/* Weights of AIGGenerator (models/generator.py:40-67), PyTorch layout [out,in] row-major fp32. */
+typedef struct aig_gen_weights {
+    const float *enc0_w, *enc0_b;   /* node_enc.0        [128,2],   [128] */
+    const float *enc2_w, *enc2_b;   /* node_enc.2        [128,128], [128] */
+    const float *proj0_w, *proj0_b; /* node_proj.0       [128,256], [128] */
+    const float *proj2_w, *proj2_b; /* node_proj.2       [128,128], [128] */
+    const float *sc0_w, *sc0_b;     /* edge_scorer.0     [128,384], [128] */
+    const float *sc2_w, *sc2_b;     /* edge_scorer.2     [1,128],   [1]   */
+    const float *at0_w, *at0_b;     /* edge_attr_pred.0  [128,384], [128] */
+    const float *at2_w, *at2_b;     /* edge_attr_pred.2  [1,128],   [1]   */
+} aig_gen_weights;
+
+/* Node encoder + conditioning + the node-wise halves of both edge MLPs -
+ * models/generator.py:115-117 and the first Linear of :94-98 / :169, split by input block:
+ *   h_cond = node_proj(cat[node_enc(x), z])                                   (optional output)
+ *   proj[0] = h_cond @ W_sc[:, 0:128]^T                       (source half of edge_scorer.0)
+ *   proj[1] = h_cond @ W_sc[:, 128:256]^T + W_sc[:, 256:384] z + b_sc   (target half + z + bias)
+ *   proj[2], proj[3] likewise for edge_attr_pred.0
+ * so that the hidden layer of a (candidate c, target v) pair is relu(proj[0][c] + proj[1][v]).
+ * proj is 4 consecutive [n,128] fp32 matrices; h_cond may be NULL.  f32 MFMA, k-ordered chains:
+ * equal input rows give bit-equal output rows wherever they sit. */
+size_t aig_gen_node_proj_ws_bytes(int64_t n);
+int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_weights* w_host,
+                      float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream);
+
+/* Candidate scores - models/generator.py:84-99 (_score_candidates + edge_scorer):
+ *   logits[r*K + i] = w2 . relu(projA[cand[r*K+i]] + projB[order[r]]) + b2,   i < cnt[r] */
+int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* cnt, const int32_t* cand,
+                  const float* projA, const float* projB, const float* w2, const float* b2,
+                  float* logits, void* stream);
+
+/* Tie-exact top-k - torch.topk(logits, k, largest=True, sorted=True) as called at
+ * models/generator.py:162-168, i.e. ATen's CPU kernel (native/TopKImpl.h: partial_sort when
+ * k*64 <= C, else nth_element) including the order libstdc++ leaves equal values in.
+ *   row r holds cnt[r] values at logits + r*ld; k = min(want[r], cnt[r]) in {0,1,2}
+ *   sel[2r + j] = position (0-based, within the row) of the j-th pick, -1 when absent */
+size_t aig_topk_select_ws_bytes(int64_t rows, int64_t ld);
+int aig_topk_select(int64_t rows, int64_t ld, const float* logits, const int32_t* cnt, const int32_t* want,
+                    int32_t* sel, void* ws, size_t ws_bytes, void* stream);
+
+/* Edge assembly - models/generator.py:145-154 (fallback), :168-186 (picks, inversion bit, padding by
+ * repeating the first pick), :196-209 (edge tensors in processing order, x[:,1] = inverted in-edges).
+ *   inversion bit = (w2a . relu(projA2[src] + projB2[v]) + b2a > 0)   (sigmoid(l) > 0.5  <=>  l > 0)
+ *   edge_index int64 [2,E] (row 0 sources, row 1 targets), edge_attr int64 [E], x_out float32 [n,2] */
+int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order, const int32_t* want,
+                 const int32_t* cnt, const int32_t* cand, const int32_t* fb, const int32_t* eoff,
+                 const int32_t* sel, const float* projA2, const float* projB2, const float* w2a, const float* b2a,
+                 int64_t* edge_index, int64_t* edge_attr, float* x_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Critic: graph attention layer (torch_geometric.nn.GATConv(in, 32, heads=4, edge_dim=1) as called at
+ * models/discriminator.py:30-31,60-61; the layer itself is a third-party dependency of the reference).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Edge lists by target and by source.  Self loops and out-of-range endpoints are dropped (GATConv
+ * removes self loops and re-adds one per node); kept edges are stably sorted by target.
+ *   edge_index int64 [2,E]; edge_attr float32 [E] or NULL (zeros)
+ *   row_ptr[n+1], csr_src/csr_ea/csr_eid [E]: edges entering node v are row_ptr[v]..row_ptr[v+1]
+ *       (row_ptr[n] = number of kept edges); csr_eid = position in the caller's edge list
+ *   loop_ea[n]: attribute of the implicit self loop = mean attribute of the entering edges, 0 if none
+ *   col_ptr[n+1], csc_pos/csc_dst [E]: edges leaving node u; csc_pos indexes the by-target arrays */
+size_t aig_gat_csr_ws_bytes(int64_t n, int64_t E);
+int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_attr,
+                int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
+                int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, void* ws, size_t ws_bytes, void* stream);
+
+/* Forward of one layer after the dense projection xw = x W^T ([n,128], 4 heads x 32 channels):
+ *   a_s[i,h] = <xw[i,h,:], att_src[h,:]>, a_d likewise            (outputs, [n,4] each)
+ *   e = leaky_relu(a_s[src] + a_d[dst] + edge_attr * ce[h], 0.2)   ce[h] = <lin_edge.weight[h,:], att_edge[h,:]>
+ *   alpha = exp(e - max) / (sum exp(e - max) + 1e-16) over the edges entering dst, self loop included
+ *   out[dst] = elu(sum alpha * xw[src] + bias)                     (the F.elu of discriminator.py:60-61 is fused)
+ * alpha_e [E,4] (by-target order) and alpha_loop [n,4] are kept for the backward pass. */
+int aig_gat_fwd(int64_t n, const float* xw, const float* att_src, const float* att_dst, const float* ce,
+                const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                const float* loop_ea, float* a_s, float* a_d, float* out, float* alpha_e, float* alpha_loop,
+                void* stream);
+
+/* Backward of the same layer: given g_out = dLoss/d out, returns d_xw [n,128], d_att_src [128],
+ * d_att_dst [128], d_ce [4], d_bias [128].  (Gradients w.r.t. edge_attr are not produced: the only
+ * caller that differentiates edge attributes in the reference is dead code, train.py:154-185.) */
+size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E);
+int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
+                const float* att_src, const float* att_dst, const float* ce, const float* a_s, const float* a_d,
+                const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea, const float* loop_ea,
+                const int32_t* col_ptr, const int32_t* csc_pos, const int32_t* csc_dst,
+                const float* alpha_e, const float* alpha_loop,
+                float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
+                void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Critic: level-wise readout - models/discriminator.py:64-91
+ * ------------------------------------------------------------------------------------------- */
+
+/* Groups nodes by depth level 0..L (negative depth = ignored node, as for padding).
+ *   depth int64 [n] or NULL (every node in level 0); L = largest level, read by the caller
+ *   perm[n]: node ids stably sorted by level, ignored nodes last; lvl_ptr[L+2]: start of each level in perm
+ *   node_level[n]: level or -1; w[n] = 1 / ((L+1) * size of the node's level), 0 for ignored nodes */
+size_t aig_level_plan_ws_bytes(int64_t n, int64_t L);
+int aig_level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
+                   int32_t* node_level, float* w, void* ws, size_t ws_bytes, void* stream);
+
+/* out[0:128] = mean over levels 0..L of the level means, out[128:256] = mean over levels of the level
+ * maxima (an empty level counts as a zero vector); argmax[l*128+f] = smallest node id attaining the
+ * maximum of feature f in level l (-1 for an empty level), which is where the gradient goes.
+ * nvalid = number of nodes with a level (= lvl_ptr[L+1]). */
+size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L);
+int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const float* h, const int32_t* perm,
+                       const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
+                       float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIG_ABI_H */

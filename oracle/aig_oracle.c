@@ -427,3 +427,105 @@ int orc_resync(int64_t n, int64_t e, const int64_t *src, const int64_t *dst, con
     free(fs); free(ptr); free(adj); free(deg); free(q);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Floating-point half of the generator in a position-independent form.
+ *
+ * models/generator.py:115-117 (node_enc, node_proj) and :94-98 / :169 (edge_scorer,
+ * edge_attr_pred) are dense layers.  The reference evaluates them through the CPU BLAS, whose
+ * blocked kernels round the remainder rows of a matrix differently from the full blocks: equal
+ * input rows can come out 1-3 ulp apart depending on where they sit (observed: 59 identical
+ * candidate rows gave 3 distinct logits).  Its pick among tied candidates is therefore not a
+ * function of the inputs alone.  The library defines the arithmetic instead: every output element
+ * is one fmaf chain over k in a fixed order, so equal rows give equal results anywhere.  These
+ * routines state that chain on the CPU; results agree with the reference's to ~1e-6 relative.
+ *
+ * Chain order of a 128-wide product: k runs 8g+0, 8g+4, 8g+1, 8g+5, 8g+2, 8g+6, 8g+3, 8g+7 for
+ * g = 0..15 (the order in which the matrix-core kernel feeds k), accumulator starts at 0, the
+ * bias is added last.  Compile with -ffp-contract=off: every fused operation below is explicit.
+ * ------------------------------------------------------------------------------------------ */
+#include <math.h>
+
+static float chain128(const float *a, const float *w) {
+    float acc = 0.0f;
+    for (int g = 0; g < 16; ++g)
+        for (int t = 0; t < 4; ++t) {
+            acc = fmaf(a[8 * g + t], w[8 * g + t], acc);
+            acc = fmaf(a[8 * g + 4 + t], w[8 * g + 4 + t], acc);
+        }
+    return acc;
+}
+
+/* out[j] = b[j] + sum_k w[j*ld + off + k] * z[k], k ascending */
+static void zbias128(const float *w, int ld, int off, const float *b, const float *z, float *out) {
+    for (int j = 0; j < 128; ++j) {
+        float acc = 0.0f;
+        for (int k = 0; k < 128; ++k) acc = fmaf(w[(size_t)j * ld + off + k], z[k], acc);
+        out[j] = acc + b[j];
+    }
+}
+
+static void layer128(int64_t n, const float *x, const float *w, int ldw, const float *bias, int relu, float *y) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < 128; ++j) {
+            float v = chain128(x + i * 128, w + (size_t)j * ldw) + (bias ? bias[j] : 0.0f);
+            y[i * 128 + j] = (relu && !(v > 0.0f)) ? 0.0f : v;
+        }
+}
+
+/* weights: the 16 tensors of AIGGenerator in state_dict order, PyTorch [out,in] layout.
+ * h_cond [n,128]; proj = 4 planes [n,128]: source half / target half(+z,+bias) of edge_scorer.0,
+ * then the same two for edge_attr_pred.0. */
+int orc_node_proj(int64_t n, const float *x, const float *z,
+                  const float *enc0_w, const float *enc0_b, const float *enc2_w, const float *enc2_b,
+                  const float *proj0_w, const float *proj0_b, const float *proj2_w, const float *proj2_b,
+                  const float *sc0_w, const float *sc0_b, const float *at0_w, const float *at0_b,
+                  float *h_cond, float *proj) {
+    float zb[3][128];
+    zbias128(proj0_w, 256, 128, proj0_b, z, zb[0]);
+    zbias128(sc0_w, 384, 256, sc0_b, z, zb[1]);
+    zbias128(at0_w, 384, 256, at0_b, z, zb[2]);
+    float *t0 = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * 128 * 2), *t1 = t0 + n * 128;
+    if (!t0) return -1;
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < 128; ++j) {
+            float s = fmaf(x[2 * i + 1], enc0_w[2 * j + 1], x[2 * i] * enc0_w[2 * j]) + enc0_b[j];
+            t0[i * 128 + j] = s > 0.0f ? s : 0.0f;
+        }
+    layer128(n, t0, enc2_w, 128, enc2_b, 1, t1);
+    layer128(n, t1, proj0_w, 256, zb[0], 1, t0);
+    layer128(n, t0, proj2_w, 128, proj2_b, 1, h_cond);
+    layer128(n, h_cond, sc0_w, 384, NULL, 0, proj);
+    layer128(n, h_cond, sc0_w + 128, 384, zb[1], 0, proj + n * 128);
+    layer128(n, h_cond, at0_w, 384, NULL, 0, proj + 2 * n * 128);
+    layer128(n, h_cond, at0_w + 128, 384, zb[2], 0, proj + 3 * n * 128);
+    free(t0);
+    return 0;
+}
+
+/* logit of the pair (source row a, target row b): b2 + sum_j w2[j] * relu(a[j] + b[j]), j ascending */
+float orc_pair_logit(const float *a, const float *b, const float *w2, float b2) {
+    float acc = 0.0f;
+    for (int j = 0; j < 128; ++j) {
+        float h = a[j] + b[j];
+        acc = fmaf(h > 0.0f ? h : 0.0f, w2[j], acc);
+    }
+    return acc + b2;
+}
+
+/* logits[t*K + i] for every target t (processing order) and candidate i < cnt[t]; others untouched */
+int orc_score_rows(int64_t T, int64_t K, const int64_t *tgt, const int64_t *cnt, const int64_t *cand,
+                   const float *A, const float *B, const float *w2, const float *b2, float *logits) {
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t i = 0; i < cnt[t]; ++i)
+            logits[t * K + i] = orc_pair_logit(A + cand[t * K + i] * 128, B + tgt[t] * 128, w2, b2[0]);
+    return 0;
+}
+
+/* inversion bits of given (src, dst) pairs: (w2a . relu(A2[src] + B2[dst]) + b2a) > 0 */
+int orc_inv_bits(int64_t m, const int64_t *src, const int64_t *dst, const float *A2, const float *B2,
+                 const float *w2a, const float *b2a, int64_t *bits) {
+    for (int64_t i = 0; i < m; ++i)
+        bits[i] = orc_pair_logit(A2 + src[i] * 128, B2 + dst[i] * 128, w2a, b2a[0]) > 0.0f;
+    return 0;
+}

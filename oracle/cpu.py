@@ -38,7 +38,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         for fn in ("orc_build_order", "orc_enforce", "orc_penalties", "orc_validate", "orc_resync",
-                   "orc_topk", "orc_topk_rows"):
+                   "orc_topk", "orc_topk_rows", "orc_node_proj", "orc_score_rows", "orc_inv_bits"):
             getattr(_lib, fn).restype = C.c_int
         _lib.orc_candidates.restype = C.c_int64
     return _lib
@@ -105,6 +105,51 @@ def topk_rows(values: np.ndarray, cnt: np.ndarray, k: np.ndarray) -> np.ndarray:
                              _p(k, i64p), _p(out, i64p))
     assert rc == 0
     return out
+
+
+GEN_KEYS = ["node_enc.0", "node_enc.2", "node_proj.0", "node_proj.2", "edge_scorer.0", "edge_attr_pred.0"]
+
+
+def _f32(a) -> np.ndarray:
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def node_proj(state, x: np.ndarray, z: np.ndarray):
+    """Position-independent node pipeline (see aig_oracle.c) -> (h_cond [n,128], proj [4,n,128])."""
+    x, z = _f32(x), _f32(z).reshape(-1)
+    n = int(x.shape[0])
+    ws = []
+    for k in GEN_KEYS:
+        ws += [_f32(state[k + ".weight"]), _f32(state[k + ".bias"])]
+    h_cond = np.empty((n, 128), np.float32)
+    proj = np.empty((4, max(n, 1), 128), np.float32)
+    rc = lib().orc_node_proj(C.c_int64(n), _p(x, f32p), _p(z, f32p), *[_p(w, f32p) for w in ws],
+                             _p(h_cond, f32p), _p(proj, f32p))
+    assert rc == 0
+    return h_cond, proj[:, :n]
+
+
+def score_rows(tgt, cnt, cand, A, B, w2, b2) -> np.ndarray:
+    tgt, cnt, cand = _i64(tgt), _i64(cnt), _i64(cand)
+    T, K = cand.shape
+    A, B, w2, b2 = _f32(A), _f32(B), _f32(w2).reshape(-1), _f32(b2).reshape(-1)
+    logits = np.full((T, K), np.nan, np.float32)
+    rc = lib().orc_score_rows(C.c_int64(T), C.c_int64(K), _p(tgt, i64p), _p(cnt, i64p), _p(cand, i64p),
+                              _p(A, f32p), _p(B, f32p), _p(w2, f32p), _p(b2, f32p), _p(logits, f32p))
+    assert rc == 0
+    return logits
+
+
+def inv_bits(src, dst, A2, B2, w2a, b2a) -> np.ndarray:
+    src, dst = _i64(src), _i64(dst)
+    A2, B2, w2a, b2a = _f32(A2), _f32(B2), _f32(w2a).reshape(-1), _f32(b2a).reshape(-1)
+    bits = np.empty(src.shape[0], np.int64)
+    rc = lib().orc_inv_bits(C.c_int64(src.shape[0]), _p(src, i64p), _p(dst, i64p), _p(A2, f32p), _p(B2, f32p),
+                            _p(w2a, f32p), _p(b2a, f32p), _p(bits, i64p))
+    assert rc == 0
+    return bits
 
 
 # ----------------------------------------------------------------------------- constraints

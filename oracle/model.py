@@ -112,6 +112,51 @@ def _generator_forward(state, x, node_depth, z, candidate_k, keep):
     return out
 
 
+def generator_forward_canonical(state: Dict[str, torch.Tensor], x: torch.Tensor,
+                                node_depth: Optional[torch.Tensor], z: torch.Tensor, candidate_k: int):
+    """models/generator.py:101-217 with the dense layers evaluated as fixed-order fmaf chains
+    (aig_oracle.c, "position-independent form") instead of through the CPU BLAS.  Same order,
+    windows, top-k routine, padding and assembly as ``generator_forward``; logits agree with it
+    to ~1e-6 relative, and equal candidate rows always tie exactly.  This is the form the HIP
+    kernels are compared with bit for bit."""
+    x = x.detach().cpu()
+    n = x.size(0)
+    types = x[:, 0].long().numpy()
+    depth = None
+    if node_depth is not None and node_depth.numel() == n:
+        depth = node_depth.detach().cpu().to(torch.float64).numpy()
+    order, _ = cpu.build_order(types, depth)
+    tgt, cand, cnt, fb = cpu.candidates(types, order, candidate_k)
+    h_cond, proj = cpu.node_proj(state, x.float().numpy(), z.detach().cpu().float().numpy())
+    T = tgt.shape[0]
+    logits = cpu.score_rows(tgt, cnt, np.where(cand < 0, 0, cand), proj[0], proj[1],
+                            state["edge_scorer.2.weight"], state["edge_scorer.2.bias"])
+    want = np.where(types[tgt] == AND, 2, 1).astype(np.int64)
+    sel = cpu.topk_rows(np.nan_to_num(logits, nan=0.0) if T else logits, cnt, want)
+    k_eff = np.minimum(want, cnt)
+    ne = np.where((cnt > 0) | (fb >= 0), want, 0)
+    eoff = np.concatenate([[0], np.cumsum(ne)])
+    E = int(eoff[-1])
+    src, dst, use_fb = np.zeros(E, np.int64), np.zeros(E, np.int64), np.zeros(E, bool)
+    rows = np.arange(T)
+    for j in (0, 1):
+        m = ne > j
+        pick = np.where(k_eff > j, sel[:, j], sel[:, 0])           # missing second pick repeats the first
+        s = np.where(cnt > 0, cand[rows, np.maximum(pick, 0)], fb)
+        src[eoff[:-1][m] + j] = s[m]
+        dst[eoff[:-1][m] + j] = tgt[m]
+        use_fb[eoff[:-1][m] + j] = (cnt == 0)[m]
+    bits = cpu.inv_bits(src, dst, proj[2], proj[3], state["edge_attr_pred.2.weight"], state["edge_attr_pred.2.bias"])
+    bits[use_fb] = 0
+    x_out = x.clone()
+    inv_count = np.zeros(n, np.int64)
+    np.add.at(inv_count, dst, bits)
+    x_out[:, 1] = torch.from_numpy(inv_count).to(x_out.dtype)
+    return {"edge_index": torch.from_numpy(np.stack([src, dst])), "edge_attr": torch.from_numpy(bits).view(-1, 1),
+            "x": x_out, "h_cond": h_cond, "proj": proj, "order": order, "tgt": tgt, "cand": cand, "cnt": cnt,
+            "fb": fb, "logits": logits, "sel": sel}
+
+
 # ------------------------------------------------------------------------------------ critic
 def gat_self_loops(edge_index: torch.Tensor, edge_attr: torch.Tensor, n: int):
     """Drop self loops, then append one per node whose attribute is the mean attribute of

@@ -12,9 +12,8 @@ outputs) are stored, as ``.npz`` files.
 
 What is captured
   gen_weights.npz          AIGGenerator state_dict after torch.manual_seed(123)
-  gen_<case>.npz           template, z, candidate_k -> edge_index / edge_attr / x,
-                           and for the small cases h_cond plus every target's
-                           candidate list and logits
+  gen_<case>.npz           template, z, candidate_k -> edge_index / edge_attr / x, every
+                           target's candidate list and logits, and for the small cases h_cond
   cons_<case>.npz          graph -> enforce_aig_constraints output, penalty dict,
                            validate_strict_aig strings, resync_attrs output
   pad_<case>.npz           pad_data / unpad_data outputs
@@ -136,15 +135,16 @@ def main():
         print(f"[gen] {name}")
         g = torch.Generator().manual_seed(1000 + ci)
         z = torch.randn(128, generator=g)
-        out, rec = run_generator(AIGGenerator, state, tpl, K, z, keep)
+        out, rec = run_generator(AIGGenerator, state, tpl, K, z, True)
         nd = getattr(tpl, "node_depth", None)
         arrays = dict(
             x=np_of(tpl.x), node_depth=None if nd is None else np_of(nd), z=np_of(z),
             candidate_k=np.int64(K),
             out_edge_index=np_of(out.edge_index), out_edge_attr=np_of(out.edge_attr), out_x=np_of(out.x),
         )
-        if keep and rec["tgt"]:
-            arrays["h_cond"] = rec["h_cond"]
+        if rec["tgt"]:
+            if keep:
+                arrays["h_cond"] = rec["h_cond"]
             arrays["rec_tgt"] = np.asarray(rec["tgt"], dtype=np.int64)
             arrays["rec_off"] = np.cumsum([0] + [len(c) for c in rec["cand"]]).astype(np.int64)
             arrays["rec_cand"] = np.concatenate(rec["cand"])

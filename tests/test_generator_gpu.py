@@ -1,0 +1,263 @@
+"""GPU parity of the generator path (all calls go through the C ABI of libaig_hip.so).
+
+Bars: order, candidate windows, picks, edges and x bit-exact against the reference's own
+outputs (tests/golden) and against the CPU checker; h_cond / logits within 1e-4 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_names
+from gan_amd import _abi
+from gan_amd.data import Data
+from gan_amd.generator import AIGGenerator, GeneratorPlan
+from gan_amd.synth import synth_aig
+from oracle import cpu as ocpu
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+from util_golden import gen_state, golden_targets, load, tie_consistent
+
+
+def golden_generator(K):
+    G = AIGGenerator(candidate_k=K)
+    G.load_state_dict(gen_state())
+    return G.to(DEV).eval()
+
+
+def cpu_state():
+    return gen_state()
+
+
+GEN_CASES = [c for c in golden_names("gen_") if c != "weights"]
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+def test_generator_against_reference_vectors(case):
+    """Against the reference's own outputs: windows exact, scores within 1e-4 relative, picks exact
+    when the select kernel is fed the reference's scores, and exact end to end wherever the
+    reference's scores are a function of the candidate features (see util_golden.tie_consistent)."""
+    d = load("gen_" + case)
+    K = int(d["candidate_k"])
+    G = golden_generator(K)
+    tpl = Data(x=torch.from_numpy(d["x"]).to(DEV))
+    if "node_depth" in d.files:
+        tpl.node_depth = torch.from_numpy(d["node_depth"]).to(DEV)
+    z = torch.from_numpy(d["z"]).to(DEV)
+    out = G(tpl, z, return_debug=True)
+    torch.cuda.synchronize()
+    assert out.edge_index.dtype == torch.int64 and out.edge_attr.dtype == torch.int64
+    assert out.edge_index.shape == tuple(d["out_edge_index"].shape)
+    assert np.array_equal(out.edge_index[1].cpu().numpy(), d["out_edge_index"][1])
+    if "node_depth" in d.files:
+        assert np.array_equal(out.node_depth.cpu().numpy(), d["node_depth"])
+    plan = out._debug["plan"]
+    if "h_cond" in d.files:
+        np.testing.assert_allclose(out._debug["h_cond"].cpu().numpy()[: d["x"].shape[0]], d["h_cond"],
+                                   rtol=1e-4, atol=1e-5)
+    rank = plan.rank.cpu().numpy()
+    cand = plan.cand.cpu().numpy()
+    cnt = plan.cnt.cpu().numpy()
+    want = plan.want.cpu().numpy()
+    logits = out._debug["logits"].cpu().numpy()
+    sel = out._debug["sel"].cpu().numpy()
+    targets = golden_targets(d)
+    ref_rows = np.zeros((len(targets), K), np.float32)
+    ref_cnt, ref_want, ref_picks = [], [], []
+    all_consistent = True
+    for t, (v, ref_c, ref_l, picks) in enumerate(targets):
+        r = rank[v]
+        assert cnt[r] == len(ref_c)
+        assert np.array_equal(cand[r, :cnt[r]], ref_c)
+        np.testing.assert_allclose(logits[r, :cnt[r]], ref_l, rtol=1e-4, atol=1e-6)
+        ref_rows[t, :len(ref_l)] = ref_l
+        ref_cnt.append(len(ref_c))
+        ref_want.append(want[r])
+        ref_picks.append(picks + [-1] * (2 - len(picks)))
+        if tie_consistent(d["x"], ref_c, ref_l):
+            assert sel[r, :len(picks)].tolist() == picks, (case, v)
+        else:
+            all_consistent = False
+    got = run_select(ref_rows, np.asarray(ref_cnt), np.asarray(ref_want))
+    assert np.array_equal(got, np.asarray(ref_picks))
+    if all_consistent:
+        assert np.array_equal(out.edge_index.cpu().numpy(), d["out_edge_index"])
+        assert np.array_equal(out.edge_attr.cpu().numpy(), d["out_edge_attr"])
+        assert np.array_equal(out.x.cpu().numpy(), d["out_x"])
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+def test_generator_bit_exact_against_checker(case):
+    """Against the CPU checker's fixed-order form: every tensor identical, scores bit for bit."""
+    d = load("gen_" + case)
+    K = int(d["candidate_k"])
+    G = golden_generator(K)
+    x, z = torch.from_numpy(d["x"]), torch.from_numpy(d["z"])
+    nd = torch.from_numpy(d["node_depth"]) if "node_depth" in d.files else None
+    tpl = Data(x=x.to(DEV))
+    if nd is not None:
+        tpl.node_depth = nd.to(DEV)
+    out = G(tpl, z.to(DEV), return_debug=True)
+    ref = omodel.generator_forward_canonical(cpu_state(), x, nd, z, K)
+    n = x.size(0)
+    assert np.array_equal(out._debug["h_cond"].cpu().numpy()[:n].view(np.int32), ref["h_cond"].view(np.int32))
+    assert np.array_equal(out._debug["proj"].cpu().numpy()[:, :n].view(np.int32), ref["proj"].view(np.int32))
+    rank = out._debug["plan"].rank.cpu().numpy()
+    logits = out._debug["logits"].cpu().numpy()
+    for t, v in enumerate(ref["tgt"]):
+        c = int(ref["cnt"][t])
+        assert np.array_equal(logits[rank[v], :c].view(np.int32), ref["logits"][t, :c].view(np.int32))
+    assert np.array_equal(out.edge_index.cpu().numpy(), ref["edge_index"].numpy())
+    assert np.array_equal(out.edge_attr.cpu().numpy(), ref["edge_attr"].numpy())
+    assert np.array_equal(out.x.cpu().numpy(), ref["x"].numpy())
+
+
+def check_plan_against_checker(tpl_cpu: Data, K: int):
+    x = tpl_cpu.x
+    n = x.size(0)
+    nd = getattr(tpl_cpu, "node_depth", None)
+    plan = GeneratorPlan.build(x.to(DEV).float().contiguous(), None if nd is None else nd.to(DEV), K)
+    torch.cuda.synchronize()
+    types = x[:, 0].long().numpy()
+    depth = None if nd is None else nd.to(torch.float64).numpy()
+    order, rank = ocpu.build_order(types, depth)
+    assert np.array_equal(plan.order.cpu().numpy(), order)
+    assert np.array_equal(plan.rank.cpu().numpy(), rank)
+    assert np.array_equal(plan.types.cpu().numpy(), types)
+    tgt, cand, cnt, fb = ocpu.candidates(types, order, K)
+    want = plan.want.cpu().numpy()
+    slots = np.nonzero(want)[0]
+    assert np.array_equal(order[slots], tgt)
+    assert np.array_equal(plan.cnt.cpu().numpy()[slots], cnt)
+    assert np.array_equal(plan.fb.cpu().numpy()[slots], fb)
+    got = plan.cand.cpu().numpy()[slots]
+    mask = np.arange(K)[None, :] < cnt[:, None]
+    assert np.array_equal(np.where(mask, got, -1), np.where(mask, cand, -1))
+    # edge offsets: want[r] edges whenever the slot has a candidate or a fallback source
+    ne = np.zeros(n, np.int64)
+    ne[slots] = np.where((cnt > 0) | (fb >= 0), want[slots], 0)
+    eoff = plan.eoff.cpu().numpy()
+    assert np.array_equal(eoff, np.concatenate([[0], np.cumsum(ne)]))
+    assert plan.E == int(ne.sum())
+    return plan
+
+
+@pytest.mark.parametrize("K", [1, 3, 64, 65, 200, 512, 1000])
+@pytest.mark.parametrize("kind", ["forward", "dataset", "shuffled", "nodepth", "longdepth"])
+def test_plan_matches_checker(kind, K):
+    t = synth_aig(50, 900, 40, seed=K, window=300, orientation="dataset" if kind == "dataset" else "forward",
+                  shuffle_ids=(kind == "shuffled"))
+    if kind == "nodepth":
+        del t.node_depth
+    if kind == "longdepth":
+        t.node_depth = t.node_depth.long() - 1
+    check_plan_against_checker(t, K)
+
+
+def test_plan_large_graph_and_limits():
+    t = synth_aig(1000, 98000, 1000, seed=0, window=4096)
+    check_plan_against_checker(t, 64)
+    with pytest.raises(_abi.AigAbiError):
+        GeneratorPlan.build(t.x.to(DEV), None, 5000)  # beyond AIG_MAX_CANDIDATE_K
+    # empty template
+    e = GeneratorPlan.build(torch.zeros((0, 2), device=DEV), None, 8)
+    assert e.E == 0
+
+
+def run_select(values, cnt, want):
+    lib = _abi.lib()
+    rows, ld = values.shape
+    v = torch.from_numpy(values).to(DEV)
+    c = torch.from_numpy(cnt.astype(np.int32)).to(DEV)
+    w = torch.from_numpy(want.astype(np.int32)).to(DEV)
+    sel = torch.full((rows, 2), -7, dtype=torch.int32, device=DEV)
+    _abi.check(lib.aig_topk_select(rows, ld, _abi.ptr(v), _abi.ptr(c), _abi.ptr(w), _abi.ptr(sel), None, 0,
+                                   _abi.stream()))
+    torch.cuda.synchronize()
+    return sel.cpu().numpy()
+
+
+def test_select_matches_torch_topk_table():
+    d = load("topk_kat")
+    offs, vals = d["offsets"], d["values"]
+    rows = len(offs) - 1  # 2,560 rows: C = 1..512, five tie patterns each
+    mat = np.zeros((rows, 512), np.float32)
+    cnt = np.diff(offs)
+    for r in range(rows):
+        mat[r, :cnt[r]] = vals[offs[r]:offs[r + 1]]
+    s1 = run_select(mat, cnt, np.ones(rows))
+    assert np.array_equal(s1[:, 0], d["top1"])
+    assert (s1[:, 1] == -1).all()
+    s2 = run_select(mat, cnt, np.full(rows, 2))
+    two = cnt >= 2
+    assert np.array_equal(s2[two], d["top2"][two])
+    # a single candidate asked for two fan-ins: one pick, the caller repeats it
+    assert np.array_equal(s2[~two][:, 0], np.zeros((~two).sum())) and (s2[~two][:, 1] == -1).all()
+
+
+def test_select_matches_checker_on_random_rows():
+    rng = np.random.default_rng(3)
+    rows, ld = 5000, 1024
+    cnt = rng.integers(0, ld + 1, rows)
+    cnt[:200] = rng.integers(0, 130, 200)
+    want = rng.integers(0, 3, rows)
+    mat = np.zeros((rows, ld), np.float32)
+    for r in range(rows):
+        nlev = int(rng.integers(1, 12))
+        lv = rng.standard_normal(nlev).astype(np.float32)
+        row = rng.choice(lv, size=cnt[r]) if r % 3 else rng.standard_normal(cnt[r]).astype(np.float32)
+        if r % 17 == 0 and cnt[r] > 3:
+            row[rng.integers(0, cnt[r], 2)] = np.nan
+        if r % 19 == 0 and cnt[r] > 3:
+            row[rng.integers(0, cnt[r], 2)] = np.inf
+        mat[r, :cnt[r]] = row
+    got = run_select(mat, cnt, want)
+    ref = ocpu.topk_rows(mat, cnt, want)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("n_and,K", [(3000, 64), (1500, 256)])
+def test_generator_matches_checker_beyond_golden_sizes(n_and, K):
+    t = synth_aig(150, n_and, 80, seed=n_and, window=700, orientation="dataset")
+    z = torch.randn(128, generator=torch.Generator().manual_seed(1))
+    G = golden_generator(K)
+    out = G(Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV)), z.to(DEV))
+    ref = omodel.generator_forward_canonical(cpu_state(), t.x, t.node_depth, z, K)
+    assert np.array_equal(out.edge_index.cpu().numpy(), ref["edge_index"].numpy())
+    assert np.array_equal(out.edge_attr.cpu().numpy(), ref["edge_attr"].numpy())
+    assert np.array_equal(out.x.cpu().numpy(), ref["x"].numpy())
+
+
+def test_generator_full_size_properties():
+    """100k-node template (too slow for the CPU checker): structural invariants of the output."""
+    t = synth_aig(1000, 98000, 1000, seed=0, window=4096)
+    G = golden_generator(64)
+    tpl = Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV))
+    z = torch.randn(128, generator=torch.Generator().manual_seed(5)).to(DEV)
+    out = G(tpl, z)
+    out2 = G(tpl, z)  # cached plan, same z: identical
+    assert torch.equal(out.edge_index, out2.edge_index) and torch.equal(out.edge_attr, out2.edge_attr)
+    ei = out.edge_index.cpu().numpy()
+    types = t.x[:, 0].long().numpy()
+    depth = t.node_depth.numpy()
+    assert ei.shape[1] == 2 * 98000 + 1000
+    src, dst = ei
+    assert (types[src] != 1).all() and (types[dst] != 0).all() and (src != dst).all()
+    # sources are processed before their targets: (depth, id) strictly smaller
+    assert ((depth[src] < depth[dst]) | ((depth[src] == depth[dst]) & (src < dst))).all()
+    indeg = np.bincount(dst, minlength=types.size)
+    assert np.array_equal(indeg, np.where(types == 2, 2, np.where(types == 1, 1, 0)))
+    inv = out.edge_attr.cpu().numpy().reshape(-1)
+    assert set(np.unique(inv)) <= {0, 1}
+    assert np.array_equal(out.x.cpu().numpy()[:, 1], np.bincount(dst, weights=inv, minlength=types.size))
+
+
+def test_generator_requires_gpu_tensors():
+    G = golden_generator(8)
+    with pytest.raises(_abi.AigAbiError):
+        G(Data(x=torch.zeros(4, 2)), torch.zeros(128))
