@@ -1,0 +1,273 @@
+"""Edge-aware GAT critic on MI355X kernels.
+
+Drop-in for ``models.discriminator.AIGDiscriminator`` of the reference
+(models/discriminator.py:13-100): same constructor, same parameter names as a PyG
+``GATConv(edge_dim=1)`` state dict (``gat1.lin.weight``, ``gat1.att_src`` ...; the older
+``lin_src`` / ``lin_dst`` spelling is accepted on load), same ``forward(data) -> Tensor[1]``
+(ONE score per call, also for a ``Batch`` of several graphs: all of them are pooled by level
+together, discriminator.py:89-100).
+
+Where the work runs:
+* dense projections ``x W^T`` and the 256-128-64-1 head: torch (rocBLAS), with autograd;
+* attention logits, per-target softmax, neighbour aggregation, bias and ELU: one fused HIP
+  kernel over a by-target CSR (``aig_gat_fwd``), backward in ``aig_gat_bwd``;
+* level-wise mean/max readout: one HIP pass (``aig_level_pool_fwd``); its backward is a weighted
+  broadcast plus a scatter expressed in torch ops so that it can be differentiated again;
+* a graph without edges (the gradient-penalty interpolate of train.py:141-152) needs no kernel
+  in the attention layers: softmax over the lone self loop is exactly 1, so a layer is
+  ``elu(x W^T + bias)`` and the whole pass supports double backward.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
+
+from . import _abi
+from .data import Data
+
+HIDDEN = 128
+
+
+class GraphCSR:
+    """By-target and by-source edge lists of one (batched) graph, built on the GPU once."""
+
+    def __init__(self, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], n: int):
+        lib = _abi.lib()
+        dev = edge_index.device
+        E = int(edge_index.size(1))
+        self.n, self.E = int(n), E
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.row_ptr = torch.empty(n + 1, **i32)
+        self.col_ptr = torch.empty(n + 1, **i32)
+        self.csr_src = torch.empty(max(E, 1), **i32)
+        self.csr_eid = torch.empty(max(E, 1), **i32)
+        self.csc_pos = torch.empty(max(E, 1), **i32)
+        self.csc_dst = torch.empty(max(E, 1), **i32)
+        self.csr_ea = torch.empty(max(E, 1), **f32)
+        self.loop_ea = torch.empty(max(n, 1), **f32)
+        ei = edge_index.contiguous()
+        ea = None if edge_attr is None else edge_attr.reshape(-1).float().contiguous()
+        ws = _abi.workspace(lib.aig_gat_csr_ws_bytes(n, E), dev)
+        _abi.check(lib.aig_gat_csr(n, E, _abi.ptr(ei) if E else None, _abi.ptr(ea) if E else None,
+                                   _abi.ptr(self.row_ptr), _abi.ptr(self.csr_src), _abi.ptr(self.csr_ea),
+                                   _abi.ptr(self.csr_eid), _abi.ptr(self.loop_ea), _abi.ptr(self.col_ptr),
+                                   _abi.ptr(self.csc_pos), _abi.ptr(self.csc_dst), _abi.ptr(ws), ws.numel(),
+                                   _abi.stream()), "aig_gat_csr")
+
+
+class LevelPlan:
+    """Nodes grouped by depth level (negative depth = ignored)."""
+
+    def __init__(self, node_depth: Optional[torch.Tensor], n: int, device):
+        lib = _abi.lib()
+        L = 0
+        depth = None
+        if node_depth is not None and n > 0:
+            nd = node_depth.to(device)
+            top = int(nd.max().item())  # host read, once per depth vector (the plan is cached)
+            if top >= 0:                # otherwise no valid level: pool over all nodes (discriminator.py:68-72)
+                L = top
+                depth = nd.to(torch.int64).contiguous()
+        self.n, self.L = int(n), int(L)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.perm = torch.empty(max(n, 1), **i32)
+        self.node_level = torch.empty(max(n, 1), **i32)
+        self.lvl_ptr = torch.empty(L + 2, **i32)
+        self.w = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+        ws = _abi.workspace(lib.aig_level_plan_ws_bytes(n, L), device)
+        _abi.check(lib.aig_level_plan(n, L, _abi.ptr(depth), _abi.ptr(self.perm), _abi.ptr(self.lvl_ptr),
+                                      _abi.ptr(self.node_level), _abi.ptr(self.w), _abi.ptr(ws), ws.numel(),
+                                      _abi.stream()), "aig_level_plan")
+        self.nvalid = int(self.lvl_ptr[L + 1].item()) if n > 0 else 0
+
+
+class _GATAggregate(torch.autograd.Function):
+    """softmax-attention aggregation + bias + ELU over a GraphCSR (first-order differentiable)."""
+
+    @staticmethod
+    def forward(ctx, xw, att_src, att_dst, ce, bias, csr: GraphCSR):
+        lib = _abi.lib()
+        n, dev = csr.n, xw.device
+        xw = xw.contiguous()
+        att_src, att_dst, ce, bias = (t.detach().contiguous() for t in (att_src, att_dst, ce, bias))
+        f32 = dict(dtype=torch.float32, device=dev)
+        a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
+        out = torch.empty((n, HIDDEN), **f32)
+        alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
+        alpha_loop = torch.empty((max(n, 1), 4), **f32)
+        _abi.check(lib.aig_gat_fwd(n, _abi.ptr(xw), _abi.ptr(att_src), _abi.ptr(att_dst), _abi.ptr(ce),
+                                   _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
+                                   _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(a_s), _abi.ptr(a_d),
+                                   _abi.ptr(out), _abi.ptr(alpha_e), _abi.ptr(alpha_loop), _abi.stream()),
+                   "aig_gat_fwd")
+        ctx.csr = csr
+        ctx.save_for_backward(xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        lib = _abi.lib()
+        csr: GraphCSR = ctx.csr
+        xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop = ctx.saved_tensors
+        n, dev = csr.n, xw.device
+        g_out = g_out.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_xw = torch.empty((n, HIDDEN), **f32)
+        d_as, d_ad, d_bias = torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32)
+        d_ce = torch.empty(4, **f32)
+        ws = _abi.workspace(lib.aig_gat_bwd_ws_bytes(n, csr.E), dev)
+        _abi.check(lib.aig_gat_bwd(n, csr.E, _abi.ptr(g_out), _abi.ptr(out), _abi.ptr(xw), _abi.ptr(att_src),
+                                   _abi.ptr(att_dst), _abi.ptr(ce), _abi.ptr(a_s), _abi.ptr(a_d),
+                                   _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea),
+                                   _abi.ptr(csr.loop_ea), _abi.ptr(csr.col_ptr), _abi.ptr(csr.csc_pos),
+                                   _abi.ptr(csr.csc_dst), _abi.ptr(alpha_e), _abi.ptr(alpha_loop),
+                                   _abi.ptr(d_xw), _abi.ptr(d_as), _abi.ptr(d_ad), _abi.ptr(d_ce), _abi.ptr(d_bias),
+                                   _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_gat_bwd")
+        return d_xw, d_as, d_ad, d_ce, d_bias, None
+
+
+class _LevelPool(torch.autograd.Function):
+    """[n,128] -> [1,256] level-wise mean || max readout."""
+
+    @staticmethod
+    def forward(ctx, h, plan: LevelPlan):
+        lib = _abi.lib()
+        dev = h.device
+        h = h.contiguous()
+        out = torch.empty((1, 2 * HIDDEN), dtype=torch.float32, device=dev)
+        argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
+        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), dev)
+        _abi.check(lib.aig_level_pool_fwd(plan.n, plan.nvalid, plan.L, _abi.ptr(h), _abi.ptr(plan.perm),
+                                          _abi.ptr(plan.lvl_ptr), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+                                          _abi.ptr(out), _abi.ptr(argmax), _abi.ptr(ws), ws.numel(), _abi.stream()),
+                   "aig_level_pool_fwd")
+        ctx.plan = plan
+        ctx.n = int(h.size(0))
+        ctx.save_for_backward(argmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # Linear in g with constant coefficients, written with differentiable torch ops so that the
+        # gradient penalty can back-propagate through it a second time.
+        plan: LevelPlan = ctx.plan
+        (argmax,) = ctx.saved_tensors
+        n = ctx.n
+        d_h = g[:, :HIDDEN] * plan.w[:n].unsqueeze(1)
+        has = (argmax >= 0)
+        src = (g[:, HIDDEN:] / float(plan.L + 1)).expand(plan.L + 1, HIDDEN) * has
+        d_h = d_h.scatter_add(0, argmax.clamp(min=0).long(), src)
+        return d_h, None
+
+
+def _glorot_(t: torch.Tensor) -> torch.Tensor:
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        return t.uniform_(-a, a)
+
+
+class GATLayer(nn.Module):
+    """Parameters of ``GATConv(in_dim, hidden/heads, heads, edge_dim=1, concat=True)``; the forward
+    pass also applies the ELU that follows each layer in the critic (fused in the kernel)."""
+
+    def __init__(self, in_dim: int, out_per_head: int, heads: int):
+        super().__init__()
+        self.heads, self.out_per_head = heads, out_per_head
+        self.lin = nn.Linear(in_dim, heads * out_per_head, bias=False)
+        self.lin_edge = nn.Linear(1, heads * out_per_head, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_per_head))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_per_head))
+        self.att_edge = nn.Parameter(torch.empty(1, heads, out_per_head))
+        self.bias = nn.Parameter(torch.zeros(heads * out_per_head))
+        for t in (self.lin.weight, self.lin_edge.weight, self.att_src, self.att_dst, self.att_edge):
+            _glorot_(t)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # older PyG releases store the shared projection as lin_src (and a tied lin_dst)
+        src, dst = prefix + "lin_src.weight", prefix + "lin_dst.weight"
+        if src in state_dict and prefix + "lin.weight" not in state_dict:
+            state_dict[prefix + "lin.weight"] = state_dict.pop(src)
+            state_dict.pop(dst, None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x: torch.Tensor, csr: Optional[GraphCSR]) -> torch.Tensor:
+        xw = self.lin(x)
+        if csr is None or csr.E == 0:
+            # only self loops: alpha = 1/(1 + 1e-16) = 1 in fp32
+            return F.elu(xw + self.bias)
+        ce = (self.lin_edge.weight.view(self.heads, self.out_per_head) *
+              self.att_edge.view(self.heads, self.out_per_head)).sum(-1)
+        return _GATAggregate.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), ce, self.bias, csr)
+
+
+class _Cache(OrderedDict):
+    def __init__(self, cap: int = 16):
+        super().__init__()
+        self.cap = cap
+
+    def lookup(self, key, make):
+        if key in self:
+            self.move_to_end(key)
+            return self[key]
+        v = make()
+        self[key] = v
+        if len(self) > self.cap:
+            self.popitem(last=False)
+        return v
+
+
+def _tkey(t: Optional[torch.Tensor]):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+
+class AIGDiscriminator(nn.Module):
+    def __init__(self, in_dim: int = 2, hidden_dim: int = 128, heads: int = 4):
+        super().__init__()
+        assert hidden_dim % heads == 0, "hidden_dim must be divisible by heads"
+        self.hidden_dim = hidden_dim
+        self.heads = heads
+        self.gat1 = GATLayer(in_dim, hidden_dim // heads, heads)
+        self.gat2 = GATLayer(hidden_dim, hidden_dim // heads, heads)
+        self.mlp = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.ReLU(),
+                                 nn.Linear(hidden_dim, hidden_dim // 2), nn.ReLU())
+        self.out = nn.Linear(hidden_dim // 2, 1)
+        if (hidden_dim, heads) != (128, 4):
+            raise NotImplementedError("the MI355X kernels are built for hidden_dim=128, heads=4 (reference defaults)")
+        self._csr_cache = _Cache()
+        self._lvl_cache = _Cache()
+
+    # graph structure is weight-independent, so the several critic evaluations of one training
+    # step (train.py:246-283 calls D ten times on three edge lists) share one CSR / level plan
+    def graph_csr(self, edge_index, edge_attr, n) -> GraphCSR:
+        key = (_tkey(edge_index), _tkey(edge_attr), n)
+        # keep the keyed tensors alive with the entry so a recycled address cannot alias
+        return self._csr_cache.lookup(key, lambda: (GraphCSR(edge_index, edge_attr, n), edge_index, edge_attr))[0]
+
+    def level_plan(self, node_depth, n, device) -> LevelPlan:
+        key = (_tkey(node_depth), n)
+        return self._lvl_cache.lookup(key, lambda: (LevelPlan(node_depth, n, device), node_depth))[0]
+
+    def forward(self, data: Data) -> torch.Tensor:
+        x = data.x.float()
+        if x.device.type != "cuda":
+            raise _abi.AigAbiError("AIGDiscriminator.forward needs the graph on a HIP device (no CPU path exists)")
+        n = int(x.size(0))
+        edge_index = data.edge_index
+        has_edges = edge_index is not None and edge_index.numel() > 0
+        edge_attr = data.edge_attr if (hasattr(data, "edge_attr") and data.edge_attr is not None) else None
+        csr = self.graph_csr(edge_index, edge_attr, n) if has_edges else None
+        h = self.gat1(x, csr)
+        h = self.gat2(h, csr)
+        nd = data.node_depth if (hasattr(data, "node_depth") and data.node_depth is not None) else None
+        plan = self.level_plan(nd, n, x.device)
+        graph_repr = _LevelPool.apply(h, plan)           # [1, 2H]
+        g = self.mlp(graph_repr)
+        return self.out(g).view(-1)

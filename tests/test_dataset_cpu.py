@@ -1,0 +1,63 @@
+"""Host-side data plumbing against the reference's own outputs (no GPU needed)."""
+import os
+
+import numpy as np
+import torch
+
+from gan_amd.data import Batch, Data, GraphLoader
+from gan_amd.dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
+from util_golden import load
+
+
+def test_pad_unpad_match_reference():
+    d = load("pad_c17")
+    g = Data(x=torch.from_numpy(d["x"]), edge_index=torch.from_numpy(d["edge_index"]),
+             edge_attr=torch.from_numpy(d["edge_attr"]), node_depth=torch.from_numpy(d["node_depth"]))
+    p = pad_data(g, 20, 30)
+    for k in ("x", "edge_index", "edge_attr", "node_depth"):
+        got = getattr(p, k)
+        assert np.array_equal(got.numpy(), d["pad_" + k]), k
+        assert got.dtype == torch.from_numpy(d["pad_" + k]).dtype, k
+    u = unpad_data(p)
+    for k in ("x", "edge_index", "edge_attr", "node_depth"):
+        assert np.array_equal(getattr(u, k).numpy(), d["unpad_" + k]), k
+    # private size attributes do not survive batching: the graph stays padded
+    (back,) = Batch.from_data_list([p]).to_data_list()
+    assert not hasattr(back, "_orig_n")
+    u2 = unpad_data(back)
+    assert np.array_equal(u2.x.numpy(), d["unpad2_x"])
+    assert np.array_equal(u2.edge_index.numpy(), d["unpad2_edge_index"])
+
+
+def test_pad_truncates_and_defaults_depth():
+    g = Data(x=torch.ones(3, 2), edge_index=torch.tensor([[0, 1, 2], [1, 2, 0]]), edge_attr=torch.ones(3, 1))
+    p = pad_data(g, 5, 2)
+    assert p.edge_index.tolist() == [[0, 1], [1, 2]] and p._orig_e == 3
+    assert p.node_depth.tolist() == [0, 0, 0, -1, -1]
+
+
+def test_batch_shifts_every_index_including_sentinels():
+    a = pad_data(Data(x=torch.zeros(2, 2), edge_index=torch.tensor([[0], [1]]), edge_attr=torch.ones(1, 1)), 3, 2)
+    b = Batch.from_data_list([a, a])
+    assert b.edge_index.tolist() == [[0, -1, 3, 2], [1, -1, 4, 2]]   # second graph: -1 + 3 = 2, a self loop
+    assert b.batch.tolist() == [0, 0, 0, 1, 1, 1] and b.ptr.tolist() == [0, 3, 6]
+    parts = b.to_data_list()
+    assert parts[1].edge_index.tolist() == [[0, -1], [1, -1]]
+
+
+def test_pt_round_trip(tmp_path):
+    g = Data(x=torch.rand(4, 2), edge_index=torch.tensor([[0, 1], [2, 3]]), edge_attr=torch.tensor([[1], [0]]),
+             node_depth=torch.tensor([0, 0, 1, 1]))
+    save_data_list_as_pt([g, g], str(tmp_path), prefix="s", start_idx=3)
+    assert sorted(os.listdir(tmp_path)) == ["s_000003.pt", "s_000004.pt"]
+    back = load_pt_dataset(str(tmp_path), max_files=1)
+    assert len(back) == 1 and torch.equal(back[0].x, g.x) and torch.equal(back[0].node_depth, g.node_depth)
+
+
+def test_loader_shards_batches_across_ranks():
+    items = [Data(x=torch.full((1, 2), float(i))) for i in range(10)]
+    full = [b.sample_ids for b in GraphLoader(items, batch_size=2, seed=5)]
+    r0 = [b.sample_ids for b in GraphLoader(items, batch_size=2, seed=5, rank=0, world_size=2)]
+    r1 = [b.sample_ids for b in GraphLoader(items, batch_size=2, seed=5, rank=1, world_size=2)]
+    assert len(r0) == len(r1) == 2                      # 5 batches -> 4 usable, 2 per rank
+    assert r0 == full[0:4:2] and r1 == full[1:4:2]
