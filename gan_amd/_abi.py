@@ -50,6 +50,14 @@ SIGNATURES = {
     "aig_level_plan": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),
     "aig_level_pool_fwd": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, SZ, P]),
+    "aig_enforce_ws_bytes": (SZ, [I64, I64]),
+    "aig_enforce": (INT, [I64, I64, P, P, P, INT, P, P, I64, P, P, P, P, P, SZ, P]),
+    "aig_penalties_ws_bytes": (SZ, [I64, I64]),
+    "aig_penalties": (INT, [I64, I64, P, P, P, P, SZ, P]),
+    "aig_validate_ws_bytes": (SZ, [I64, I64]),
+    "aig_validate": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "aig_resync_ws_bytes": (SZ, [I64, I64]),
+    "aig_resync": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
 }
 
 _lib = None

@@ -1,0 +1,653 @@
+// AIG structural constraints as linear-time integer kernels: repair (enforce), violation counts
+// (penalties), strict validation verdicts, attribute resync.  All byte/integer work: sorts for
+// grouping and de-duplication, integer atomics (order independent), level-synchronous traversals.
+#include <climits>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace aig {
+namespace {
+
+constexpr int PI_T = 0, PO_T = 1, AND_T = 2;
+constexpr int TRAV_THREADS = 1024;
+
+struct Cnt4 {
+    int a, b, c, d;
+};
+struct Cnt4Plus {
+    __host__ __device__ Cnt4 operator()(const Cnt4& x, const Cnt4& y) const {
+        return {x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d};
+    }
+};
+
+// ------------------------------------------------------------------------------------------ types and pos
+__global__ void k_type_flags(int n, const float* __restrict__ x, int* __restrict__ types, Cnt4* __restrict__ flags) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        if (i == n) { flags[n] = {0, 0, 0, 0}; continue; }
+        int t = static_cast<int>(x[2 * i]);
+        types[i] = t;
+        flags[i] = {t == PI_T, t == AND_T, t == PO_T, (t != PI_T && t != AND_T && t != PO_T)};
+    }
+}
+// pos = rank in (all PI, all AND, all PO, anything else), index order inside a group
+// (constraints.py:118-132).  scan[n] holds the group totals.
+__global__ void k_pos(int n, const int* __restrict__ types, const Cnt4* __restrict__ scan, int* __restrict__ pos,
+                      int* __restrict__ small /*[3]*/) {
+    const Cnt4 tot = scan[n];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = types[i];
+        const Cnt4 s = scan[i];
+        int p = t == PI_T ? s.a : t == AND_T ? tot.a + s.b : t == PO_T ? tot.a + tot.b + s.c : tot.a + tot.b + tot.c + s.d;
+        pos[i] = p;
+        if (small && p < 3 && (t == PI_T || t == AND_T)) small[p] = i;
+    }
+}
+
+__device__ __forceinline__ bool in_range(long long u, long long v, int n) { return u >= 0 && u < n && v >= 0 && v < n; }
+
+// ------------------------------------------------------------------------------------------ sort helpers
+int bits_for(unsigned long long maxval) {
+    int b = 1;
+    while (b < 64 && (1ull << b) <= maxval) ++b;
+    return b;
+}
+template <typename K>
+size_t sort_temp(int64_t E, int bits) {
+    size_t bytes = 0;
+    K* k = nullptr;
+    int* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(E > 0 ? E : 1), 0, bits, hipStream_t(0));
+    return bytes;
+}
+size_t scan_temp(int64_t n) {
+    size_t bytes = 0;
+    int* p = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, p, p, 0, (size_t)n, rocprim::plus<int>(), hipStream_t(0));
+    size_t b4 = 0;
+    Cnt4* q = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, b4, q, q, Cnt4{0, 0, 0, 0}, (size_t)n, Cnt4Plus(), hipStream_t(0));
+    return bytes > b4 ? bytes : b4;
+}
+
+template <typename K>
+__global__ void k_segment_ptr(int n, int E, const K* __restrict__ skey, K scale, int* __restrict__ ptr) {
+    // ptr[v] = first sorted position whose key is >= v*scale, v = 0..n
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += gridDim.x * blockDim.x) {
+        const K target = (K)v * scale;
+        int lo = 0, hi = E;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (skey[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        ptr[v] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ traversal
+// Level-synchronous frontier walk by ONE workgroup over CSR (ptr, adj).
+//   MODE 0: breadth-first levels; depth[] preset to 0 on the sources and -1 elsewhere.
+//   MODE 1: Kahn peel; state[] = indegree, every node released in the round after its last
+//           predecessor, so depth = longest-path level; *popped counts released nodes.
+// Every wave leaves through the same `break` (the frontier size is read between two barriers),
+// and the loop ends after at most n rounds because a node enters a queue at most once.
+template <int MODE>
+__global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, const int* __restrict__ ptr,
+                                                           const int* __restrict__ adj, int* __restrict__ state,
+                                                           int* __restrict__ depth, int* __restrict__ q0,
+                                                           int* __restrict__ q1, int* __restrict__ popped) {
+    __shared__ int s_cnt[2];
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_cnt[0] = s_cnt[1] = 0; s_total = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += TRAV_THREADS) {
+        bool start;
+        if (MODE == 0) start = depth[i] == 0;
+        else { start = state[i] == 0; depth[i] = 0; }
+        if (start) q0[atomicAdd(&s_cnt[0], 1)] = i;
+    }
+    int cur = 0;
+    for (int level = 0; level <= n; ++level) {
+        __syncthreads();
+        const int c = s_cnt[cur];
+        __syncthreads();
+        if (c == 0) break;
+        if (tid == 0) { s_cnt[cur ^ 1] = 0; s_total += c; }
+        __syncthreads();
+        const int* qc = cur ? q1 : q0;
+        int* qn = cur ? q0 : q1;
+        for (int idx = tid; idx < c; idx += TRAV_THREADS) {
+            const int u = qc[idx];
+            for (int e = ptr[u]; e < ptr[u + 1]; ++e) {
+                const int v = adj[e];
+                if (MODE == 0) {
+                    if (atomicCAS(&depth[v], -1, level + 1) == -1) qn[atomicAdd(&s_cnt[cur ^ 1], 1)] = v;
+                } else {
+                    if (atomicSub(&state[v], 1) == 1) {
+                        depth[v] = level + 1;
+                        qn[atomicAdd(&s_cnt[cur ^ 1], 1)] = v;
+                    }
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    if (tid == 0 && popped) *popped = s_total;
+}
+
+// adjacency in sorted order: adj[p] = other endpoint of edge sid[p]
+__global__ void k_gather_adj(int m, const int* __restrict__ sid, const long long* __restrict__ endpoint,
+                             int* __restrict__ adj) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x)
+        adj[p] = (int)endpoint[sid[p]];
+}
+
+__global__ void k_seed_depth(int n, const int* __restrict__ types, int want_type, int* __restrict__ depth) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        depth[i] = types[i] == want_type ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------ enforce
+// key of a cleaned edge = v*n + u (grouped by target, then source); dropped edges sort last
+__global__ void k_enf_keys(int n, int E, const long long* __restrict__ ei, const int* __restrict__ pos,
+                           unsigned long long* __restrict__ key, unsigned* __restrict__ key_src, int* __restrict__ ids) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        long long u = ei[e], v = ei[(size_t)E + e];
+        bool ok = u != v && in_range(u, v, n) && pos[u] < pos[v];
+        key[e] = ok ? (unsigned long long)v * (unsigned long long)n + (unsigned long long)u : ~0ull;
+        key_src[e] = ok ? (unsigned)u : (unsigned)n;
+        ids[e] = e;
+    }
+}
+
+// head[p] = first of a run of equal (u,v); minv[p] at a head = merged inversion value of the run:
+// the first occurrence's value, raised to 1 if it was 0 and any repeat carries 1 (constraints.py:36-41)
+__global__ void k_enf_merge(int m_total, const unsigned long long* __restrict__ skey, const int* __restrict__ sid,
+                            const long long* __restrict__ inv, long long* __restrict__ minv) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m_total; p += gridDim.x * blockDim.x) {
+        const unsigned long long k = skey[p];
+        if (k == ~0ull) continue;
+        if (p > 0 && skey[p - 1] == k) { minv[p] = LLONG_MIN; continue; }  // not a head
+        long long val = inv ? inv[sid[p]] : 0;
+        for (int q = p + 1; q < m_total && skey[q] == k; ++q)
+            if (val == 0 && inv && inv[sid[q]] == 1) val = 1;
+        minv[p] = val;
+    }
+}
+
+struct Pick {
+    int s0, s1;
+    long long i0, i1;
+    int count;
+};
+
+__device__ __forceinline__ long long depth_trunc(int kind, const void* depth, int u) {
+    if (kind == 1) return (long long)static_cast<const float*>(depth)[u];  // int(): toward zero
+    if (kind == 2) return static_cast<const long long*>(depth)[u];
+    return 0;
+}
+
+// one thread per target: choose the fan-ins to keep (constraints.py:558-620) and sum inversions
+__global__ void k_enf_select(int n, const int* __restrict__ types, const int* __restrict__ pos,
+                             const int* __restrict__ small, const Cnt4* __restrict__ scan,
+                             const unsigned long long* __restrict__ skey, const long long* __restrict__ minv,
+                             const int* __restrict__ vptr, int depth_kind, const void* __restrict__ depth,
+                             Pick* __restrict__ picks, int* __restrict__ pick_cnt, float* __restrict__ x_out,
+                             const float* __restrict__ x) {
+    const Cnt4 tot = scan[n];
+    const int n_src_nodes = tot.a + tot.b;  // PI + AND
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += gridDim.x * blockDim.x) {
+        if (v == n) { pick_cnt[n] = 0; continue; }
+        const int t = types[v];
+        const int beg = vptr[v], end = vptr[v + 1];
+        Pick pk{-1, -1, 0, 0, 0};
+        long long inv_sum = 0;
+        int nl = 0;
+        int b_and = 0; long long b_dep = 0;  // PO: best so far
+        int p1 = INT_MAX, p2 = INT_MAX;      // AND: two smallest pos
+        for (int p = beg; p < end; ++p) {
+            const long long iv = minv[p];
+            if (iv == LLONG_MIN) continue;  // repeat of the previous pair
+            inv_sum += iv;
+            const int u = (int)(skey[p] - (unsigned long long)v * (unsigned long long)n);
+            const int tu = types[u];
+            if (!(tu == PI_T || tu == AND_T)) continue;
+            ++nl;
+            if (t == PO_T) {
+                const int is_and = tu == AND_T;
+                const long long dep = depth_trunc(depth_kind, depth, u);
+                bool better;
+                if (pk.s0 < 0) better = true;
+                else if (is_and != b_and) better = is_and > b_and;
+                else if (dep != b_dep) better = dep > b_dep;
+                else better = u < pk.s0;
+                if (better) { pk.s0 = u; pk.i0 = iv; b_and = is_and; b_dep = dep; }
+            } else if (t == AND_T) {
+                const int pu = pos[u];
+                if (pu < p1) { p2 = p1; pk.s1 = pk.s0; pk.i1 = pk.i0; p1 = pu; pk.s0 = u; pk.i0 = iv; }
+                else if (pu < p2) { p2 = pu; pk.s1 = u; pk.i1 = iv; }
+            }
+        }
+        if (t == PO_T) pk.count = nl >= 1 ? 1 : 0;
+        else if (t == AND_T) {
+            if (nl >= 2) pk.count = 2;
+            else if (n_src_nodes - 1 >= 2) {
+                // widen with every other PI/AND node (inversion 0): the two smallest pos besides v
+                int c0 = -1, c1 = -1;
+                for (int j = 0; j < 3; ++j) {
+                    int u = j < n_src_nodes ? small[j] : -1;
+                    if (u < 0 || u == v) continue;
+                    if (c0 < 0) c0 = u; else if (c1 < 0) c1 = u;
+                }
+                const int legal = nl == 1 ? pk.s0 : -1;
+                const long long legal_inv = pk.i0;
+                pk.s0 = c0; pk.i0 = (c0 == legal) ? legal_inv : 0;
+                pk.s1 = c1; pk.i1 = (c1 == legal) ? legal_inv : 0;
+                pk.count = (c0 >= 0 && c1 >= 0) ? 2 : 0;
+            }
+        }
+        picks[v] = pk;
+        pick_cnt[v] = pk.count;
+        x_out[2 * v] = x[2 * v];
+        x_out[2 * v + 1] = (float)(inv_sum > 2 ? 2 : inv_sum);
+    }
+}
+
+__global__ void k_enf_write(int n, long long cap, const Pick* __restrict__ picks, const int* __restrict__ off,
+                            long long* __restrict__ out_ei, long long* __restrict__ out_ea, int* __restrict__ out_count) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        const Pick pk = picks[v];
+        const int o = off[v];
+        if (pk.count >= 1) { out_ei[o] = pk.s0; out_ei[cap + o] = v; out_ea[o] = pk.i0; }
+        if (pk.count >= 2) { out_ei[o + 1] = pk.s1; out_ei[cap + o + 1] = v; out_ea[o + 1] = pk.i1; }
+        if (v == 0) *out_count = off[n];
+    }
+}
+
+__global__ void k_widen_i32_i64(int n, const int* __restrict__ in, long long* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+// ------------------------------------------------------------------------------------------ penalties / validate
+// counters: 0 pi_in, 1 po_out, 2 backedge, 3 selfloop, 4 fanin_type
+__global__ void k_pen_edges(int n, int E, const long long* __restrict__ ei, const int* __restrict__ types,
+                            const int* __restrict__ pos, int* __restrict__ counters, int* __restrict__ indeg,
+                            unsigned long long* __restrict__ pair_key, unsigned* __restrict__ key_src,
+                            unsigned* __restrict__ key_dst, int* __restrict__ ids, unsigned char* __restrict__ eflag) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        long long u = ei[e], v = ei[(size_t)E + e];
+        ids[e] = e;
+        if (!in_range(u, v, n)) {  // the reference cannot index such an edge; it is left out of every count
+            pair_key[e] = ~0ull; key_src[e] = (unsigned)n; key_dst[e] = (unsigned)n;
+            if (eflag) eflag[e] = 0;
+            continue;
+        }
+        const int tu = types[u], tv = types[v];
+        const bool self = u == v, to_pi = tv == PI_T, from_po = tu == PO_T, back = !(pos[u] < pos[v]);
+        const bool bad_src = (tv == AND_T || tv == PO_T) && !(tu == PI_T || tu == AND_T);
+        if (counters) {
+            if (to_pi) atomicAdd(&counters[0], 1);
+            if (from_po) atomicAdd(&counters[1], 1);
+            if (back) atomicAdd(&counters[2], 1);
+            if (self) atomicAdd(&counters[3], 1);
+            if (bad_src) atomicAdd(&counters[4], 1);
+        }
+        if (eflag) eflag[e] = (unsigned char)((self ? 1 : 0) | (to_pi ? 4 : 0) | (from_po ? 8 : 0) | (bad_src ? 16 : 0));
+        atomicAdd(&indeg[v], 1);
+        pair_key[e] = (unsigned long long)u * (unsigned long long)n + (unsigned long long)v;
+        key_src[e] = (unsigned)u;
+        key_dst[e] = (unsigned)v;
+    }
+}
+
+// counters[5] += repeats of an already seen (u,v); flags those edges with bit 2 (validator)
+__global__ void k_pen_dups(int E, const unsigned long long* __restrict__ skey, const int* __restrict__ sid,
+                           int* __restrict__ counters, unsigned char* __restrict__ eflag) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E; p += gridDim.x * blockDim.x) {
+        if (p == 0 || skey[p] == ~0ull || skey[p] != skey[p - 1]) continue;
+        if (counters) atomicAdd(&counters[5], 1);
+        if (eflag) eflag[sid[p]] |= 2;
+    }
+}
+
+// counters[6] += |indeg - target|; counters[7] += node not (reached forward from a PI and backward from a PO)
+__global__ void k_pen_nodes(int n, const int* __restrict__ types, const int* __restrict__ indeg,
+                            const int* __restrict__ fwd, const int* __restrict__ rev, int* __restrict__ counters,
+                            unsigned char* __restrict__ on_path) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = types[i];
+        const int target = t == PO_T ? 1 : (t == AND_T ? 2 : 0);
+        const int d = indeg[i] - target;
+        if (d) atomicAdd(&counters[6], d < 0 ? -d : d);
+        const bool ok = fwd[i] >= 0 && rev[i] >= 0;
+        if (!ok) atomicAdd(&counters[7], 1);
+        if (on_path) on_path[i] = ok;
+    }
+}
+
+__global__ void k_pen_finish(const int* __restrict__ c, float* __restrict__ out) {
+    // pi_in, po_out, backedge, selfloop, dup_fanin, indeg_mse, fanin_type, reach_violation, total
+    float pi_in = (float)c[0], po_out = (float)c[1], back = (float)c[2], self = (float)c[3], ftype = (float)c[4],
+          dup = (float)c[5], mse = (float)c[6], reach = (float)c[7];
+    out[0] = pi_in; out[1] = po_out; out[2] = back; out[3] = self; out[4] = dup; out[5] = mse; out[6] = ftype;
+    out[7] = reach;
+    // summed in the reference's dict order, weights 1,1,2,3,1,1,1,0.5 (constraints.py:341-364)
+    float total = 0.f;
+    total += 1.0f * pi_in; total += 1.0f * po_out; total += 2.0f * back; total += 3.0f * self;
+    total += 1.0f * dup; total += 1.0f * mse; total += 1.0f * ftype; total += 0.5f * reach;
+    out[8] = total;
+}
+
+// per-node verdicts of the strict validator (constraints.py:398-462)
+__global__ void k_val_nodes(int n, const int* __restrict__ types, const int* __restrict__ indeg,
+                            const int* __restrict__ dptr, const int* __restrict__ dadj /*src by target, edge order*/,
+                            unsigned char* __restrict__ ncode, int* __restrict__ pred2) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = types[i], d = indeg[i];
+        const int b = dptr[i];
+        const int f0 = d > 0 ? dadj[b] : -1, f1 = d > 1 ? dadj[b + 1] : -1;
+        pred2[2 * i] = f0;
+        pred2[2 * i + 1] = f1;
+        unsigned char code = 0;
+        if (t != PI_T && t != PO_T && t != AND_T) code = 1;
+        else if (t == PO_T && d != 1) code = 2;
+        else if (t == AND_T && d != 2) code = 3;
+        else if (t == AND_T && f0 == f1) code = 4;
+        ncode[i] = code;
+    }
+}
+
+__global__ void k_val_summary(int n, const int* __restrict__ popped, const int* __restrict__ counters,
+                              int* __restrict__ summary) {
+    summary[0] = popped[0] != n;  // Kahn left nodes behind: a cycle (a self loop counts)
+    summary[1] = counters[7];
+}
+
+// ------------------------------------------------------------------------------------------ resync
+__global__ void k_rs_edges(int n, int E, const long long* __restrict__ ei, const long long* __restrict__ inv,
+                           int* __restrict__ inv_cnt, int* __restrict__ indeg, unsigned* __restrict__ key_src,
+                           int* __restrict__ ids) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        long long u = ei[e], v = ei[(size_t)E + e];
+        ids[e] = e;
+        const bool ok = in_range(u, v, n);
+        if (v >= 0 && v < n && inv && inv[e] == 1) atomicAdd(&inv_cnt[v], 1);
+        key_src[e] = ok ? (unsigned)u : (unsigned)n;
+        if (ok) atomicAdd(&indeg[v], 1);
+    }
+}
+__global__ void k_rs_finish(int n, const int* __restrict__ popped, const int* __restrict__ depth,
+                            const int* __restrict__ inv_cnt, long long* __restrict__ depth_out,
+                            long long* __restrict__ inv_out) {
+    const bool cyclic = popped[0] != n;  // networkx raises on a cycle and the depth falls back to zeros
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        depth_out[i] = cyclic ? 0 : depth[i];
+        inv_out[i] = inv_cnt[i];
+    }
+}
+
+inline int g256(int64_t items) { return grid_for(items, 256, 4096); }
+
+// types/pos for n nodes into (types, pos, scan[n+1]); `flags` and `temp` are scratch
+int run_types_pos(hipStream_t s, int n, const float* x, int* types, int* pos, int* small, Cnt4* flags, Cnt4* scan,
+                  void* temp, size_t tb) {
+    hipLaunchKernelGGL(k_type_flags, dim3(g256(n + 1)), dim3(256), 0, s, n, x, types, flags);
+    AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, flags, scan, Cnt4{0, 0, 0, 0}, (size_t)(n + 1), Cnt4Plus(), s));
+    if (small) AIG_HIP_CHECK(hipMemsetAsync(small, 0xFF, 3 * sizeof(int), s));
+    hipLaunchKernelGGL(k_pos, dim3(g256(n)), dim3(256), 0, s, n, types, scan, pos, small);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+// CSR over the edges whose key (an endpoint id) is < n: ptr[n+1], adj = the other endpoint
+int run_csr(hipStream_t s, int n, int E, int bits, unsigned* key, unsigned* skey, int* ids, int* sid,
+            const long long* other_endpoint, int* ptr, int* adj, void* temp, size_t tb) {
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, sid, (size_t)E, 0, bits, s));
+    hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(n + 1)), dim3(256), 0, s, n, E, skey, 1u, ptr);
+    hipLaunchKernelGGL(k_gather_adj, dim3(g256(E)), dim3(256), 0, s, E, sid, other_endpoint, adj);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+}  // namespace
+}  // namespace aig
+
+using namespace aig;
+
+// ============================================================================================ enforce
+extern "C" size_t aig_enforce_ws_bytes(int64_t n, int64_t E) {
+    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
+    int kb = bits_for((unsigned long long)N * N + N);
+    size_t t64 = sort_temp<unsigned long long>(E, kb < 64 ? kb : 64), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
+    size_t tmax = t64 > t32 ? t64 : t32;
+    tmax = tmax > ts ? tmax : ts;
+    return 2 * align_up((N + 1) * sizeof(Cnt4)) + 6 * align_up((N + 2) * 4) + align_up(N * sizeof(Pick)) +
+           2 * align_up(M * 8) + 5 * align_up(M * 4) + align_up(M * 8) + align_up(tmax) + 1024;
+}
+
+extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
+                           int depth_kind, const void* depth, int64_t* out_edge_index, int64_t cap,
+                           int64_t* out_edge_attr, int32_t* out_count, int64_t* node_depth, float* x_out, void* ws,
+                           size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_enforce: needs n > 0 and E > 0 (got %lld, %lld)",
+                (long long)n, (long long)E);
+    AIG_REQUIRE((double)n * (double)n < 1.8e19, "aig_enforce: n too large for 64-bit pair keys");
+    AIG_REQUIRE(x && edge_index && out_edge_index && out_edge_attr && out_count && node_depth && x_out && ws,
+                "aig_enforce: null pointer");
+    AIG_REQUIRE(cap >= 2 * n, "aig_enforce: output capacity %lld < 2n", (long long)cap);
+    AIG_REQUIRE(depth_kind >= 0 && depth_kind <= 2 && (depth_kind == 0 || depth), "aig_enforce: bad depth argument");
+    if (ws_bytes < aig_enforce_ws_bytes(n, E))
+        return fail(AIG_EWORKSPACE, "aig_enforce: workspace %zu < %zu", ws_bytes, aig_enforce_ws_bytes(n, E));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N = (int)n, M = (int)E;
+    Carver c(ws);
+    Cnt4* flags = c.take<Cnt4>(N + 1);
+    Cnt4* scan = c.take<Cnt4>(N + 1);
+    int* types = c.take<int>(N + 2);
+    int* pos = c.take<int>(N + 2);
+    int* vptr = c.take<int>(N + 2);
+    int* sptr = c.take<int>(N + 2);
+    int* pick_cnt = c.take<int>(N + 2);
+    int* pick_off = c.take<int>(N + 2);
+    Pick* picks = c.take<Pick>(N);
+    unsigned long long* key64 = c.take<unsigned long long>(M);
+    unsigned long long* skey64 = c.take<unsigned long long>(M);
+    unsigned* key_src = c.take<unsigned>(M);
+    unsigned* skey_src = c.take<unsigned>(M);
+    int* ids = c.take<int>(M);
+    int* sid = c.take<int>(M);
+    int* adj = c.take<int>(M);
+    long long* minv = c.take<long long>(M);
+    int* small = c.take<int>(64);
+    const int kb = bits_for((unsigned long long)n * (unsigned long long)n + (unsigned long long)n);
+    size_t t64 = sort_temp<unsigned long long>(E, kb), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
+    size_t tb = t64 > t32 ? t64 : t32;
+    tb = tb > ts ? tb : ts;
+    void* temp = c.take<char>(tb);
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    const long long* inv = reinterpret_cast<const long long*>(edge_attr);
+
+    int rc = run_types_pos(s, N, x, types, pos, small, flags, scan, temp, tb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_enf_keys, dim3(g256(M)), dim3(256), 0, s, N, M, ei, pos, key64, key_src, ids);
+    AIG_LAUNCH_CHECK();
+    // by (target, source): runs of equal pairs are adjacent, first occurrence first (stable)
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, kb, s));
+    hipLaunchKernelGGL(k_enf_merge, dim3(g256(M)), dim3(256), 0, s, M, skey64, sid, inv, minv);
+    hipLaunchKernelGGL(k_segment_ptr<unsigned long long>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey64,
+                       (unsigned long long)n, vptr);
+    hipLaunchKernelGGL(k_enf_select, dim3(g256(N + 1)), dim3(256), 0, s, N, types, pos, small, scan, skey64, minv, vptr,
+                       depth_kind, depth, picks, pick_cnt, x_out, x);
+    AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, pick_cnt, pick_off, 0, (size_t)(N + 1), rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_enf_write, dim3(g256(N)), dim3(256), 0, s, N, (long long)cap, picks, pick_off,
+                       reinterpret_cast<long long*>(out_edge_index), reinterpret_cast<long long*>(out_edge_attr),
+                       out_count);
+    AIG_LAUNCH_CHECK();
+    // node_depth: breadth-first level from the PIs over the cleaned (pre-repair) edges
+    rc = run_csr(s, N, M, 32, key_src, skey_src, ids, sid, ei + E, sptr, adj, temp, tb);
+    if (rc) return rc;
+    int* depth32 = pick_cnt;  // free again
+    int* q0 = reinterpret_cast<int*>(flags);  // (n+1)*16 bytes each: room for n ints
+    int* q1 = reinterpret_cast<int*>(scan);
+    hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
+    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, adj, nullptr, depth32, q0, q1, nullptr);
+    hipLaunchKernelGGL(k_widen_i32_i64, dim3(g256(N)), dim3(256), 0, s, N, depth32, reinterpret_cast<long long*>(node_depth));
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+// ============================================================================================ penalties / validate
+static size_t graph_checks_ws_bytes(int64_t n, int64_t E) {
+    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
+    int kb = bits_for((unsigned long long)N * N + N);
+    size_t t64 = sort_temp<unsigned long long>(E, kb < 64 ? kb : 64), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
+    size_t tmax = t64 > t32 ? t64 : t32;
+    tmax = tmax > ts ? tmax : ts;
+    return 2 * align_up((N + 1) * sizeof(Cnt4)) + 10 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
+           8 * align_up(M * 4) + align_up(tmax) + 2048;
+}
+
+// shared body: counters (penalties) and/or flags (validator)
+static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edge_index, float* pen_out,
+                        unsigned char* eflag, unsigned char* ncode, int* indeg_out, int* pred2,
+                        unsigned char* on_path, int* summary, void* ws, size_t ws_bytes, void* stream,
+                        const char* who) {
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "%s: needs n > 0 and E > 0 (got %lld, %lld)", who,
+                (long long)n, (long long)E);
+    AIG_REQUIRE((double)n * (double)n < 1.8e19, "%s: n too large for 64-bit pair keys", who);
+    AIG_REQUIRE(x && edge_index && ws, "%s: null pointer", who);
+    if (ws_bytes < graph_checks_ws_bytes(n, E)) return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N = (int)n, M = (int)E;
+    Carver c(ws);
+    Cnt4* flags = c.take<Cnt4>(N + 1);
+    Cnt4* scan = c.take<Cnt4>(N + 1);
+    int* types = c.take<int>(N + 2);
+    int* pos = c.take<int>(N + 2);
+    int* indeg = c.take<int>(N + 2);
+    int* sptr = c.take<int>(N + 2);
+    int* dptr = c.take<int>(N + 2);
+    int* fwd = c.take<int>(N + 2);
+    int* rev = c.take<int>(N + 2);
+    int* kdeg = c.take<int>(N + 2);
+    int* kdepth = c.take<int>(N + 2);
+    int* qx = c.take<int>(N + 2);
+    unsigned long long* key64 = c.take<unsigned long long>(M);
+    unsigned long long* skey64 = c.take<unsigned long long>(M);
+    unsigned* key_src = c.take<unsigned>(M);
+    unsigned* key_dst = c.take<unsigned>(M);
+    unsigned* skey32 = c.take<unsigned>(M);
+    int* ids = c.take<int>(M);
+    int* sid = c.take<int>(M);
+    int* sadj = c.take<int>(M);
+    int* dadj = c.take<int>(M);
+    int* q1 = qx;                                  // second queue (n entries)
+    int* counters = c.take<int>(64);               // [0..7] counts, [8] Kahn popped
+    const int kb = bits_for((unsigned long long)n * (unsigned long long)n + (unsigned long long)n);
+    size_t t64 = sort_temp<unsigned long long>(E, kb), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
+    size_t tb = t64 > t32 ? t64 : t32;
+    tb = tb > ts ? tb : ts;
+    void* temp = c.take<char>(tb);
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+
+    int rc = run_types_pos(s, N, x, types, pos, nullptr, flags, scan, temp, tb);
+    if (rc) return rc;
+    AIG_HIP_CHECK(hipMemsetAsync(counters, 0, 64 * sizeof(int), s));
+    AIG_HIP_CHECK(hipMemsetAsync(indeg, 0, (size_t)(N + 2) * sizeof(int), s));
+    hipLaunchKernelGGL(k_pen_edges, dim3(g256(M)), dim3(256), 0, s, N, M, ei, types, pos, counters, indeg, key64,
+                       key_src, key_dst, ids, eflag);
+    AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, kb, s));
+    hipLaunchKernelGGL(k_pen_dups, dim3(g256(M)), dim3(256), 0, s, M, skey64, sid, counters, eflag);
+    AIG_LAUNCH_CHECK();
+    // forward reachability from the PIs, backward from the POs
+    if ((rc = run_csr(s, N, M, 32, key_src, skey32, ids, sid, ei + E, sptr, sadj, temp, tb))) return rc;
+    if ((rc = run_csr(s, N, M, 32, key_dst, skey32, ids, sid, ei, dptr, dadj, temp, tb))) return rc;
+    int* q0 = reinterpret_cast<int*>(flags);
+    hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, fwd);
+    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, sadj, nullptr, fwd, q0, q1, nullptr);
+    hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PO_T, rev);
+    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, dptr, dadj, nullptr, rev, q0, q1, nullptr);
+    hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, fwd, rev, counters, on_path);
+    AIG_LAUNCH_CHECK();
+    if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3(1), dim3(1), 0, s, counters, pen_out);
+    if (ncode) {
+        hipLaunchKernelGGL(k_val_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, dptr, dadj, ncode, pred2);
+        AIG_HIP_CHECK(hipMemcpyAsync(kdeg, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
+        if (indeg_out) AIG_HIP_CHECK(hipMemcpyAsync(indeg_out, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, sadj, kdeg, kdepth, q0, q1,
+                           counters + 8);
+        hipLaunchKernelGGL(k_val_summary, dim3(1), dim3(1), 0, s, N, counters + 8, counters, summary);
+    }
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" size_t aig_penalties_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws_bytes(n, E); }
+
+extern "C" int aig_penalties(int64_t n, int64_t E, const float* x, const int64_t* edge_index, float* out9, void* ws,
+                             size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(out9, "aig_penalties: null output");
+    return graph_checks(n, E, x, edge_index, out9, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                        stream, "aig_penalties");
+}
+
+extern "C" size_t aig_validate_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws_bytes(n, E); }
+
+extern "C" int aig_validate(int64_t n, int64_t E, const float* x, const int64_t* edge_index, uint8_t* eflag,
+                            uint8_t* ncode, int32_t* indeg, int32_t* pred2, uint8_t* on_path, int32_t* summary,
+                            void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(eflag && ncode && indeg && pred2 && on_path && summary, "aig_validate: null output");
+    return graph_checks(n, E, x, edge_index, nullptr, eflag, ncode, indeg, pred2, on_path, summary, ws, ws_bytes,
+                        stream, "aig_validate");
+}
+
+// ============================================================================================ resync
+extern "C" size_t aig_resync_ws_bytes(int64_t n, int64_t E) {
+    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
+    return 7 * align_up((N + 2) * 4) + 5 * align_up(M * 4) + align_up(sort_temp<unsigned>(E, 32)) + 1024;
+}
+
+extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
+                          int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_resync: needs n > 0 and E > 0");
+    AIG_REQUIRE(edge_index && inv_cnt && depth && ws, "aig_resync: null pointer");
+    if (ws_bytes < aig_resync_ws_bytes(n, E)) return fail(AIG_EWORKSPACE, "aig_resync: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N = (int)n, M = (int)E;
+    Carver c(ws);
+    int* icnt = c.take<int>(N + 2);
+    int* indeg = c.take<int>(N + 2);
+    int* sptr = c.take<int>(N + 2);
+    int* d32 = c.take<int>(N + 2);
+    int* q0 = c.take<int>(N + 2);
+    int* q1 = c.take<int>(N + 2);
+    int* popped = c.take<int>(N + 2);
+    unsigned* key = c.take<unsigned>(M);
+    unsigned* skey = c.take<unsigned>(M);
+    int* ids = c.take<int>(M);
+    int* sid = c.take<int>(M);
+    int* adj = c.take<int>(M);
+    size_t tb = sort_temp<unsigned>(E, 32);
+    void* temp = c.take<char>(tb);
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    AIG_HIP_CHECK(hipMemsetAsync(icnt, 0, (size_t)(N + 2) * 4, s));
+    AIG_HIP_CHECK(hipMemsetAsync(indeg, 0, (size_t)(N + 2) * 4, s));
+    hipLaunchKernelGGL(k_rs_edges, dim3(g256(M)), dim3(256), 0, s, N, M, ei, reinterpret_cast<const long long*>(edge_attr),
+                       icnt, indeg, key, ids);
+    AIG_LAUNCH_CHECK();
+    int rc = run_csr(s, N, M, 32, key, skey, ids, sid, ei + E, sptr, adj, temp, tb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, adj, indeg, d32, q0, q1, popped);
+    hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, N, popped, d32, icnt,
+                       reinterpret_cast<long long*>(depth), reinterpret_cast<long long*>(inv_cnt));
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}

@@ -178,6 +178,53 @@ int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const float* h, con
                        const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
                        float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Structural constraints - models/constraints.py.  One graph per call, n > 0 and E > 0 (the callers
+ * handle the empty cases, which need no kernel); edge_index int64 [2,E], x float32 [n,2].
+ * ------------------------------------------------------------------------------------------- */
+
+/* Repair - enforce_aig_constraints (constraints.py:508-669, strict=False).
+ *   edge_attr int64 [E] inversion values (NULL = zeros); depth_kind 0 none / 1 float32 / 2 int64 node_depth
+ *   of the INPUT graph (used to rank a PO's candidate drivers)
+ * Cleaning: self loops dropped, repeated (u,v) merged (first value kept, raised to 1 when it is 0 and a
+ * repeat carries 1), out-of-range endpoints dropped, edges with pos[u] >= pos[v] dropped (pos = rank in
+ * PI < AND < PO order).  Selection per target in id order: a PO keeps the legal driver minimising
+ * (-is_and, -int(depth), id); an AND keeps its two smallest-pos legal fan-ins, or - with fewer than two -
+ * the two smallest-pos PI/AND nodes other than itself (a kept legal fan-in keeps its inversion value).
+ * Outputs: out_edge_index rows of stride `cap` (>= 2n), out_edge_attr [cap], *out_count = edges written;
+ * node_depth int64 [n] = breadth-first level from the PIs over the CLEANED edges (-1 unreachable);
+ * x_out [n,2] = (x[:,0], min(2, sum of merged inversion values entering the node over the cleaned edges)). */
+size_t aig_enforce_ws_bytes(int64_t n, int64_t E);
+int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
+                int depth_kind, const void* depth, int64_t* out_edge_index, int64_t cap, int64_t* out_edge_attr,
+                int32_t* out_count, int64_t* node_depth, float* x_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Violation counts - aig_constraint_penalties (constraints.py:253-366), default weights.
+ * out9 = pi_in, po_out, backedge, selfloop, dup_fanin, indeg_mse, fanin_type, reach_violation, total.
+ * Edges with an endpoint outside [0,n) cannot be indexed by the reference and are left out of every count. */
+size_t aig_penalties_ws_bytes(int64_t n, int64_t E);
+int aig_penalties(int64_t n, int64_t E, const float* x, const int64_t* edge_index, float* out9,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* Verdicts of validate_strict_aig (constraints.py:375-505); the caller turns them into the message list.
+ *   eflag[E]  bit 0 self loop, bit 1 repeat of an earlier (u,v), bit 2 enters a PI, bit 3 leaves a PO,
+ *             bit 4 source type not PI/AND for an AND/PO target
+ *   ncode[n]  0 fine, 1 unknown type, 2 PO with indegree != 1, 3 AND with indegree != 2, 4 AND fed twice by one node
+ *   indeg[n]; pred2[2n] first two sources entering each node in edge order (-1 when absent)
+ *   on_path[n] 1 when reached forward from a PI and backward from a PO
+ *   summary[0] graph has a cycle (Kahn), summary[1] nodes not on a PI->PO path */
+size_t aig_validate_ws_bytes(int64_t n, int64_t E);
+int aig_validate(int64_t n, int64_t E, const float* x, const int64_t* edge_index, uint8_t* eflag, uint8_t* ncode,
+                 int32_t* indeg, int32_t* pred2, uint8_t* on_path, int32_t* summary,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* Attribute resync of the sampling CLI - resync_attrs (AIGgan.py:29-62).
+ *   inv_cnt[v] = number of entering edges whose inversion value is 1 (not clamped)
+ *   depth[v]   = longest-path level over the in-range edges, all zeros when the graph has a cycle */
+size_t aig_resync_ws_bytes(int64_t n, int64_t E);
+int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
+               int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
