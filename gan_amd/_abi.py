@@ -43,7 +43,8 @@ SIGNATURES = {
     "aig_gen_emit": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "aig_gat_csr_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_csr": (INT, [I64, I64] + [P] * 10 + [P, SZ, P]),
-    "aig_gat_fwd": (INT, [I64] + [P] * 14 + [P]),
+    "aig_gat_node_alpha": (INT, [I64, P, P, P, P, P, P]),
+    "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_bwd": (INT, [I64, I64] + [P] * 22 + [P, SZ, P]),
     "aig_level_plan_ws_bytes": (SZ, [I64, I64]),
@@ -80,6 +81,36 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+class _Timeline:
+    """Optional per-entry-point GPU timing with stream events (used by bench.py)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def reset(self):
+        self.events = {}
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.events.items()}
+
+
+timeline = _Timeline()
+
+
+def timed(name: str, fn, *args):
+    """Call an entry point; when the timeline is on, bracket it with events on the current stream."""
+    if not timeline.enabled:
+        return fn(*args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = fn(*args)
+    b.record()
+    timeline.events.setdefault(name, []).append((a, b))
+    return rc
 
 
 def check(rc: int, what: str = "") -> None:

@@ -397,19 +397,27 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     return AIG_OK;
 }
 
-extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* att_src, const float* att_dst, const float* ce,
+extern "C" int aig_gat_node_alpha(int64_t n, const float* xw, const float* att_src, const float* att_dst,
+                                  float* a_s, float* a_d, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat_node_alpha: n=%lld out of range", (long long)n);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(xw && att_src && att_dst && a_s && a_d, "aig_gat_node_alpha: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_gat_node_alpha, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, att_src, att_dst, a_s,
+                       a_d);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const float* a_d, const float* ce,
                            const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
-                           const float* loop_ea, float* a_s, float* a_d, float* out, float* alpha_e,
-                           float* alpha_loop, void* stream) {
+                           const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat_fwd: n=%lld out of range", (long long)n);
     if (n == 0) return AIG_OK;
-    AIG_REQUIRE(xw && att_src && att_dst && ce && bias && row_ptr && loop_ea && a_s && a_d && out && alpha_loop,
-                "aig_gat_fwd: null pointer");
+    AIG_REQUIRE(xw && a_s && a_d && ce && bias && row_ptr && loop_ea && out && alpha_loop, "aig_gat_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int g = grid_blocks(n);
-    hipLaunchKernelGGL(k_gat_node_alpha, dim3(g), dim3(THREADS), 0, s, (int)n, xw, att_src, att_dst, a_s, a_d);
-    hipLaunchKernelGGL(k_gat_aggregate, dim3(g), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d, ce, bias, row_ptr, csr_src,
-                       csr_ea, loop_ea, out, alpha_e, alpha_loop);
+    hipLaunchKernelGGL(k_gat_aggregate, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d, ce, bias,
+                       row_ptr, csr_src, csr_ea, loop_ea, out, alpha_e, alpha_loop);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -102,11 +102,13 @@ class _GATAggregate(torch.autograd.Function):
         out = torch.empty((n, HIDDEN), **f32)
         alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
         alpha_loop = torch.empty((max(n, 1), 4), **f32)
-        _abi.check(lib.aig_gat_fwd(n, _abi.ptr(xw), _abi.ptr(att_src), _abi.ptr(att_dst), _abi.ptr(ce),
-                                   _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
-                                   _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(a_s), _abi.ptr(a_d),
-                                   _abi.ptr(out), _abi.ptr(alpha_e), _abi.ptr(alpha_loop), _abi.stream()),
-                   "aig_gat_fwd")
+        st = _abi.stream()
+        _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
+                              _abi.ptr(att_dst), _abi.ptr(a_s), _abi.ptr(a_d), st), "aig_gat_node_alpha")
+        _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
+                              _abi.ptr(ce), _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
+                              _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
+                              _abi.ptr(alpha_loop), st), "aig_gat_fwd")
         ctx.csr = csr
         ctx.save_for_backward(xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop)
         return out
@@ -124,7 +126,7 @@ class _GATAggregate(torch.autograd.Function):
         d_as, d_ad, d_bias = torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32)
         d_ce = torch.empty(4, **f32)
         ws = _abi.workspace(lib.aig_gat_bwd_ws_bytes(n, csr.E), dev)
-        _abi.check(lib.aig_gat_bwd(n, csr.E, _abi.ptr(g_out), _abi.ptr(out), _abi.ptr(xw), _abi.ptr(att_src),
+        _abi.check(_abi.timed("aig_gat_bwd", lib.aig_gat_bwd, n, csr.E, _abi.ptr(g_out), _abi.ptr(out), _abi.ptr(xw), _abi.ptr(att_src),
                                    _abi.ptr(att_dst), _abi.ptr(ce), _abi.ptr(a_s), _abi.ptr(a_d),
                                    _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea),
                                    _abi.ptr(csr.loop_ea), _abi.ptr(csr.col_ptr), _abi.ptr(csr.csc_pos),
@@ -145,7 +147,7 @@ class _LevelPool(torch.autograd.Function):
         out = torch.empty((1, 2 * HIDDEN), dtype=torch.float32, device=dev)
         argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
         ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), dev)
-        _abi.check(lib.aig_level_pool_fwd(plan.n, plan.nvalid, plan.L, _abi.ptr(h), _abi.ptr(plan.perm),
+        _abi.check(_abi.timed("aig_level_pool_fwd", lib.aig_level_pool_fwd, plan.n, plan.nvalid, plan.L, _abi.ptr(h), _abi.ptr(plan.perm),
                                           _abi.ptr(plan.lvl_ptr), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
                                           _abi.ptr(out), _abi.ptr(argmax), _abi.ptr(ws), ws.numel(), _abi.stream()),
                    "aig_level_pool_fwd")

@@ -145,21 +145,21 @@ class AIGGenerator(nn.Module):
         h_cond = torch.empty((max(n, 1), 128), **f32) if return_debug else None
         ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), dev)
         w = self._weights()
-        _abi.check(lib.aig_gen_node_proj(n, _abi.ptr(x_in), _abi.ptr(z), C.byref(w), _abi.ptr(h_cond),
+        _abi.check(_abi.timed("aig_gen_node_proj", lib.aig_gen_node_proj, n, _abi.ptr(x_in), _abi.ptr(z), C.byref(w), _abi.ptr(h_cond),
                                          _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st), "aig_gen_node_proj")
         logits = torch.empty((max(n, 1), K), **f32)
         if return_debug:
             logits.fill_(float("nan"))
-        _abi.check(lib.aig_gen_score(n, K, _abi.ptr(plan.order), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
+        _abi.check(_abi.timed("aig_gen_score", lib.aig_gen_score, n, K, _abi.ptr(plan.order), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
                                      _abi.ptr(proj[0]), _abi.ptr(proj[1]), _abi.ptr(self.edge_scorer[2].weight),
                                      _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), "aig_gen_score")
         sel = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
-        _abi.check(lib.aig_topk_select(n, K, _abi.ptr(logits), _abi.ptr(plan.cnt), _abi.ptr(plan.want),
+        _abi.check(_abi.timed("aig_topk_select", lib.aig_topk_select, n, K, _abi.ptr(logits), _abi.ptr(plan.cnt), _abi.ptr(plan.want),
                                        _abi.ptr(sel), None, 0, st), "aig_topk_select")
         edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
         edge_attr = torch.empty((E, 1), dtype=torch.int64, device=dev)
         x_out = torch.empty((n, 2), **f32)
-        _abi.check(lib.aig_gen_emit(n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
+        _abi.check(_abi.timed("aig_gen_emit", lib.aig_gen_emit, n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
                                     _abi.ptr(plan.cnt), _abi.ptr(plan.cand), _abi.ptr(plan.fb), _abi.ptr(plan.eoff),
                                     _abi.ptr(sel), _abi.ptr(proj[2]), _abi.ptr(proj[3]),
                                     _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias),

@@ -1,0 +1,96 @@
+"""Data-parallel plumbing: one process per GPU, RCCL over xGMI through ``torch.distributed``.
+
+The reference is single-process (train.py:191-360).  Here graph minibatches are sharded over
+the ranks of one node and the only exchange is the critic's gradient: 59,137 fp32 values
+(236.5 KB), once per critic iteration.  Such a message is latency-bound on xGMI, so it goes
+out as ONE flat buffer (never per tensor), with a validity flag appended so that a rank whose
+step raised still takes part in the collective - the reference's catch-and-continue contract
+(train.py:349-352) would otherwise leave the other ranks waiting forever.  The generator has
+no gradient (see gan_amd/generator.py), hence no second collective.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> tuple:
+    """(rank, local_rank, world_size) from the torchrun environment, (0, 0, 1) without it."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0) -> None:
+    """Every rank starts from rank ``src``'s weights (one flat broadcast per module)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for m in modules:
+        tensors = [p.data for p in m.parameters()] + [b.data for b in m.buffers()]
+        if not tensors:
+            continue
+        flat = torch.cat([t.reshape(-1).float() for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+class FlatGradAllReduce:
+    """Mean of the parameter gradients over ranks through one flat all-reduce.
+
+    ``reduce(ok)`` returns True when every rank reported a valid gradient; otherwise the
+    gradients are left zeroed and the caller skips its optimiser step - on every rank alike."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        first = self.params[0]
+        self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=first.device)
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def reduce(self, ok: bool = True) -> bool:
+        if self.world == 1:
+            return ok
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if ok and p.grad is not None:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            else:
+                self.flat[off:off + n].zero_()
+            off += n
+        self.flat[self.numel] = 1.0 if ok else 0.0
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        all_ok = bool(self.flat[self.numel].item() >= self.world - 0.5)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            if all_ok:
+                p.grad.copy_(g).div_(self.world)
+            else:
+                p.grad.zero_()
+            off += n
+        return all_ok
+
+
+def shard_indices(total: int, rank: int, world: int) -> List[int]:
+    """Samples of a bulk-sampling job owned by ``rank``: i with i % world == rank (no exchange)."""
+    return list(range(rank, total, world))

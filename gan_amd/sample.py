@@ -1,0 +1,98 @@
+"""Sampling CLI: template + generator checkpoint -> repaired AIG ``.pt`` file(s).
+
+Same flags and steps as AIGgan.py of the reference (AIGgan.py:72-117): seed, load templates,
+build the generator and load its weights, draw ``z`` on the device, one forward pass without
+gradients, ``enforce_aig_constraints``, ``resync_attrs``, save.  Extensions: ``--num-samples`` for
+bulk sampling (sample i draws z from a device generator seeded ``seed + i``, so sample 0 is the
+reference's draw and the set of samples does not depend on how many ranks produce it), and
+under torchrun the samples are dealt to the ranks with no collective at all.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+
+from . import parallel
+from .constraints import enforce_aig_constraints, resync_attrs
+from .data import Data
+from .dataset import load_pt_dataset
+from .generator import AIGGenerator
+
+PI, PO, AND = 0, 1, 2
+
+
+def summarize(d: Data) -> str:
+    n = d.x.size(0)
+    e = d.edge_index.size(1) if getattr(d, "edge_index", None) is not None else 0
+    t = d.x[:, 0].long()
+    counts = [int((t == k).sum().item()) for k in (PI, PO, AND)]
+    inv = int((d.edge_attr.view(-1) == 1).sum().item()) if getattr(d, "edge_attr", None) is not None else 0
+    return f"N={n}, E={e}, PI={counts[0]}, PO={counts[1]}, AND={counts[2]}, inv_edges={inv}"
+
+
+def sample_one(G: AIGGenerator, tpl: Data, z: torch.Tensor) -> Data:
+    """AIGgan.py:104-111: forward, repair, resync."""
+    with torch.no_grad():
+        raw = G(tpl, z)
+    return resync_attrs(enforce_aig_constraints(raw))
+
+
+def out_path(base: str, i: int, total: int) -> str:
+    if total == 1:
+        return base
+    root, ext = os.path.splitext(base)
+    return f"{root}_{i:06d}{ext or '.pt'}"
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset-dir", required=True, help="directory of real AIG .pt files used as templates")
+    ap.add_argument("--gen-ckpt", required=True, help="generator state dict (.pt)")
+    ap.add_argument("--out", required=True, help="output path, e.g. results/ISCAS85/AIGfake/sample_0.pt")
+    ap.add_argument("--g-hidden", type=int, default=128)
+    ap.add_argument("--z-dim", type=int, default=128)
+    ap.add_argument("--candidate-k", type=int, default=512)
+    ap.add_argument("--template-idx", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--num-samples", type=int, default=1, help="extension: bulk sampling")
+    return ap
+
+
+def main(argv=None) -> None:
+    args = build_parser().parse_args(argv)
+    rank, local_rank, world = parallel.env_world()   # bulk sampling needs no process group
+    if not torch.cuda.is_available():
+        raise RuntimeError("gan_amd.sample needs a HIP device: the generator has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed_all(args.seed)
+
+    dataset = load_pt_dataset(args.dataset_dir, max_files=None)
+    if len(dataset) == 0:
+        raise RuntimeError(f"No .pt files in {args.dataset_dir}")
+    tpl = dataset[min(args.template_idx, len(dataset) - 1)].to(device)
+
+    G = AIGGenerator(node_in_dim=2, hidden_dim=args.g_hidden, z_dim=args.z_dim, candidate_k=args.candidate_k).to(device)
+    G.load_state_dict(torch.load(args.gen_ckpt, map_location=device, weights_only=True))
+    G.eval()
+
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    for i in parallel.shard_indices(args.num_samples, rank, world):
+        gen = torch.Generator(device=device).manual_seed(args.seed + i)
+        z = torch.randn(args.z_dim, device=device, generator=gen)
+        fixed = sample_one(G, tpl, z)
+        if args.num_samples == 1:
+            print("[INFO] FIX:", summarize(fixed))
+        path = out_path(args.out, i, args.num_samples)
+        torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in fixed.to_dict().items()}, path)
+        if args.num_samples == 1:
+            print(f"[OK] saved {path}")
+    if args.num_samples > 1:
+        print(f"[OK] rank {rank}: saved {len(parallel.shard_indices(args.num_samples, rank, world))} samples")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,326 @@
+"""WGAN-GP training loop of the AIG-GAN on MI355X kernels.
+
+Same loop, flags and artefacts as train.py of the reference (train.py:191-387): per minibatch
+the generator wires a fake per template once, the fakes are repaired and padded, the critic
+takes ``--n-critic`` steps of ``(D_fake - D_real) + gp_lambda * GP`` with a node-only gradient
+penalty, then the generator step evaluates ``-D(raw) + lambda_cons * penalties``; checkpoints and
+``metrics.csv`` per epoch, sample ``.pt`` files every ``--save-every`` steps.
+
+What differs, on purpose:
+* every model / constraint call runs on the GPU kernels of this package (no CPU path);
+* ``sanitize_for_D`` of the real and fake batch is hoisted out of the critic loop (its result
+  does not change between iterations), which lets the critic reuse one CSR per edge list;
+* with ``WORLD_SIZE > 1`` (torchrun) the shuffled minibatches are dealt to the ranks and the
+  critic gradient is averaged over ranks after every ``loss_D.backward()`` (gan_amd/parallel.py);
+* extension flags: ``--seed``, ``--unpad-templates`` (the reference's templates stay padded,
+  see gan_amd/dataset.py), ``--no-progress``.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+import traceback
+from typing import Dict, List, Optional
+
+import torch
+
+from . import parallel
+from .constraints import aig_constraint_penalties, enforce_aig_constraints, validate_strict_aig
+from .data import Batch, Data, GraphLoader
+from .dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
+from .discriminator import AIGDiscriminator
+from .generator import AIGGenerator
+
+METRIC_FIELDS = ["step", "epoch", "D_real", "D_fake", "gap", "grad_norm", "loss_D", "loss_G", "gp", "pen"]
+
+
+class MetricsLogger:
+    """Rows of train.py:29-41 written as ``metrics.csv`` (train.py:43-50)."""
+
+    def __init__(self, out_dir: str):
+        self.out_dir = out_dir
+        os.makedirs(out_dir, exist_ok=True)
+        self.rows: List[Dict[str, float]] = []
+
+    def log(self, step, epoch, d_real, d_fake, gap, grad_norm, loss_d, loss_g, gp, pen):
+        vals = [float(step), int(epoch), float(d_real), float(d_fake), float(gap), float(grad_norm), float(loss_d),
+                float(loss_g), float(gp), float(pen)]
+        self.rows.append(dict(zip(METRIC_FIELDS, vals)))
+
+    def flush_csv(self):
+        if not self.rows:
+            return
+        with open(os.path.join(self.out_dir, "metrics.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=METRIC_FIELDS)
+            w.writeheader()
+            w.writerows(self.rows)
+
+
+def valid_edge_mask(d: Data) -> torch.Tensor:
+    """Columns of ``edge_index`` without a negative (padding) index (train.py:126-130)."""
+    if d.edge_index is None or d.edge_index.numel() == 0:
+        return torch.zeros(0, dtype=torch.bool, device=d.x.device)
+    return d.edge_index.min(dim=0).values >= 0
+
+
+def sanitize_for_D(padded: Data) -> Data:
+    """Critic input without the -1 padding edges (train.py:108-123)."""
+    dev = padded.x.device
+    d = Data(x=padded.x)
+    if padded.edge_index is not None and padded.edge_index.numel() > 0:
+        keep = valid_edge_mask(padded)
+        d.edge_index = padded.edge_index[:, keep]
+        ea = getattr(padded, "edge_attr", None)
+        if ea is not None and ea.numel() > 0:
+            d.edge_attr = ea[keep]
+        else:
+            d.edge_attr = torch.zeros((d.edge_index.size(1), 1), dtype=torch.long, device=dev)
+    else:
+        d.edge_index = torch.zeros((2, 0), dtype=torch.long, device=dev)
+        d.edge_attr = torch.zeros((0, 1), dtype=torch.long, device=dev)
+    d.node_depth = padded.node_depth
+    return d
+
+
+def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool = True,
+                     alpha: Optional[torch.Tensor] = None):
+    """Node-feature gradient penalty on an edge-free interpolate (train.py:141-152).
+
+    Returns ``(gp, grad_norm)``.  Only the branch the reference's loop takes is provided
+    (``use_edges=False``, train.py:261); its edge-interpolating branch is never reached there."""
+    if use_edges:
+        raise NotImplementedError("only the node-only gradient penalty (use_edges=False) is implemented")
+    if alpha is None:
+        alpha = torch.rand(1, 1, device=device)
+    x_inter = (alpha * real_pad.x + (1 - alpha) * fake_pad.x).requires_grad_(True)
+    inter = Data(x=x_inter, edge_index=torch.zeros((2, 0), dtype=torch.long, device=device),
+                 edge_attr=torch.zeros((0, 1), dtype=torch.float32, device=device), node_depth=real_pad.node_depth)
+    out = D(inter)
+    grads = torch.autograd.grad(out.sum(), [x_inter], create_graph=True, retain_graph=True, only_inputs=True)
+    grad_norm = torch.norm(grads[0].reshape(-1), p=2)
+    gp = (grad_norm - 1.0) ** 2
+    return gp, grad_norm.detach()
+
+
+class Trainer:
+    """State of one training run; ``step(batch)`` is one pass of the reference's inner loop body."""
+
+    def __init__(self, args, max_nodes: int, max_edges: int, device: torch.device, rank: int = 0, world: int = 1):
+        self.args, self.device, self.rank, self.world = args, device, rank, world
+        self.max_nodes, self.max_edges = max_nodes, max_edges
+        self.G = AIGGenerator(node_in_dim=2, hidden_dim=args.g_hidden, z_dim=args.z_dim,
+                              candidate_k=args.candidate_k).to(device)
+        self.D = AIGDiscriminator(in_dim=2, hidden_dim=args.d_hidden).to(device)
+        parallel.broadcast_parameters([self.G, self.D])
+        self.opt_G = torch.optim.Adam(self.G.parameters(), lr=args.lr, betas=(0.5, 0.9))
+        self.opt_D = torch.optim.Adam(self.D.parameters(), lr=args.lr, betas=(0.5, 0.9))
+        self.reducer = parallel.FlatGradAllReduce(self.D.parameters())
+        self.global_step = 0
+        self._templates: Dict[int, Data] = {}
+        self.last: Dict[str, torch.Tensor] = {}
+        self.edges_last_step = 0
+        # random draws of the loop (train.py:143,241,276); tests substitute recorded values
+        self.draw_z = lambda: torch.randn(args.z_dim, device=device)
+        self.draw_alpha = lambda: torch.rand(1, 1, device=device)
+
+    # templates are the same tensors every epoch: keep them (and their generator plan) per sample
+    def templates_of(self, real_padded: Batch) -> List[Data]:
+        ids = getattr(real_padded, "sample_ids", None)
+        parts = None
+        out = []
+        for k in range(real_padded.num_graphs):
+            key = ids[k] if ids is not None else None
+            if key is None or key not in self._templates:
+                if parts is None:
+                    parts = real_padded.to_data_list()
+                d = parts[k]
+                if getattr(self.args, "unpad_templates", False):
+                    keep = int((d.node_depth >= 0).sum().item())
+                    d._orig_n, d._orig_e = keep, int(valid_edge_mask(d).sum().item())
+                t = unpad_data(d)   # without _orig_n the template keeps its padded size, as in the reference
+                t = Data(x=t.x.clone(), node_depth=None if t.node_depth is None else t.node_depth.clone())
+                if key is None:
+                    out.append(t)
+                    continue
+                self._templates[key] = t
+            out.append(self._templates[key])
+        return out
+
+    def _pad_batch(self, graphs: List[Data]) -> Batch:
+        return Batch.from_data_list([pad_data(g, self.max_nodes, self.max_edges) for g in graphs]).to(self.device)
+
+    def step(self, real_padded: Batch, epoch: int = 0, save_dir: Optional[str] = None) -> Dict[str, float]:
+        a, dev, G, D = self.args, self.device, self.G, self.D
+        real_padded = real_padded.to(dev)
+        templates = self.templates_of(real_padded)
+
+        # ---- critic: fakes are generated once and reused for all n_critic iterations (train.py:241-245)
+        # A rank whose step raises still enters every gradient all-reduce of the step (with a
+        # "not valid" flag), then re-raises: the other ranks never wait on a missing partner.
+        failed: Optional[BaseException] = None
+        try:
+            zs_once = [self.draw_z() for _ in templates]
+            raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
+            corr_fakes_once = [enforce_aig_constraints(r) for r in raw_fakes_once]
+            fake_padded = self._pad_batch(corr_fakes_once)
+            real_for_D = sanitize_for_D(real_padded)
+            fake_for_D = sanitize_for_D(fake_padded)
+            self.edges_last_step = int(real_for_D.edge_index.size(1) + fake_for_D.edge_index.size(1))
+        except Exception as e:
+            if self.world == 1:
+                raise
+            failed = e
+        for _ in range(a.n_critic):
+            if failed is None:
+                try:
+                    self.opt_D.zero_grad()
+                    D_real_mean = torch.mean(D(real_for_D))
+                    D_fake_mean = torch.mean(D(fake_for_D))
+                    gap = D_real_mean - D_fake_mean
+                    gp_term, grad_norm = gradient_penalty(D, real_padded, fake_padded, dev, use_edges=False,
+                                                          alpha=self.draw_alpha())
+                    loss_D = (D_fake_mean - D_real_mean) + a.gp_lambda * gp_term
+                    loss_D.backward()
+                    self.last = dict(D_real=D_real_mean.detach(), D_fake=D_fake_mean.detach(), gap=gap.detach(),
+                                     gp=gp_term.detach(), grad_norm=grad_norm.detach(), loss_D=loss_D.detach())
+                except Exception as e:
+                    if self.world == 1:
+                        raise
+                    failed = e
+            if self.reducer.reduce(failed is None):
+                self.opt_D.step()
+        if failed is not None:
+            raise failed
+
+        # ---- generator (train.py:275-299); its output carries no gradient, so backward only touches D
+        self.opt_G.zero_grad()
+        zs = [self.draw_z() for _ in templates]
+        raw_gen = [G(t, z) for t, z in zip(templates, zs)]
+        raw_batch_for_D = sanitize_for_D(self._pad_batch(raw_gen))
+        loss_G_adv = -torch.mean(D(raw_batch_for_D))
+        pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
+        loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
+        if (self.global_step % a.save_every) == 0:
+            scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
+            loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
+        loss_G = loss_G_adv + a.lambda_cons * loss_pen
+        loss_G.backward()
+        self.opt_G.step()
+        self.last.update(loss_G=loss_G.detach(), pen=loss_pen.detach())
+
+        if save_dir is not None and (self.global_step % a.save_every) == 0:
+            self._save_samples(raw_gen, epoch, save_dir)
+        self.global_step += 1
+        return self.last
+
+    def _save_samples(self, raw_gen: List[Data], epoch: int, out_dir: str) -> None:
+        a, step = self.args, self.global_step
+        k = min(len(raw_gen), a.save_num)
+        # the reference repairs the very objects it then writes as "raw" (train.py:324-327)
+        corr_list = [enforce_aig_constraints(r) for r in raw_gen[:k]]
+        tag = f"ep{epoch}_st{step}" if self.world == 1 else f"ep{epoch}_st{step}_r{self.rank}"
+        save_data_list_as_pt(corr_list, out_dir, prefix="raw_" + tag, start_idx=0)
+        save_data_list_as_pt(corr_list, out_dir, prefix="corr_" + tag, start_idx=0)
+        valid = []
+        for c in corr_list:
+            violations = validate_strict_aig(c, check_all_on_path=True)
+            has_edges = c.edge_index is not None and c.edge_index.numel() > 0
+            and_count = int((c.x[:, 0] == 2).sum().item()) if has_edges else 0
+            max_lev = int(c.node_depth.max().item()) if c.node_depth is not None and c.node_depth.numel() > 0 else 0
+            if len(violations) == 0 and and_count > 0 and max_lev > 0:
+                valid.append(c)
+        if valid:
+            save_data_list_as_pt(valid, os.path.join("results", "ISCAS85", "pt_fake"), prefix="valid_" + tag)
+
+
+def train(args) -> None:
+    rank, local_rank, world = parallel.init_distributed()
+    if not torch.cuda.is_available():
+        raise RuntimeError("gan_amd.train needs a HIP device: the models have no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    os.makedirs(args.out_dir, exist_ok=True)
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+        torch.cuda.manual_seed_all(args.seed)
+
+    data_list = load_pt_dataset(args.dataset_dir, max_files=args.max_files)
+    if len(data_list) == 0:
+        raise RuntimeError("No .pt files found in dataset_dir")
+    max_nodes = max(d.x.size(0) for d in data_list) if args.max_nodes is None else args.max_nodes
+    max_edges = (max((d.edge_index.size(1) if d.edge_index is not None else 0) for d in data_list)
+                 if args.max_edges is None else args.max_edges)
+    if rank == 0:
+        print(f"[INFO] dataset size {len(data_list)}, max_nodes={max_nodes}, max_edges={max_edges}")
+    padded_list = [pad_data(d, max_nodes=max_nodes, max_edges=max_edges) for d in data_list]
+    loader = GraphLoader(padded_list, batch_size=args.batch_size, shuffle=True,
+                         seed=args.seed if world == 1 else (args.seed or 0), rank=rank, world_size=world)
+    trainer = Trainer(args, max_nodes, max_edges, device, rank, world)
+    logger = MetricsLogger(args.out_dir)
+
+    for epoch in range(args.epochs):
+        it = loader
+        if not args.no_progress and rank == 0:
+            try:
+                from tqdm import tqdm
+                it = tqdm(loader, desc=f"Epoch {epoch}", dynamic_ncols=True)
+            except ImportError:
+                pass
+        for real_padded in it:
+            try:
+                step_no = trainer.global_step
+                m = trainer.step(real_padded, epoch, save_dir=args.out_dir)
+                logger.log(step_no, epoch, d_real=m["D_real"].item(), d_fake=m["D_fake"].item(), gap=m["gap"].item(),
+                           grad_norm=m["grad_norm"].item(), loss_d=m["loss_D"].item(), loss_g=m["loss_G"].item(),
+                           gp=m["gp"].item(), pen=m["pen"].item())
+                if step_no % args.log_every == 0 and hasattr(it, "set_postfix"):
+                    r = logger.rows[-1]
+                    it.set_postfix({k: f"{r[k]:.4f}" for k in ("loss_D", "loss_G", "D_real", "D_fake", "gp", "pen")})
+            except Exception as e:  # the reference reports and moves on (train.py:349-352)
+                print("[ERROR] exception in training step:", e)
+                traceback.print_exc()
+                continue
+        if rank == 0:
+            torch.save(trainer.G.state_dict(), os.path.join(args.out_dir, f"generator_epoch{epoch}.pt"))
+            torch.save(trainer.D.state_dict(), os.path.join(args.out_dir, f"discriminator_epoch{epoch}.pt"))
+            logger.flush_csv()
+            print(f"[INFO] saved checkpoints & metrics epoch {epoch}")
+    if rank == 0:
+        print("[INFO] training finished")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataset-dir", type=str, required=True, help="Directory containing the dataset.")
+    p.add_argument("--out-dir", type=str, default="out_gen", help="Output directory.")
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--batch-size", type=int, default=1)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--g-hidden", type=int, default=128)
+    p.add_argument("--d-hidden", type=int, default=128)
+    p.add_argument("--z-dim", type=int, default=128)
+    p.add_argument("--candidate-k", type=int, default=512, help="Number of candidate predecessors per node.")
+    p.add_argument("--max-nodes", type=int, default=None)
+    p.add_argument("--max-edges", type=int, default=None)
+    p.add_argument("--lambda-cons", type=float, default=1e-2)
+    p.add_argument("--gp-lambda", type=float, default=10.0)
+    p.add_argument("--n-critic", type=int, default=3)
+    p.add_argument("--save-every", type=int, default=10)
+    p.add_argument("--save-num", type=int, default=2)
+    p.add_argument("--log-every", type=int, default=1)
+    p.add_argument("--max-files", type=int, default=None)
+    # extensions
+    p.add_argument("--seed", type=int, default=None, help="Seed torch's generators (the reference sets none).")
+    p.add_argument("--unpad-templates", action="store_true",
+                   help="Strip padding rows from templates (the reference keeps them padded).")
+    p.add_argument("--no-progress", action="store_true")
+    return p
+
+
+def main(argv=None) -> None:
+    train(build_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -134,16 +134,19 @@ int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* ed
                 int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
                 int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, void* ws, size_t ws_bytes, void* stream);
 
-/* Forward of one layer after the dense projection xw = x W^T ([n,128], 4 heads x 32 channels):
- *   a_s[i,h] = <xw[i,h,:], att_src[h,:]>, a_d likewise            (outputs, [n,4] each)
+/* Attention logits' node terms after the dense projection xw = x W^T ([n,128], 4 heads x 32 channels):
+ *   a_s[i,h] = <xw[i,h,:], att_src[h,:]>,  a_d[i,h] = <xw[i,h,:], att_dst[h,:]>        ([n,4] each) */
+int aig_gat_node_alpha(int64_t n, const float* xw, const float* att_src, const float* att_dst,
+                       float* a_s, float* a_d, void* stream);
+
+/* Fused attention / softmax / aggregation / bias / ELU of one layer (one kernel):
  *   e = leaky_relu(a_s[src] + a_d[dst] + edge_attr * ce[h], 0.2)   ce[h] = <lin_edge.weight[h,:], att_edge[h,:]>
  *   alpha = exp(e - max) / (sum exp(e - max) + 1e-16) over the edges entering dst, self loop included
  *   out[dst] = elu(sum alpha * xw[src] + bias)                     (the F.elu of discriminator.py:60-61 is fused)
  * alpha_e [E,4] (by-target order) and alpha_loop [n,4] are kept for the backward pass. */
-int aig_gat_fwd(int64_t n, const float* xw, const float* att_src, const float* att_dst, const float* ce,
+int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const float* a_d, const float* ce,
                 const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
-                const float* loop_ea, float* a_s, float* a_d, float* out, float* alpha_e, float* alpha_loop,
-                void* stream);
+                const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* stream);
 
 /* Backward of the same layer: given g_out = dLoss/d out, returns d_xw [n,128], d_att_src [128],
  * d_att_dst [128], d_ce [4], d_bias [128].  (Gradients w.r.t. edge_attr are not produced: the only
