@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the AIG-GAN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload synth100k|iscas85|synth1m]
+
+A "step" is one full pass of the training loop body (gan_amd.train.Trainer.step) over one
+minibatch of synthetic AIGs: 2 generator passes per template, repair, 3 critic iterations with
+the node-only gradient penalty (10 critic evaluations, 4 backward passes), the generator-side
+penalties.  Every rank holds its own minibatch (weak scaling); for N > 1 the critic gradient is
+all-reduced over RCCL after each critic backward.  Rank 0 prints ONE JSON line:
+
+  value            train edges/s = (real + fake non-sentinel edges of all ranks' minibatches) / step time
+  sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job
+  roofline         the dominant kernel (fused GAT aggregate, aig_gat_fwd): algorithmic bytes of its
+                   launches inside the timed region / their duration from stream events
+  cpu_baseline     the CPU checker's training step on a bounded sample, timed on this host (rank 0, N=1)
+
+Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak; ~6300 GB/s is the measured copy ceiling
+
+
+def workload_graphs(name: str, rank: int):
+    from gan_amd.synth import iscas85_like, synth_aig
+    if name == "synth100k":
+        return [synth_aig(1000, 98000, 1000, seed=rank, window=4096, orientation="dataset")], \
+            "synthetic 100k-node AIG (1000 PI / 98000 AND / 1000 PO, window 4096), one graph per step per GPU"
+    if name == "synth1m":
+        return [synth_aig(10000, 980000, 10000, seed=rank, window=4096, orientation="dataset")], \
+            "synthetic 1M-node AIG (10k PI / 980k AND / 10k PO, window 4096), one graph per step per GPU"
+    if name == "iscas85":
+        return iscas85_like(seed=rank), "11 synthetic graphs with ISCAS85 node counts (c17..c7552), one batch of 11 per step per GPU"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def gat_fwd_bytes(n: int, e: int) -> int:
+    """Algorithmic bytes of one fused aggregate launch (E' = e + n edges incl. self loops):
+    gather 512 B per edge, write 512 B per node, int32 source + fp32 attribute per real edge,
+    row pointers, attention terms (a_s gather + alpha write per edge and head, a_d / loop attr per node)."""
+    ep = e + n
+    return 512 * ep + 512 * n + 8 * e + 4 * (n + 1) + 16 * ep + 16 * ep + 16 * n + 4 * n
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """One training step of the CPU checker on a bounded sample (10k-node synthetic AIG)."""
+    import numpy as np
+    from gan_amd.data import Batch
+    from gan_amd.dataset import pad_data, unpad_data
+    from gan_amd.synth import synth_aig
+    from oracle import model as omodel
+    from oracle.train_oracle import CpuTrainer
+    n_and = 9800
+    g = synth_aig(100, n_and, 100, seed=0, window=1024, orientation="dataset")
+    mn, me = g.x.size(0), g.edge_index.size(1)
+    real = Batch.from_data_list([pad_data(g, mn, me)])
+    w = np.load(os.path.join(ROOT, "tests", "golden", "gen_weights.npz"))
+    gs = {k: torch.from_numpy(w[k]) for k in w.files}
+    tr = CpuTrainer(gs, omodel.init_discriminator_params(0), 64, mn, me)
+    gen = torch.Generator().manual_seed(0)
+    zs = [torch.randn(128, generator=gen) for _ in range(2)]
+    alphas = [torch.rand(1, 1, generator=gen) for _ in range(3)]
+    templates = [unpad_data(d) for d in real.to_data_list()]
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    steps = 0
+    edges = 0
+    while True:
+        m = tr.step(real, templates, zs[:1], zs[1:], alphas, validate=False)
+        edges += m["edges"]
+        steps += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.5 or steps >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": edges / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} full training step(s) of the CPU checker on a 10k-node synthetic AIG "
+                      f"(100 PI / {n_and} AND / 100 PO, candidate-k 64), {dt:.1f} s; dense critic ops on "
+                      f"{threads} torch threads, generator/constraint checker single-threaded C"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="synth100k", choices=["synth100k", "iscas85", "synth1m"])
+    ap.add_argument("--sample-iters", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from gan_amd import _abi, parallel
+    from gan_amd.constraints import enforce_aig_constraints, resync_attrs
+    from gan_amd.data import Batch, Data
+    from gan_amd.dataset import pad_data
+    from gan_amd.train import Trainer, build_parser
+
+    rank, local_rank, world = parallel.init_distributed()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(123)
+
+    graphs, desc = workload_graphs(a.workload, rank)
+    max_nodes = max(g.x.size(0) for g in graphs)
+    max_edges = max(g.edge_index.size(1) for g in graphs)
+    targs = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000"])
+    trainer = Trainer(targs, max_nodes, max_edges, dev, rank, world)
+    trainer.global_step = 1      # step 0 would add the save-step validation pass; steady state is measured
+    batch = Batch.from_data_list([pad_data(g, max_nodes, max_edges) for g in graphs]).to(dev)
+    batch.sample_ids = list(range(len(graphs)))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(batch)
+    barrier()
+    _abi.timeline.reset()
+    _abi.timeline.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _abi.timeline.enabled = False
+    tl = _abi.timeline.totals_ms()
+    tl_meta = dict(_abi.timeline.meta)
+
+    edges_rank = trainer.edges_last_step * a.steps
+    stat = torch.tensor([elapsed, float(edges_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stat[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        esum = stat[1:].clone()
+        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        elapsed, edges_total = float(tmax.item()), float(esum.item())
+    else:
+        edges_total = float(edges_rank)
+
+    # ---- sampling throughput (generator + repair + resync), same templates, fresh z per sample
+    templates = trainer.templates_of(batch)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+
+    def sample_once():
+        for t in templates:
+            z = torch.randn(128, device=dev, generator=gen)
+            resync_attrs(enforce_aig_constraints(trainer.G(t, z)))
+    sample_once()
+    barrier()
+    s0 = time.perf_counter()
+    for _ in range(a.sample_iters):
+        sample_once()
+    barrier()
+    s_el = time.perf_counter() - s0
+    s_stat = torch.tensor([s_el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(s_stat, op=dist.ReduceOp.MAX)
+    nodes_per_iter = sum(int(t.x.size(0)) for t in templates)
+    sample_nodes_per_sec = nodes_per_iter * a.sample_iters * world / float(s_stat.item())
+
+    if rank == 0:
+        ms_fwd, launches = tl.get("aig_gat_fwd", (0.0, 0))
+        total_bytes = sum(gat_fwd_bytes(n, e) for (n, e) in tl_meta.get("aig_gat_fwd", []))
+        roof = None
+        if launches:
+            achieved = total_bytes / (ms_fwd * 1e-3) / 1e9
+            roof = {"kernel": "k_gat_aggregate (entry point aig_gat_fwd)", "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": launches, "avg_launch_us": round(ms_fwd * 1e3 / launches, 2),
+                    "algorithmic_bytes_per_launch_avg": int(total_bytes / launches)}
+        out = {
+            "metric": "train edges/sec (AIG nodes/sec sampled at k=64 in sample_nodes_per_sec)",
+            "value": round(edges_total / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed * 1e3 / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {desc}; candidate-k 64, n_critic 3, hidden 128, fp32",
+                       "edges_per_step_per_gpu": trainer.edges_last_step,
+                       "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
+            "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
+            "roofline": roof,
+            "timeline_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(tl.items())},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,11 +42,11 @@ SIGNATURES = {
     "aig_topk_select": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
     "aig_gen_emit": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "aig_gat_csr_ws_bytes": (SZ, [I64, I64]),
-    "aig_gat_csr": (INT, [I64, I64] + [P] * 10 + [P, SZ, P]),
+    "aig_gat_csr": (INT, [I64, I64] + [P] * 11 + [P, SZ, P]),
     "aig_gat_node_alpha": (INT, [I64, P, P, P, P, P, P]),
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
-    "aig_gat_bwd": (INT, [I64, I64] + [P] * 22 + [P, SZ, P]),
+    "aig_gat_bwd": (INT, [I64, I64] + [P] * 23 + [P, SZ, P]),
     "aig_level_plan_ws_bytes": (SZ, [I64, I64]),
     "aig_level_plan": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),
@@ -89,9 +89,11 @@ class _Timeline:
     def __init__(self):
         self.enabled = False
         self.events = {}
+        self.meta = {}
 
     def reset(self):
         self.events = {}
+        self.meta = {}
 
     def totals_ms(self):
         torch.cuda.synchronize()
@@ -101,8 +103,9 @@ class _Timeline:
 timeline = _Timeline()
 
 
-def timed(name: str, fn, *args):
-    """Call an entry point; when the timeline is on, bracket it with events on the current stream."""
+def timed(name: str, fn, *args, meta=None):
+    """Call an entry point; when the timeline is on, bracket it with events on the current stream
+    (the stream the kernels are enqueued on) and remember ``meta`` (problem sizes) per launch."""
     if not timeline.enabled:
         return fn(*args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -110,6 +113,8 @@ def timed(name: str, fn, *args):
     rc = fn(*args)
     b.record()
     timeline.events.setdefault(name, []).append((a, b))
+    if meta is not None:
+        timeline.meta.setdefault(name, []).append(meta)
     return rc
 
 

@@ -94,6 +94,22 @@ __global__ void k_segment_ptr(int n, int E, const K* __restrict__ skey, K scale,
 //           predecessor, so depth = longest-path level; *popped counts released nodes.
 // Every wave leaves through the same `break` (the frontier size is read between two barriers),
 // and the loop ends after at most n rounds because a node enters a queue at most once.
+constexpr int HEAVY_DEG = 64;    // adjacency lists longer than this are expanded by a whole wave
+constexpr int HEAVY_CAP = 2048;  // heavy nodes remembered per level (the rest are expanded in place)
+
+template <int MODE>
+__device__ __forceinline__ void visit(int v, int level, int* __restrict__ state, int* __restrict__ depth,
+                                      int* __restrict__ qn, int* s_next) {
+    if (MODE == 0) {
+        if (atomicCAS(&depth[v], -1, level + 1) == -1) qn[atomicAdd(s_next, 1)] = v;
+    } else {
+        if (atomicSub(&state[v], 1) == 1) {
+            depth[v] = level + 1;
+            qn[atomicAdd(s_next, 1)] = v;
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, const int* __restrict__ ptr,
                                                            const int* __restrict__ adj, int* __restrict__ state,
@@ -101,8 +117,10 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, const int* __r
                                                            int* __restrict__ q1, int* __restrict__ popped) {
     __shared__ int s_cnt[2];
     __shared__ int s_total;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_cnt[0] = s_cnt[1] = 0; s_total = 0; }
+    __shared__ int s_nheavy;
+    __shared__ int s_heavy[HEAVY_CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_cnt[0] = s_cnt[1] = 0; s_total = 0; s_nheavy = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += TRAV_THREADS) {
         bool start;
@@ -116,23 +134,26 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, const int* __r
         const int c = s_cnt[cur];
         __syncthreads();
         if (c == 0) break;
-        if (tid == 0) { s_cnt[cur ^ 1] = 0; s_total += c; }
+        if (tid == 0) { s_cnt[cur ^ 1] = 0; s_total += c; s_nheavy = 0; }
         __syncthreads();
         const int* qc = cur ? q1 : q0;
         int* qn = cur ? q0 : q1;
+        // short adjacency lists: one thread each; long ones are set aside for whole waves
         for (int idx = tid; idx < c; idx += TRAV_THREADS) {
             const int u = qc[idx];
-            for (int e = ptr[u]; e < ptr[u + 1]; ++e) {
-                const int v = adj[e];
-                if (MODE == 0) {
-                    if (atomicCAS(&depth[v], -1, level + 1) == -1) qn[atomicAdd(&s_cnt[cur ^ 1], 1)] = v;
-                } else {
-                    if (atomicSub(&state[v], 1) == 1) {
-                        depth[v] = level + 1;
-                        qn[atomicAdd(&s_cnt[cur ^ 1], 1)] = v;
-                    }
-                }
+            const int b = ptr[u], e = ptr[u + 1];
+            if (e - b > HEAVY_DEG) {
+                const int slot = atomicAdd(&s_nheavy, 1);
+                if (slot < HEAVY_CAP) { s_heavy[slot] = u; continue; }
             }
+            for (int k = b; k < e; ++k) visit<MODE>(adj[k], level, state, depth, qn, &s_cnt[cur ^ 1]);
+        }
+        __syncthreads();
+        const int nh = min(s_nheavy, HEAVY_CAP);
+        for (int hidx = wave; hidx < nh; hidx += TRAV_THREADS / 64) {
+            const int u = s_heavy[hidx];
+            for (int k = ptr[u] + lane; k < ptr[u + 1]; k += 64)
+                visit<MODE>(adj[k], level, state, depth, qn, &s_cnt[cur ^ 1]);
         }
         cur ^= 1;
     }

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 
@@ -93,6 +94,23 @@ size_t sort_temp_bytes(int64_t E, int bits) {
     unsigned* k = nullptr;
     int* v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)E, 0, bits, hipStream_t(0));
+    return bytes;
+}
+
+constexpr int SEG = 32;  // edges per by-source segment: long fan-out lists are cut into pieces of this size
+
+// number of segments of node j's out-edge list (at least one, so every node owns a segment)
+__global__ void k_seg_count(int n, const int* __restrict__ col_ptr, int* __restrict__ nch) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += gridDim.x * blockDim.x) {
+        int d = j < n ? col_ptr[j + 1] - col_ptr[j] : 0;
+        nch[j] = j < n ? max(1, (d + SEG - 1) / SEG) : 0;
+    }
+}
+
+size_t scan_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    int* p = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, p, p, 0, (size_t)n, rocprim::plus<int>(), hipStream_t(0));
     return bytes;
 }
 
@@ -271,25 +289,68 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
 
 // Source side.  d_xw[j] = sum_{e: src=j} alpha_e g_pre[dst_e] + alpha_loop g_pre[j]
 //                        + d_a_s[j] att_src + d_a_d[j] att_dst,   d_a_s[j] = sum d_raw over out-edges.
-// Per-block partials of d_att_src / d_att_dst follow the same pattern as above.
-__global__ __launch_bounds__(THREADS) void k_gat_bwd_src(
-    int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
-    const float* __restrict__ att_dst, const int* __restrict__ col_ptr, const int* __restrict__ csc_pos,
-    const int* __restrict__ csc_dst, const float* __restrict__ alpha_e, const float* __restrict__ alpha_loop,
-    const float* __restrict__ d_raw_e, const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d,
-    float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
+// Fan-out is heavily skewed (a generated graph can hang thousands of gates on one source), so the
+// out-edge lists are cut into segments of SEG edges and a half-wave owns one SEGMENT: a node with a
+// single segment is finished on the spot, a longer list leaves one partial row per segment and is
+// finished by k_gat_bwd_src_heavy, which adds the partials in segment order (reproducible).
+struct SrcFinish {
+    float4 as4, ad4;
+};
+__device__ __forceinline__ void src_finish(int j, int l, int h, float4 acc, float das, const SrcFinish& f,
+                                           const float4* __restrict__ g4, const float* __restrict__ xw,
+                                           const float* __restrict__ alpha_loop,
+                                           const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d,
+                                           float* __restrict__ d_xw, float4& ps, float4& pd) {
+    das += d_raw_loop[j * HEADS + h];
+    const float al = alpha_loop[j * HEADS + h];
+    const float4 gj = g4[(size_t)j * 32 + l];
+    const float dad = d_a_d[j * HEADS + h];
+    acc.x += al * gj.x + das * f.as4.x + dad * f.ad4.x;
+    acc.y += al * gj.y + das * f.as4.y + dad * f.ad4.y;
+    acc.z += al * gj.z + das * f.as4.z + dad * f.ad4.z;
+    acc.w += al * gj.w + das * f.as4.w + dad * f.ad4.w;
+    reinterpret_cast<float4*>(d_xw + (size_t)j * H)[l] = acc;
+    const float4 x = reinterpret_cast<const float4*>(xw + (size_t)j * H)[l];
+    ps.x += das * x.x; ps.y += das * x.y; ps.z += das * x.z; ps.w += das * x.w;
+    pd.x += dad * x.x; pd.y += dad * x.y; pd.z += dad * x.z; pd.w += dad * x.w;
+}
+
+__device__ __forceinline__ void block_partial_2h(float4 ps, float4 pd, float* __restrict__ partial) {
     __shared__ float red[HW_PER_BLOCK][2 * H];
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    reinterpret_cast<float4*>(&red[hw][0])[l] = ps;
+    reinterpret_cast<float4*>(&red[hw][H])[l] = pd;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
+    partial[(size_t)blockIdx.x * (2 * H) + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
+    int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
+    const float* __restrict__ att_dst, const int* __restrict__ col_ptr, const int* __restrict__ seg_base,
+    const int* __restrict__ csc_pos, const int* __restrict__ csc_dst, const float* __restrict__ alpha_e,
+    const float* __restrict__ alpha_loop, const float* __restrict__ d_raw_e, const float* __restrict__ d_raw_loop,
+    const float* __restrict__ d_a_d, float* __restrict__ d_xw, float* __restrict__ part_acc /*[nseg][H]*/,
+    float* __restrict__ part_das /*[nseg][HEADS]*/, float* __restrict__ partial /*[grid][2H]*/) {
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
-    const float4 as4 = reinterpret_cast<const float4*>(att_src)[l], ad4 = reinterpret_cast<const float4*>(att_dst)[l];
+    SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
     const float4* g4 = reinterpret_cast<const float4*>(g_pre);
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
-    NodeRange r = block_nodes(n);
-    for (int j = r.begin + hw; j < r.end; j += HW_PER_BLOCK) {
-        const int beg = col_ptr[j], end = col_ptr[j + 1];
-        float das = d_raw_loop[j * HEADS + h];
-        const float al = alpha_loop[j * HEADS + h];
-        float4 gj = g4[(size_t)j * 32 + l];
-        float4 acc = make_float4(al * gj.x, al * gj.y, al * gj.z, al * gj.w);
+    const int nseg = seg_base[n];
+    NodeRange r = block_nodes(nseg);   // a contiguous range of segments per block, XCD-grouped
+    for (int sgm = r.begin + hw; sgm < r.end; sgm += HW_PER_BLOCK) {
+        // owner of segment sgm: the last node j with seg_base[j] <= sgm
+        int lo = 0, hi = n;
+        while (lo + 1 < hi) {
+            int mid = (lo + hi) >> 1;
+            if (seg_base[mid] <= sgm) lo = mid; else hi = mid;
+        }
+        const int j = lo;
+        const int first = seg_base[j], nsg = seg_base[j + 1] - first;
+        const int beg = col_ptr[j] + (sgm - first) * SEG, end = min(col_ptr[j + 1], beg + SEG);
+        float das = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int q = beg;
         for (; q + 2 <= end; q += 2) {
             int p0 = csc_pos[q], p1 = csc_pos[q + 1];
@@ -307,31 +368,55 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src(
             das += d_raw_e[(size_t)p0 * HEADS + h];
             acc.x += a0 * r0.x; acc.y += a0 * r0.y; acc.z += a0 * r0.z; acc.w += a0 * r0.w;
         }
-        const float dad = d_a_d[j * HEADS + h];
-        acc.x += das * as4.x + dad * ad4.x; acc.y += das * as4.y + dad * ad4.y;
-        acc.z += das * as4.z + dad * ad4.z; acc.w += das * as4.w + dad * ad4.w;
-        reinterpret_cast<float4*>(d_xw + (size_t)j * H)[l] = acc;
-        float4 x = reinterpret_cast<const float4*>(xw + (size_t)j * H)[l];
-        ps.x += das * x.x; ps.y += das * x.y; ps.z += das * x.z; ps.w += das * x.w;
-        pd.x += dad * x.x; pd.y += dad * x.y; pd.z += dad * x.z; pd.w += dad * x.w;
+        if (nsg == 1) {
+            src_finish(j, l, h, acc, das, f, g4, xw, alpha_loop, d_raw_loop, d_a_d, d_xw, ps, pd);
+        } else {
+            reinterpret_cast<float4*>(part_acc + (size_t)sgm * H)[l] = acc;
+            if ((l & 7) == 0) part_das[(size_t)sgm * HEADS + h] = das;
+        }
     }
-    reinterpret_cast<float4*>(&red[hw][0])[l] = ps;
-    reinterpret_cast<float4*>(&red[hw][H])[l] = pd;
-    __syncthreads();
-    {
-        float s = 0.f;
-        for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
-        partial[(size_t)blockIdx.x * (2 * H) + threadIdx.x] = s;
-    }
+    block_partial_2h(ps, pd, partial);
 }
 
-// out[c] = sum_b partial[b][c], b ascending
-__global__ void k_reduce_cols(int nb, int width, const float* __restrict__ partial, float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
+__global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
+    int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
+    const float* __restrict__ att_dst, const int* __restrict__ seg_base, const float* __restrict__ alpha_loop,
+    const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, const float* __restrict__ part_acc,
+    const float* __restrict__ part_das, float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
+    const float4* g4 = reinterpret_cast<const float4*>(g_pre);
+    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
+    NodeRange r = block_nodes(n);
+    for (int j = r.begin + hw; j < r.end; j += HW_PER_BLOCK) {
+        const int first = seg_base[j], nsg = seg_base[j + 1] - first;
+        if (nsg <= 1) continue;
+        float das = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nsg; ++k) {
+            const float4 a = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k) * H)[l];
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            das += part_das[(size_t)(first + k) * HEADS + h];
+        }
+        src_finish(j, l, h, acc, das, f, g4, xw, alpha_loop, d_raw_loop, d_a_d, d_xw, ps, pd);
+    }
+    block_partial_2h(ps, pd, partial);
+}
+
+// out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree
+__global__ __launch_bounds__(256) void k_reduce_cols(int nb, int width, const float* __restrict__ partial,
+                                                     float* __restrict__ out) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * width + c];
-    out[c] = s;
+    for (int b = t; b < nb; b += 256) s += partial[(size_t)b * width + c];
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) out[c] = red[0];
 }
 
 int grid_blocks(int64_t n) {
@@ -349,21 +434,23 @@ using namespace aig;
 
 extern "C" size_t aig_gat_csr_ws_bytes(int64_t n, int64_t E) {
     if (E <= 0) return 256;
-    return 4 * align_up((size_t)E * 4) + align_up(sort_temp_bytes(E, key_bits(n))) + 256;
+    size_t t = sort_temp_bytes(E, key_bits(n)), t2 = scan_temp_bytes(n + 1);
+    return 4 * align_up((size_t)E * 4) + align_up((size_t)(n + 1) * 4) + align_up(t > t2 ? t : t2) + 256;
 }
 
 extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_attr,
                            int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
-                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, void* ws, size_t ws_bytes,
-                           void* stream) {
+                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* seg_base, void* ws,
+                           size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0 && E < INT_MAX, "aig_gat_csr: bad sizes n=%lld E=%lld", (long long)n,
                 (long long)E);
-    AIG_REQUIRE(row_ptr && col_ptr && (n == 0 || loop_ea), "aig_gat_csr: null output");
+    AIG_REQUIRE(row_ptr && col_ptr && seg_base && (n == 0 || loop_ea), "aig_gat_csr: null output");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (E == 0) {
         AIG_HIP_CHECK(hipMemsetAsync(row_ptr, 0, (size_t)(n + 1) * 4, s));
         AIG_HIP_CHECK(hipMemsetAsync(col_ptr, 0, (size_t)(n + 1) * 4, s));
         if (n) AIG_HIP_CHECK(hipMemsetAsync(loop_ea, 0, (size_t)n * 4, s));
+        AIG_HIP_CHECK(hipMemsetAsync(seg_base, 0, (size_t)(n + 1) * 4, s));  // never used without edges
         return AIG_OK;
     }
     AIG_REQUIRE(edge_index && csr_src && csr_ea && csr_eid && csc_pos && csc_dst && ws, "aig_gat_csr: null pointer");
@@ -375,7 +462,9 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     unsigned* skey = c.take<unsigned>(E);
     int* ids = c.take<int>(E);
     int* seid = c.take<int>(E);
-    size_t tb = sort_temp_bytes(E, bits);
+    int* nch = c.take<int>(n + 1);
+    size_t tb = sort_temp_bytes(E, bits), tb2 = scan_temp_bytes(n + 1);
+    if (tb2 > tb) tb = tb2;
     void* temp = c.take<char>(tb);
     const int g = grid_for(E, 256, 4096), gn = grid_for(n + 1, 256, 4096);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
@@ -393,7 +482,9 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     hipLaunchKernelGGL(k_csr_ptr, dim3(gn), dim3(256), 0, s, (int)n, (int)E, ssrc, col_ptr);
     hipLaunchKernelGGL(k_csc_fill, dim3(g), dim3(256), 0, s, (int)E, row_ptr + n, skey, csc_pos, csc_dst);
     hipLaunchKernelGGL(k_loop_attr, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, (int)n, row_ptr, csr_ea, loop_ea);
+    hipLaunchKernelGGL(k_seg_count, dim3(gn), dim3(256), 0, s, (int)n, col_ptr, nch);
     AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, nch, seg_base, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
     return AIG_OK;
 }
 
@@ -423,15 +514,17 @@ extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const f
 }
 
 extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {
-    return align_up((size_t)(n > 0 ? n : 1) * H * 4) /*g_pre*/ + align_up((size_t)(E > 0 ? E : 1) * HEADS * 4) +
-           2 * align_up((size_t)(n > 0 ? n : 1) * HEADS * 4) + align_up((size_t)2049 * 2 * H * 4) + 256;
+    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1), nseg = N + M / SEG + 1;
+    return align_up(N * H * 4) /*g_pre*/ + align_up(M * HEADS * 4) + 2 * align_up(N * HEADS * 4) +
+           align_up(nseg * H * 4) + align_up(nseg * HEADS * 4) + align_up((size_t)4097 * 2 * H * 4) + 256;
 }
 
 extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
                            const float* att_src, const float* att_dst, const float* ce, const float* a_s,
                            const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
                            const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
-                           const int32_t* csc_dst, const float* alpha_e, const float* alpha_loop, float* d_xw,
+                           const int32_t* csc_dst, const int32_t* seg_base, const float* alpha_e,
+                           const float* alpha_loop, float* d_xw,
                            float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, void* ws,
                            size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0, "aig_gat_bwd: bad sizes");
@@ -445,7 +538,7 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
         return AIG_OK;
     }
     AIG_REQUIRE(g_out && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
-                    alpha_loop && d_xw && ws,
+                    seg_base && alpha_loop && d_xw && ws,
                 "aig_gat_bwd: null pointer");
     if (ws_bytes < aig_gat_bwd_ws_bytes(n, E))
         return fail(AIG_EWORKSPACE, "aig_gat_bwd: workspace %zu < %zu", ws_bytes, aig_gat_bwd_ws_bytes(n, E));
@@ -454,20 +547,28 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     float* d_raw_e = c.take<float>((size_t)(E > 0 ? E : 1) * HEADS);
     float* d_raw_loop = c.take<float>((size_t)n * HEADS);
     float* d_a_d = c.take<float>((size_t)n * HEADS);
-    float* partial = c.take<float>((size_t)2049 * 2 * H);
+    const size_t nseg_max = (size_t)n + (size_t)(E > 0 ? E : 1) / SEG + 1;
+    float* part_acc = c.take<float>(nseg_max * H);
+    float* part_das = c.take<float>(nseg_max * HEADS);
+    float* partial = c.take<float>((size_t)4097 * 2 * H);
     const int g = grid_blocks(n);
     hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
                        csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial);
     AIG_LAUNCH_CHECK();
     // bias gradient = first H columns, edge-coefficient gradient = last HEADS columns
-    hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(H + HEADS), 0, s, g, H + HEADS, partial, partial + (size_t)g * (H + HEADS));
+    hipLaunchKernelGGL(k_reduce_cols, dim3(H + HEADS), dim3(256), 0, s, g, H + HEADS, partial, partial + (size_t)g * (H + HEADS));
     AIG_HIP_CHECK(hipMemcpyAsync(d_bias, partial + (size_t)g * (H + HEADS), H * 4, hipMemcpyDeviceToDevice, s));
     AIG_HIP_CHECK(hipMemcpyAsync(d_ce, partial + (size_t)g * (H + HEADS) + H, HEADS * 4, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_gat_bwd_src, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, col_ptr,
-                       csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw, partial);
+    const int gs = grid_blocks((int64_t)nseg_max);
+    hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, col_ptr,
+                       seg_base, csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw, part_acc,
+                       part_das, partial);
+    hipLaunchKernelGGL(k_gat_bwd_src_heavy, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
+                       alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(2 * H), 0, s, g, 2 * H, partial, partial + (size_t)g * 2 * H);
-    AIG_HIP_CHECK(hipMemcpyAsync(d_att_src, partial + (size_t)g * 2 * H, H * 4, hipMemcpyDeviceToDevice, s));
-    AIG_HIP_CHECK(hipMemcpyAsync(d_att_dst, partial + (size_t)g * 2 * H + H, H * 4, hipMemcpyDeviceToDevice, s));
+    float* red = partial + (size_t)(gs + g) * 2 * H;
+    hipLaunchKernelGGL(k_reduce_cols, dim3(2 * H), dim3(256), 0, s, gs + g, 2 * H, partial, red);
+    AIG_HIP_CHECK(hipMemcpyAsync(d_att_src, red, H * 4, hipMemcpyDeviceToDevice, s));
+    AIG_HIP_CHECK(hipMemcpyAsync(d_att_dst, red + H, H * 4, hipMemcpyDeviceToDevice, s));
     return AIG_OK;
 }

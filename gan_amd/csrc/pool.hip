@@ -120,23 +120,34 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* 
     }
 }
 
-// out[0:H] = sum of partials; out[H:2H] = 1/(L+1) sum over non-empty levels of the level max;
-// argmax[l*H + f] = node holding that max (-1 for an empty level).  One block, H threads.
-__global__ void k_pool_finish(int nb, int L, const float* __restrict__ partial,
-                              const unsigned long long* __restrict__ table, const int* __restrict__ lvl_ptr,
-                              float* __restrict__ out, int* __restrict__ argmax) {
-    const int f = threadIdx.x;
-    float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * H + f];
-    out[f] = s;
-    float m = 0.f;
-    for (int l = 0; l <= L; ++l) {
+// One block per feature f: out[f] = sum of the walk's partials, out[H+f] = 1/(L+1) * sum over
+// non-empty levels of the level maximum (strided partial sums, then a fixed-shape tree: reproducible);
+// argmax[l*H + f] = node holding that maximum (-1 for an empty level).
+__global__ __launch_bounds__(256) void k_pool_finish(int nb, int L, const float* __restrict__ partial,
+                                                     const unsigned long long* __restrict__ table,
+                                                     const int* __restrict__ lvl_ptr, float* __restrict__ out,
+                                                     int* __restrict__ argmax) {
+    __shared__ float red_s[256], red_m[256];
+    const int f = blockIdx.x, t = threadIdx.x;
+    float s = 0.f, m = 0.f;
+    for (int b = t; b < nb; b += 256) s += partial[(size_t)b * H + f];
+    for (int l = t; l <= L; l += 256) {
         const bool has = lvl_ptr[l + 1] > lvl_ptr[l];
-        unsigned long long t = table[(size_t)l * H + f];
-        if (has) m += unpack_val(t);
-        argmax[(size_t)l * H + f] = has ? (int)(~(unsigned)(t & 0xFFFFFFFFull)) : -1;
+        const unsigned long long v = table[(size_t)l * H + f];
+        if (has) m += unpack_val(v);
+        argmax[(size_t)l * H + f] = has ? (int)(~(unsigned)(v & 0xFFFFFFFFull)) : -1;
     }
-    out[H + f] = m / (float)(L + 1);
+    red_s[t] = s;
+    red_m[t] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { red_s[t] += red_s[t + o]; red_m[t] += red_m[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[f] = red_s[0];
+        out[H + f] = red_m[0] / (float)(L + 1);
+    }
 }
 
 int key_bits(int64_t n) {
@@ -222,7 +233,7 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const fl
                            partial);
         AIG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_pool_finish, dim3(1), dim3(H), 0, s, blocks, (int)L, partial, table, lvl_ptr, out, argmax);
+    hipLaunchKernelGGL(k_pool_finish, dim3(H), dim3(256), 0, s, blocks, (int)L, partial, table, lvl_ptr, out, argmax);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -53,6 +53,16 @@ def graphs():
     b = Batch.from_data_list(parts)
     m = b.edge_index.min(dim=0).values >= 0
     g["padded_batch"] = Data(x=b.x, edge_index=b.edge_index[:, m], edge_attr=b.edge_attr[m], node_depth=b.node_depth)
+    # extreme skew: node 0 feeds every other node (fan-out 2999), every node feeds node 1 (fan-in 2998)
+    n = 3000
+    rng = np.random.default_rng(4)
+    others = np.arange(2, n)
+    src = np.concatenate([np.zeros(n - 1, np.int64), others, rng.integers(0, n, 500)])
+    dst = np.concatenate([np.arange(1, n), np.ones(n - 2, np.int64), rng.integers(0, n, 500)])
+    x = np.stack([rng.choice([0, 1, 2], n), rng.integers(0, 3, n)], 1).astype(np.float32)
+    g["star_skew"] = Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.stack([src, dst])),
+                          edge_attr=torch.from_numpy(rng.integers(0, 2, src.size).astype(np.float32)).view(-1, 1),
+                          node_depth=torch.from_numpy(rng.integers(0, 12, n)))
     return g
 
 
