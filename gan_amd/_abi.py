@@ -47,6 +47,8 @@ SIGNATURES = {
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_bwd": (INT, [I64, I64] + [P] * 23 + [P, SZ, P]),
+    "aig_wgrad_ws_bytes": (SZ, [I64, I64]),
+    "aig_wgrad": (INT, [I64, I64, P, P, P, P, SZ, P]),
     "aig_level_plan_ws_bytes": (SZ, [I64, I64]),
     "aig_level_plan": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),

@@ -378,27 +378,78 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
     block_partial_2h(ps, pd, partial);
 }
 
+// Nodes whose out-edge list spans several segments: the whole block adds one node's partial rows
+// (half-wave hw takes segments hw, hw+8, ... four loads in flight), the eight sums are combined in
+// half-wave order and half-wave 0 finishes the node - same result whatever the fan-out.
 __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
     int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
     const float* __restrict__ att_dst, const int* __restrict__ seg_base, const float* __restrict__ alpha_loop,
     const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, const float* __restrict__ part_acc,
     const float* __restrict__ part_das, float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
+    constexpr int LIST = 256;
+    __shared__ int s_list[LIST];
+    __shared__ int s_n, s_cursor;
+    __shared__ float s_acc[HW_PER_BLOCK][H];
+    __shared__ float s_das[HW_PER_BLOCK][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
     SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
     const float4* g4 = reinterpret_cast<const float4*>(g_pre);
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
     NodeRange r = block_nodes(n);
-    for (int j = r.begin + hw; j < r.end; j += HW_PER_BLOCK) {
-        const int first = seg_base[j], nsg = seg_base[j + 1] - first;
-        if (nsg <= 1) continue;
-        float das = 0.f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < nsg; ++k) {
-            const float4 a = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k) * H)[l];
-            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
-            das += part_das[(size_t)(first + k) * HEADS + h];
+    if (threadIdx.x == 0) s_cursor = r.begin;
+    __syncthreads();
+    while (true) {
+        if (threadIdx.x == 0) {  // next batch of heavy nodes of this block's range, in node order
+            int c = s_cursor, m = 0;
+            for (; c < r.end && m < LIST; ++c)
+                if (seg_base[c + 1] - seg_base[c] > 1) s_list[m++] = c;
+            s_cursor = c;
+            s_n = m;
         }
-        src_finish(j, l, h, acc, das, f, g4, xw, alpha_loop, d_raw_loop, d_a_d, d_xw, ps, pd);
+        __syncthreads();
+        const int m = s_n;
+        if (m == 0) break;
+        for (int t = 0; t < m; ++t) {
+            const int j = s_list[t];
+            const int first = seg_base[j], nsg = seg_base[j + 1] - first;
+            float das = 0.f;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = hw;
+            for (; k + 3 * HW_PER_BLOCK < nsg; k += 4 * HW_PER_BLOCK) {
+                const float4 a0 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k) * H)[l];
+                const float4 a1 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k + HW_PER_BLOCK) * H)[l];
+                const float4 a2 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k + 2 * HW_PER_BLOCK) * H)[l];
+                const float4 a3 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k + 3 * HW_PER_BLOCK) * H)[l];
+                const float d0 = part_das[(size_t)(first + k) * HEADS + h];
+                const float d1 = part_das[(size_t)(first + k + HW_PER_BLOCK) * HEADS + h];
+                const float d2 = part_das[(size_t)(first + k + 2 * HW_PER_BLOCK) * HEADS + h];
+                const float d3 = part_das[(size_t)(first + k + 3 * HW_PER_BLOCK) * HEADS + h];
+                acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w; das += d0;
+                acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w; das += d1;
+                acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w; das += d2;
+                acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w; das += d3;
+            }
+            for (; k < nsg; k += HW_PER_BLOCK) {
+                const float4 a0 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k) * H)[l];
+                acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+                das += part_das[(size_t)(first + k) * HEADS + h];
+            }
+            reinterpret_cast<float4*>(&s_acc[hw][0])[l] = acc;
+            if ((l & 7) == 0) s_das[hw][h] = das;
+            __syncthreads();
+            if (hw == 0) {
+                float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+                float dt = 0.f;
+                for (int q = 0; q < HW_PER_BLOCK; ++q) {
+                    const float4 a = reinterpret_cast<const float4*>(&s_acc[q][0])[l];
+                    tot.x += a.x; tot.y += a.y; tot.z += a.z; tot.w += a.w;
+                    dt += s_das[q][h];
+                }
+                src_finish(j, l, h, tot, dt, f, g4, xw, alpha_loop, d_raw_loop, d_a_d, d_xw, ps, pd);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
     }
     block_partial_2h(ps, pd, partial);
 }

@@ -139,6 +139,44 @@ class _GATAggregate(torch.autograd.Function):
         return d_xw, d_as, d_ad, d_ce, d_bias, None
 
 
+class _WGrad(torch.autograd.Function):
+    """dW[j,f] = sum_n g[n,j] x[n,f]: the node-dimension reduction of a projection's backward pass."""
+
+    @staticmethod
+    def forward(ctx, g, x):
+        lib = _abi.lib()
+        g, x = g.contiguous(), x.contiguous()
+        n, F_in = int(x.size(0)), int(x.size(1))
+        dW = torch.empty((HIDDEN, F_in), dtype=torch.float32, device=x.device)
+        ws = _abi.workspace(lib.aig_wgrad_ws_bytes(n, F_in), x.device)
+        _abi.check(_abi.timed("aig_wgrad", lib.aig_wgrad, n, F_in, _abi.ptr(g), _abi.ptr(x), _abi.ptr(dW),
+                              _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_wgrad")
+        ctx.save_for_backward(g, x)
+        return dW
+
+    @staticmethod
+    def backward(ctx, gg):
+        g, x = ctx.saved_tensors
+        return x @ gg.t(), g @ gg
+
+
+class _Project(torch.autograd.Function):
+    """x W^T with the weight gradient on the kernel above; differentiable twice (its backward is
+    made of differentiable pieces), which the gradient penalty needs."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        d_x = g @ w if ctx.needs_input_grad[0] else None
+        d_w = _WGrad.apply(g, x) if ctx.needs_input_grad[1] else None
+        return d_x, d_w
+
+
 class _LevelPool(torch.autograd.Function):
     """[n,128] -> [1,256] level-wise mean || max readout."""
 
@@ -204,7 +242,10 @@ class GATLayer(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x: torch.Tensor, csr: Optional[GraphCSR]) -> torch.Tensor:
-        xw = self.lin(x)
+        if x.size(1) in (1, 2, 4, HIDDEN) and self.lin.weight.size(0) == HIDDEN:
+            xw = _Project.apply(x, self.lin.weight)
+        else:
+            xw = self.lin(x)
         if csr is None or csr.E == 0:
             # only self loops: alpha = 1/(1 + 1e-16) = 1 in fp32
             return F.elu(xw + self.bias)

@@ -163,6 +163,12 @@ int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, cons
                 float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
                 void* ws, size_t ws_bytes, void* stream);
 
+/* Weight gradient of a dense projection xw = x W^T over the nodes (the reduction torch.nn.functional.linear's
+ * backward performs for gat{1,2}.lin at discriminator.py:60-61): dW[j][f] = sum_n g[n][j] * x[n][f],
+ * g [n,128], x [n,F], dW [128,F]; F in {1, 2, 4, 128}. */
+size_t aig_wgrad_ws_bytes(int64_t n, int64_t F);
+int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, float* dW, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Critic: level-wise readout - models/discriminator.py:64-91
  * ------------------------------------------------------------------------------------------- */
