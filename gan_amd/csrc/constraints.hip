@@ -94,13 +94,16 @@ __global__ void k_segment_ptr(int n, int E, const K* __restrict__ skey, K scale,
 //           predecessor, so depth = longest-path level; *popped counts released nodes.
 // Every wave leaves through the same `break` (the frontier size is read between two barriers),
 // and the loop ends after at most n rounds because a node enters a queue at most once.
-constexpr int HEAVY_DEG = 64;    // adjacency lists longer than this are expanded by a whole wave
+constexpr int HEAVY_DEG = 256;   // adjacency lists longer than this are expanded by the whole block
 constexpr int HEAVY_CAP = 2048;  // heavy nodes remembered per level (the rest are expanded in place)
 
 template <int MODE>
 __device__ __forceinline__ void visit(int v, int level, int* __restrict__ state, int* __restrict__ depth,
                                       int* __restrict__ qn, int* s_next) {
     if (MODE == 0) {
+        // peek first (an L1-bypassing load): a popular node is claimed once and then only read, instead
+        // of tens of thousands of compare-and-swaps queueing on one address
+        if (__hip_atomic_load(&depth[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return;
         if (atomicCAS(&depth[v], -1, level + 1) == -1) qn[atomicAdd(s_next, 1)] = v;
     } else {
         if (atomicSub(&state[v], 1) == 1) {
@@ -110,16 +113,35 @@ __device__ __forceinline__ void visit(int v, int level, int* __restrict__ state,
     }
 }
 
+// One traversal per block: block b works on job[b] (independent walks share a launch and overlap).
+struct TravJob {
+    const int* ptr;
+    const int* adj;
+    int* state;
+    int* depth;
+    int* q0;
+    int* q1;
+    int* popped;
+};
+struct TravJobs {
+    TravJob j[2];
+};
+
 template <int MODE>
-__global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, const int* __restrict__ ptr,
-                                                           const int* __restrict__ adj, int* __restrict__ state,
-                                                           int* __restrict__ depth, int* __restrict__ q0,
-                                                           int* __restrict__ q1, int* __restrict__ popped) {
+__global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs) {
+    const TravJob jb = jobs.j[blockIdx.x];
+    const int* __restrict__ ptr = jb.ptr;
+    const int* __restrict__ adj = jb.adj;
+    int* __restrict__ state = jb.state;
+    int* __restrict__ depth = jb.depth;
+    int* __restrict__ q0 = jb.q0;
+    int* __restrict__ q1 = jb.q1;
+    int* __restrict__ popped = jb.popped;
     __shared__ int s_cnt[2];
     __shared__ int s_total;
     __shared__ int s_nheavy;
     __shared__ int s_heavy[HEAVY_CAP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     if (tid == 0) { s_cnt[0] = s_cnt[1] = 0; s_total = 0; s_nheavy = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += TRAV_THREADS) {
@@ -149,10 +171,12 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, const int* __r
             for (int k = b; k < e; ++k) visit<MODE>(adj[k], level, state, depth, qn, &s_cnt[cur ^ 1]);
         }
         __syncthreads();
+        // long lists: the whole block strides over one list at a time (a generated graph can hang
+        // most of its edges on a single source)
         const int nh = min(s_nheavy, HEAVY_CAP);
-        for (int hidx = wave; hidx < nh; hidx += TRAV_THREADS / 64) {
+        for (int hidx = 0; hidx < nh; ++hidx) {
             const int u = s_heavy[hidx];
-            for (int k = ptr[u] + lane; k < ptr[u + 1]; k += 64)
+            for (int k = ptr[u] + tid; k < ptr[u + 1]; k += TRAV_THREADS)
                 visit<MODE>(adj[k], level, state, depth, qn, &s_cnt[cur ^ 1]);
         }
         cur ^= 1;
@@ -518,7 +542,9 @@ extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* 
     int* q0 = reinterpret_cast<int*>(flags);  // (n+1)*16 bytes each: room for n ints
     int* q1 = reinterpret_cast<int*>(scan);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
-    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, adj, nullptr, depth32, q0, q1, nullptr);
+    TravJobs jobs{};
+    jobs.j[0] = TravJob{sptr, adj, nullptr, depth32, q0, q1, nullptr};
+    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, jobs);
     hipLaunchKernelGGL(k_widen_i32_i64, dim3(g256(N)), dim3(256), 0, s, N, depth32, reinterpret_cast<long long*>(node_depth));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -531,7 +557,7 @@ static size_t graph_checks_ws_bytes(int64_t n, int64_t E) {
     size_t t64 = sort_temp<unsigned long long>(E, kb < 64 ? kb : 64), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
     size_t tmax = t64 > t32 ? t64 : t32;
     tmax = tmax > ts ? tmax : ts;
-    return 2 * align_up((N + 1) * sizeof(Cnt4)) + 10 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
+    return 2 * align_up((N + 1) * sizeof(Cnt4)) + 12 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
            8 * align_up(M * 4) + align_up(tmax) + 2048;
 }
 
@@ -560,6 +586,8 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
     int* kdeg = c.take<int>(N + 2);
     int* kdepth = c.take<int>(N + 2);
     int* qx = c.take<int>(N + 2);
+    int* q2 = c.take<int>(N + 2);
+    int* q3 = c.take<int>(N + 2);
     unsigned long long* key64 = c.take<unsigned long long>(M);
     unsigned long long* skey64 = c.take<unsigned long long>(M);
     unsigned* key_src = c.take<unsigned>(M);
@@ -593,9 +621,11 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
     if ((rc = run_csr(s, N, M, 32, key_dst, skey32, ids, sid, ei, dptr, dadj, temp, tb))) return rc;
     int* q0 = reinterpret_cast<int*>(flags);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, fwd);
-    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, sadj, nullptr, fwd, q0, q1, nullptr);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PO_T, rev);
-    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, dptr, dadj, nullptr, rev, q0, q1, nullptr);
+    TravJobs jobs{};  // the two reachability walks are independent: one launch, one block each
+    jobs.j[0] = TravJob{sptr, sadj, nullptr, fwd, q0, q1, nullptr};
+    jobs.j[1] = TravJob{dptr, dadj, nullptr, rev, q2, q3, nullptr};
+    hipLaunchKernelGGL(k_traverse<0>, dim3(2), dim3(TRAV_THREADS), 0, s, N, jobs);
     hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, fwd, rev, counters, on_path);
     AIG_LAUNCH_CHECK();
     if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3(1), dim3(1), 0, s, counters, pen_out);
@@ -603,8 +633,9 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
         hipLaunchKernelGGL(k_val_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, dptr, dadj, ncode, pred2);
         AIG_HIP_CHECK(hipMemcpyAsync(kdeg, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
         if (indeg_out) AIG_HIP_CHECK(hipMemcpyAsync(indeg_out, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, sadj, kdeg, kdepth, q0, q1,
-                           counters + 8);
+        TravJobs kj{};
+        kj.j[0] = TravJob{sptr, sadj, kdeg, kdepth, q0, q1, counters + 8};
+        hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, kj);
         hipLaunchKernelGGL(k_val_summary, dim3(1), dim3(1), 0, s, N, counters + 8, counters, summary);
     }
     AIG_LAUNCH_CHECK();
@@ -666,7 +697,9 @@ extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const
     AIG_LAUNCH_CHECK();
     int rc = run_csr(s, N, M, 32, key, skey, ids, sid, ei + E, sptr, adj, temp, tb);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, sptr, adj, indeg, d32, q0, q1, popped);
+    TravJobs jobs{};
+    jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, popped};
+    hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, jobs);
     hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, N, popped, d32, icnt,
                        reinterpret_cast<long long*>(depth), reinterpret_cast<long long*>(inv_cnt));
     AIG_LAUNCH_CHECK();

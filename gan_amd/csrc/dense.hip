@@ -25,17 +25,28 @@ __global__ __launch_bounds__(256) void k_wgrad128(int n, const float* __restrict
     const int chunk = ((n + gridDim.x - 1) / gridDim.x + 1) & ~1;  // even: MFMA steps take node pairs
     const int n0 = blockIdx.x * chunk, n1 = min(n, n0 + chunk);
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-#pragma unroll 4
-    for (int nn = n0; nn < n1; nn += 2) {
-        const int row = nn + kh;
-        const bool ok = row < n1;
-        const float a = ok ? g[(size_t)row * H + 32 * w + col] : 0.f;
-        const float* xr = x + (size_t)row * H + col;
-        const float b0 = ok ? xr[0] : 0.f, b1 = ok ? xr[32] : 0.f, b2 = ok ? xr[64] : 0.f, b3 = ok ? xr[96] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+    // four node pairs per trip: all twenty loads are issued before the first MFMA needs one
+    for (int nn = n0; nn < n1; nn += 8) {
+        float a[4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = nn + 2 * u + kh;
+            const bool ok = row < n1;
+            const size_t off = (size_t)(ok ? row : n0) * H;
+            a[u] = ok ? g[off + 32 * w + col] : 0.f;
+            const float* xr = x + off + col;
+            b[u][0] = ok ? xr[0] : 0.f;
+            b[u][1] = ok ? xr[32] : 0.f;
+            b[u][2] = ok ? xr[64] : 0.f;
+            b[u][3] = ok ? xr[96] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][3], acc[3], 0, 0, 0);
+        }
     }
     float* out = partial + (size_t)blockIdx.x * H * H;
 #pragma unroll

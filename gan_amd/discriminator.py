@@ -172,9 +172,26 @@ class _Project(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        d_x = g @ w if ctx.needs_input_grad[0] else None
+        d_x = _ProjectBack.apply(g, w) if ctx.needs_input_grad[0] else None
         d_w = _WGrad.apply(g, x) if ctx.needs_input_grad[1] else None
         return d_x, d_w
+
+
+class _ProjectBack(torch.autograd.Function):
+    """g W (the input gradient of a projection); its own weight gradient - reached when the
+    gradient penalty differentiates a second time - is again a reduction over the nodes."""
+
+    @staticmethod
+    def forward(ctx, g, w):
+        ctx.save_for_backward(g, w)
+        return g @ w
+
+    @staticmethod
+    def backward(ctx, gg):
+        g, w = ctx.saved_tensors
+        d_g = gg @ w.t() if ctx.needs_input_grad[0] else None
+        d_w = _WGrad.apply(g, gg) if ctx.needs_input_grad[1] else None
+        return d_g, d_w
 
 
 class _LevelPool(torch.autograd.Function):

@@ -123,6 +123,9 @@ class Trainer:
         # random draws of the loop (train.py:143,241,276); tests substitute recorded values
         self.draw_z = lambda: torch.randn(args.z_dim, device=device)
         self.draw_alpha = lambda: torch.rand(1, 1, device=device)
+        # the structural penalties only need the raw graphs and their latency-bound traversals keep
+        # one CU busy: they run on a second stream underneath the critic pass of the generator step
+        self.side_stream = torch.cuda.Stream(device=device)
 
     # templates are the same tensors every epoch: keep them (and their generator plan) per sample
     def templates_of(self, real_padded: Batch) -> List[Data]:
@@ -197,10 +200,15 @@ class Trainer:
         self.opt_G.zero_grad()
         zs = [self.draw_z() for _ in templates]
         raw_gen = [G(t, z) for t, z in zip(templates, zs)]
+        main_stream = torch.cuda.current_stream(dev)
+        self.side_stream.wait_stream(main_stream)
+        with torch.cuda.stream(self.side_stream):
+            pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
+            loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
         raw_batch_for_D = sanitize_for_D(self._pad_batch(raw_gen))
         loss_G_adv = -torch.mean(D(raw_batch_for_D))
-        pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
-        loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
+        main_stream.wait_stream(self.side_stream)
+        loss_pen.record_stream(main_stream)
         if (self.global_step % a.save_every) == 0:
             scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
             loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
