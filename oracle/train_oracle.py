@@ -56,8 +56,8 @@ class CpuTrainer:
             loss_d = (d_fake - d_real) + self.gp_lambda * gp
             loss_d.backward()
             self.opt.step()
-            m.update(D_real=float(d_real), D_fake=float(d_fake), gap=float(d_real - d_fake), gp=float(gp),
-                     grad_norm=float(gn), loss_D=float(loss_d))
+            m.update(D_real=float(d_real.detach()), D_fake=float(d_fake.detach()), gap=float((d_real - d_fake).detach()), gp=float(gp.detach()),
+                     grad_norm=float(gn), loss_D=float(loss_d.detach()))
         raw_gen = [self._fake(t, z) for t, z in zip(templates, zs_gen)]
         raw_batch = Batch.from_data_list([pad_data(r, self.max_nodes, self.max_edges) for r in raw_gen])
         self.opt.zero_grad()
