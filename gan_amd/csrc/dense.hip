@@ -14,85 +14,152 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int H = AIG_HIDDEN;
-constexpr int WG_BLOCKS_MAX = 256;  // one partial per CU
+constexpr int WG_BLOCKS_MAX = 256;         // F = 128: one 64 KB partial per CU
+constexpr int WG_SMALL_BLOCKS_MAX = 512;   // small F: partials are at most 2 KB, two blocks per CU
 
-// F == 128: wave w of a block owns rows 32w..32w+31 of dW and all four 32-column tiles.
-// MFMA 32x32x2: A[i][k] = g[n0+k][32w+i], B[k][c] = x[n0+k][32t+c], k = lane>>5, i/c = lane&31.
+// F == 128.  Node tiles of TILE rows of g and x go global -> LDS by direct 16-byte loads (no
+// register stop; one wave instruction fills two whole 512-byte rows), double-buffered: tile t+1 is
+// in flight while the matrix cores work on tile t, one barrier per tile.  Wave w owns rows
+// 32w..32w+31 of dW and all four 32-column tiles.  MFMA 32x32x2: A[i][k] = g[n0+k][32w+i],
+// B[k][c] = x[n0+k][32t+c], k = lane>>5, i/c = lane&31; the two k rows of an operand are read by
+// the two halves of the wave, which the LDS serves in separate cycles, so rows need no padding.
+constexpr int TILE = 64;
+constexpr size_t WGRAD_LDS = (size_t)2 * 2 * TILE * H * sizeof(float);
+
+__device__ __forceinline__ void load_to_lds16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void k_wgrad128(int n, const float* __restrict__ g, const float* __restrict__ x,
                                                   float* __restrict__ partial /*[grid][128][128]*/) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][g|x][TILE][H]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int col = lane & 31, kh = lane >> 5;
-    const int chunk = ((n + gridDim.x - 1) / gridDim.x + 1) & ~1;  // even: MFMA steps take node pairs
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * chunk, n1 = min(n, n0 + chunk);
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-    // four node pairs per trip: all twenty loads are issued before the first MFMA needs one
-    for (int nn = n0; nn < n1; nn += 8) {
-        float a[4], b[4][4];
+    const int ntiles = n1 > n0 ? (n1 - n0 + TILE - 1) / TILE : 0;
+    // wave w, instruction q fills tile rows 2(4q+w) and 2(4q+w)+1; lane -> (row parity kh, 16-byte column col)
+    auto fetch = [&](int tile, int buf) {
+        float* G = lds + (size_t)buf * 2 * TILE * H;
+        float* X = G + TILE * H;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = nn + 2 * u + kh;
-            const bool ok = row < n1;
-            const size_t off = (size_t)(ok ? row : n0) * H;
-            a[u] = ok ? g[off + 32 * w + col] : 0.f;
-            const float* xr = x + off + col;
-            b[u][0] = ok ? xr[0] : 0.f;
-            b[u][1] = ok ? xr[32] : 0.f;
-            b[u][2] = ok ? xr[64] : 0.f;
-            b[u][3] = ok ? xr[96] : 0.f;
+        for (int q = 0; q < TILE / 8; ++q) {
+            const int pr = 2 * (4 * q + w);
+            const int row = n0 + tile * TILE + pr + kh;
+            const size_t off = (size_t)(row < n1 ? row : n0) * H + 4 * col;  // rows past the range: any valid row
+            load_to_lds16(g + off, G + pr * H);
+            load_to_lds16(x + off, X + pr * H);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][2], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][3], acc[3], 0, 0, 0);
+    };
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    if (ntiles > 0) fetch(0, 0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        __syncthreads();  // drains this wave's loads of tile `tile`, then meets the other waves: the tile is
+                          // complete and the other buffer is no longer being read
+        const int rows = n1 - (n0 + tile * TILE);
+        if (rows < TILE) {  // last, ragged tile: rows past the range must not contribute
+            float* G = lds + (size_t)buf * 2 * TILE * H;
+            for (int i = rows * H + t; i < TILE * H; i += 256) G[i] = 0.f;
+            __syncthreads();
+        }
+        if (tile + 1 < ntiles) fetch(tile + 1, buf ^ 1);
+        const float* G = lds + (size_t)buf * 2 * TILE * H + 32 * w + col;
+        const float* X = lds + (size_t)buf * 2 * TILE * H + TILE * H + col;
+#pragma unroll 8
+        for (int kk = 0; kk < TILE / 2; ++kk) {
+            const int ro = (2 * kk + kh) * H;
+            const float a = G[ro];
+            const float b0 = X[ro], b1 = X[ro + 32], b2 = X[ro + 64], b3 = X[ro + 96];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
         }
     }
     float* out = partial + (size_t)blockIdx.x * H * H;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;  // accumulator register -> tile row
-            out[(size_t)(32 * w + row) * H + 32 * t + col] = acc[t][r];
+            out[(size_t)(32 * w + row) * H + 32 * tt + col] = acc[tt][r];
         }
 }
 
-// small F (the first layer has F = 2): thread (j, f) walks the block's node chunk
+// small F (the first layer has F = 2): half-wave per node row, 16-byte loads of g, the F inputs of
+// the row broadcast; the eight row groups of a block are added in fixed order through LDS
 template <int F>
-__global__ __launch_bounds__(128 * F) void k_wgrad_small(int n, const float* __restrict__ g,
-                                                         const float* __restrict__ x,
-                                                         float* __restrict__ partial /*[grid][128][F]*/) {
-    const int j = threadIdx.x % H, f = threadIdx.x / H;
+__global__ __launch_bounds__(256) void k_wgrad_small(int n, const float* __restrict__ g,
+                                                     const float* __restrict__ x,
+                                                     float* __restrict__ partial /*[grid][128][F]*/) {
+    __shared__ float4 red[8][F][32];
+    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     const int chunk = (n + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * chunk, n1 = min(n, n0 + chunk);
-    float acc = 0.f;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4 acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-    for (int nn = n0; nn < n1; ++nn) acc = fmaf(g[(size_t)nn * H + j], x[(size_t)nn * F + f], acc);
-    partial[(size_t)blockIdx.x * H * F + j * F + f] = acc;
-}
-
-// out[e] = sum_b partial[b][e], b ascending per thread stripe then a fixed tree
-__global__ __launch_bounds__(64) void k_wgrad_reduce(int nb, int elems, const float* __restrict__ partial,
-                                                      float* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= elems) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains keep loads in flight
-    int b = 0;
-    for (; b + 4 <= nb; b += 4) {
-        s0 += partial[(size_t)b * elems + e];
-        s1 += partial[(size_t)(b + 1) * elems + e];
-        s2 += partial[(size_t)(b + 2) * elems + e];
-        s3 += partial[(size_t)(b + 3) * elems + e];
+    for (int row = n0 + r0; row < n1; row += 8) {
+        const float4 gv = g4[(size_t)row * (H / 4) + c4];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float xv = x[(size_t)row * F + f];
+            acc[f].x = fmaf(gv.x, xv, acc[f].x);
+            acc[f].y = fmaf(gv.y, xv, acc[f].y);
+            acc[f].z = fmaf(gv.z, xv, acc[f].z);
+            acc[f].w = fmaf(gv.w, xv, acc[f].w);
+        }
     }
-    for (; b < nb; ++b) s0 += partial[(size_t)b * elems + e];
-    out[e] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int f = 0; f < F; ++f) red[r0][f][c4] = acc[f];
+    __syncthreads();
+    if (r0 < F) {
+        float4 s4 = red[0][r0][c4];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const float4 v = red[q][r0][c4];
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        }
+        float* out = partial + (size_t)blockIdx.x * H * F + (size_t)(4 * c4) * F + r0;
+        out[0] = s4.x; out[F] = s4.y; out[2 * F] = s4.z; out[3 * F] = s4.w;
+    }
 }
 
-int wg_blocks(int64_t n, int per_block) {
+// out[e] = sum_b partial[b][e]: 64 elements per block, sixteen stripes of b per element (ascending
+// within a stripe), stripes combined by a fixed tree
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(int nb, int elems, const float* __restrict__ partial,
+                                                        float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, st = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // independent chains keep loads in flight
+    if (e < elems) {
+        int b = st;
+        for (; b + 48 < nb; b += 64) {
+            s0 += partial[(size_t)b * elems + e];
+            s1 += partial[(size_t)(b + 16) * elems + e];
+            s2 += partial[(size_t)(b + 32) * elems + e];
+            s3 += partial[(size_t)(b + 48) * elems + e];
+        }
+        for (; b < nb; b += 16) s0 += partial[(size_t)b * elems + e];
+    }
+    red[st][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int half = 8; half > 0; half >>= 1) {
+        if (st < half) red[st][el] += red[st + half][el];
+        __syncthreads();
+    }
+    if (st == 0 && e < elems) out[e] = red[0][el];
+}
+
+int wg_blocks(int64_t n, int per_block, int cap) {
     int64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    if (b > WG_BLOCKS_MAX) b = WG_BLOCKS_MAX;
+    if (b > cap) b = cap;
     return (int)b;
 }
 
@@ -103,7 +170,8 @@ using namespace aig;
 
 extern "C" size_t aig_wgrad_ws_bytes(int64_t n, int64_t F) {
     (void)n;
-    return align_up((size_t)WG_BLOCKS_MAX * H * (size_t)(F > 0 ? F : 1) * 4) + 256;
+    const size_t blocks = F == 128 ? WG_BLOCKS_MAX : WG_SMALL_BLOCKS_MAX;
+    return align_up(blocks * H * (size_t)(F > 0 ? F : 1) * 4) + 256;
 }
 
 extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, float* dW, void* ws,
@@ -122,21 +190,27 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
     float* partial = static_cast<float*>(ws);
     int nb;
     if (F == 128) {
-        nb = wg_blocks(n, 256);
-        hipLaunchKernelGGL(k_wgrad128, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
+        static bool attr_set = false;  // idempotent; racing threads set the same value
+        if (!attr_set) {
+            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad128),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGRAD_LDS));
+            attr_set = true;
+        }
+        nb = wg_blocks(n, 2 * TILE, WG_BLOCKS_MAX);
+        hipLaunchKernelGGL(k_wgrad128, dim3(nb), dim3(256), WGRAD_LDS, s, (int)n, g, x, partial);
     } else if (F == 1) {
-        nb = wg_blocks(n, 1024);
-        hipLaunchKernelGGL(k_wgrad_small<1>, dim3(nb), dim3(128), 0, s, (int)n, g, x, partial);
+        nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
+        hipLaunchKernelGGL(k_wgrad_small<1>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
     } else if (F == 2) {
-        nb = wg_blocks(n, 1024);
+        nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
         hipLaunchKernelGGL(k_wgrad_small<2>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
     } else {
-        nb = wg_blocks(n, 1024);
-        hipLaunchKernelGGL(k_wgrad_small<4>, dim3(nb), dim3(512), 0, s, (int)n, g, x, partial);
+        nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
+        hipLaunchKernelGGL(k_wgrad_small<4>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
     }
     AIG_LAUNCH_CHECK();
     const int elems = (int)(H * F);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(64), 0, s, nb, elems, partial, dW);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(1024), 0, s, nb, elems, partial, dW);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

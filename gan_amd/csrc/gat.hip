@@ -4,6 +4,7 @@
 // owned by half a wavefront (32 lanes x float4), no floating-point atomics anywhere, so results
 // are bitwise reproducible run to run.
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -159,6 +160,34 @@ __global__ __launch_bounds__(THREADS) void k_gat_node_alpha(int n, const float* 
 
 // out[i] = elu( sum_e alpha_e * xw[src_e] + bias ),  alpha = softmax_e leaky_relu(a_s[src]+a_d[i]+ea*ce)
 // over the edges entering i plus its self loop (taken last).  alpha is kept for the backward pass.
+//
+// The kernel is latency-bound unless loads are kept in flight: a node needs row_ptr -> sources ->
+// rows, three dependent round trips.  An AIG node has at most two fan-ins (three entering edges with
+// the self loop in the forward orientation), so the common case is a straight-line path that issues
+// every load of a dependency level at once, for TWO nodes per half-wave at a time; longer lists
+// (fan-out lists of the dataset orientation) take the looped path.
+// exp through the hardware exp2 (v_exp_f32, ~1 ulp of the scaled argument): the accurate library
+// routines cost tens of instructions per call and made this bandwidth kernel ALU-bound
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+struct AggNode {
+    int i, beg, deg;
+    bool valid;
+    float adi, asl, lea;
+    int s[3];
+    float ea[3], as[3];
+    float4 r[3], rl;
+};
+
+__device__ __forceinline__ float4 elu4(float4 o) {
+    o.x = o.x > 0.f ? o.x : fast_exp(o.x) - 1.f; o.y = o.y > 0.f ? o.y : fast_exp(o.y) - 1.f;
+    o.z = o.z > 0.f ? o.z : fast_exp(o.z) - 1.f; o.w = o.w > 0.f ? o.w : fast_exp(o.w) - 1.f;
+    return o;
+}
+__device__ __forceinline__ void axpy4(float4& acc, float w, float4 r) {
+    acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
+}
+
 __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
     int n, const float* __restrict__ xw, const float* __restrict__ a_s, const float* __restrict__ a_d,
     const float* __restrict__ ce, const float* __restrict__ bias, const int* __restrict__ row_ptr,
@@ -169,10 +198,66 @@ __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
     const float4 b4 = reinterpret_cast<const float4*>(bias)[l];
     const float4* xw4 = reinterpret_cast<const float4*>(xw);
     NodeRange r = block_nodes(n);
-    for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
-        const int beg = row_ptr[i], end = row_ptr[i + 1];
-        const float adi = a_d[i * HEADS + h];
-        const float e_loop = lrelu(a_s[i * HEADS + h] + adi + loop_ea[i] * ceh);
+
+    auto level1 = [&](AggNode& nd, int i) {
+        nd.i = i;
+        nd.valid = i < r.end;
+        const int ii = nd.valid ? i : r.begin;
+        nd.beg = row_ptr[ii];
+        nd.deg = row_ptr[ii + 1] - nd.beg;
+        nd.adi = a_d[ii * HEADS + h];
+        nd.asl = a_s[ii * HEADS + h];
+        nd.lea = loop_ea[ii];
+        nd.rl = xw4[(size_t)ii * 32 + l];
+    };
+    auto level2 = [&](AggNode& nd) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool on = nd.valid && nd.deg <= 3 && k < nd.deg;
+            nd.s[k] = on ? csr_src[nd.beg + k] : nd.i < r.end ? nd.i : r.begin;
+            nd.ea[k] = on ? csr_ea[nd.beg + k] : 0.f;
+        }
+    };
+    auto level3 = [&](AggNode& nd) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            nd.r[k] = xw4[(size_t)nd.s[k] * 32 + l];
+            nd.as[k] = a_s[nd.s[k] * HEADS + h];
+        }
+    };
+    auto finish_small = [&](const AggNode& nd) {
+        const float e_loop = lrelu(nd.asl + nd.adi + nd.lea * ceh);
+        float e[3], m = e_loop;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            e[k] = lrelu(nd.as[k] + nd.adi + nd.ea[k] * ceh);
+            if (k < nd.deg) m = fmaxf(m, e[k]);
+        }
+        float den = 0.f, w[3];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            w[k] = k < nd.deg ? fast_exp(e[k] - m) : 0.f;
+            den += w[k];
+            axpy4(acc, w[k], nd.r[k]);
+        }
+        const float wl = fast_exp(e_loop - m);
+        den += wl;
+        axpy4(acc, wl, nd.rl);
+        const float inv = 1.f / (den + SOFTMAX_EPS);
+        float4 o = make_float4(acc.x * inv + b4.x, acc.y * inv + b4.y, acc.z * inv + b4.z, acc.w * inv + b4.w);
+        reinterpret_cast<float4*>(out + (size_t)nd.i * H)[l] = elu4(o);
+        if ((l & 7) == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < nd.deg) alpha_e[(size_t)(nd.beg + k) * HEADS + h] = w[k] * inv;
+            alpha_loop[nd.i * HEADS + h] = wl * inv;
+        }
+    };
+    auto finish_long = [&](const AggNode& nd) {
+        const int i = nd.i, beg = nd.beg, end = nd.beg + nd.deg;
+        const float adi = nd.adi;
+        const float e_loop = lrelu(nd.asl + adi + nd.lea * ceh);
         float m = e_loop;
         for (int p = beg; p < end; ++p) m = fmaxf(m, lrelu(a_s[csr_src[p] * HEADS + h] + adi + csr_ea[p] * ceh));
         float den = 0.f;
@@ -182,39 +267,45 @@ __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
             int s0 = csr_src[p], s1 = csr_src[p + 1], s2 = csr_src[p + 2], s3 = csr_src[p + 3];
             float4 r0 = xw4[(size_t)s0 * 32 + l], r1 = xw4[(size_t)s1 * 32 + l], r2 = xw4[(size_t)s2 * 32 + l],
                    r3 = xw4[(size_t)s3 * 32 + l];
-            float w0 = expf(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m);
-            float w1 = expf(lrelu(a_s[s1 * HEADS + h] + adi + csr_ea[p + 1] * ceh) - m);
-            float w2 = expf(lrelu(a_s[s2 * HEADS + h] + adi + csr_ea[p + 2] * ceh) - m);
-            float w3 = expf(lrelu(a_s[s3 * HEADS + h] + adi + csr_ea[p + 3] * ceh) - m);
-            den += w0; acc.x += w0 * r0.x; acc.y += w0 * r0.y; acc.z += w0 * r0.z; acc.w += w0 * r0.w;
-            den += w1; acc.x += w1 * r1.x; acc.y += w1 * r1.y; acc.z += w1 * r1.z; acc.w += w1 * r1.w;
-            den += w2; acc.x += w2 * r2.x; acc.y += w2 * r2.y; acc.z += w2 * r2.z; acc.w += w2 * r2.w;
-            den += w3; acc.x += w3 * r3.x; acc.y += w3 * r3.y; acc.z += w3 * r3.z; acc.w += w3 * r3.w;
+            float w0 = fast_exp(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m);
+            float w1 = fast_exp(lrelu(a_s[s1 * HEADS + h] + adi + csr_ea[p + 1] * ceh) - m);
+            float w2 = fast_exp(lrelu(a_s[s2 * HEADS + h] + adi + csr_ea[p + 2] * ceh) - m);
+            float w3 = fast_exp(lrelu(a_s[s3 * HEADS + h] + adi + csr_ea[p + 3] * ceh) - m);
+            den += w0; axpy4(acc, w0, r0);
+            den += w1; axpy4(acc, w1, r1);
+            den += w2; axpy4(acc, w2, r2);
+            den += w3; axpy4(acc, w3, r3);
         }
-        {   // tail of up to three edges and the self loop, loads issued together
-            const int rem = end - p;
-            int s0 = rem > 0 ? csr_src[p] : i, s1 = rem > 1 ? csr_src[p + 1] : i, s2 = rem > 2 ? csr_src[p + 2] : i;
-            float4 r0 = xw4[(size_t)s0 * 32 + l], r1 = xw4[(size_t)s1 * 32 + l], r2 = xw4[(size_t)s2 * 32 + l],
-                   rl = xw4[(size_t)i * 32 + l];
-            float w0 = rem > 0 ? expf(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m) : 0.f;
-            float w1 = rem > 1 ? expf(lrelu(a_s[s1 * HEADS + h] + adi + csr_ea[p + 1] * ceh) - m) : 0.f;
-            float w2 = rem > 2 ? expf(lrelu(a_s[s2 * HEADS + h] + adi + csr_ea[p + 2] * ceh) - m) : 0.f;
-            float wl = expf(e_loop - m);
-            den += w0; acc.x += w0 * r0.x; acc.y += w0 * r0.y; acc.z += w0 * r0.z; acc.w += w0 * r0.w;
-            den += w1; acc.x += w1 * r1.x; acc.y += w1 * r1.y; acc.z += w1 * r1.z; acc.w += w1 * r1.w;
-            den += w2; acc.x += w2 * r2.x; acc.y += w2 * r2.y; acc.z += w2 * r2.z; acc.w += w2 * r2.w;
-            den += wl; acc.x += wl * rl.x; acc.y += wl * rl.y; acc.z += wl * rl.z; acc.w += wl * rl.w;
+        for (; p < end; ++p) {
+            const int s0 = csr_src[p];
+            const float4 r0 = xw4[(size_t)s0 * 32 + l];
+            const float w0 = fast_exp(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m);
+            den += w0; axpy4(acc, w0, r0);
         }
+        const float wl = fast_exp(e_loop - m);
+        den += wl;
+        axpy4(acc, wl, nd.rl);
         const float inv = 1.f / (den + SOFTMAX_EPS);
-        float4 o;
-        o.x = acc.x * inv + b4.x; o.y = acc.y * inv + b4.y; o.z = acc.z * inv + b4.z; o.w = acc.w * inv + b4.w;
-        o.x = o.x > 0.f ? o.x : expm1f(o.x); o.y = o.y > 0.f ? o.y : expm1f(o.y);
-        o.z = o.z > 0.f ? o.z : expm1f(o.z); o.w = o.w > 0.f ? o.w : expm1f(o.w);
-        reinterpret_cast<float4*>(out + (size_t)i * H)[l] = o;
-        if ((l & 7) == 0) {  // attention coefficients, one per head
+        float4 o = make_float4(acc.x * inv + b4.x, acc.y * inv + b4.y, acc.z * inv + b4.z, acc.w * inv + b4.w);
+        reinterpret_cast<float4*>(out + (size_t)i * H)[l] = elu4(o);
+        if ((l & 7) == 0) {
             for (int q = beg; q < end; ++q)
-                alpha_e[(size_t)q * HEADS + h] = expf(lrelu(a_s[csr_src[q] * HEADS + h] + adi + csr_ea[q] * ceh) - m) * inv;
-            alpha_loop[i * HEADS + h] = expf(e_loop - m) * inv;
+                alpha_e[(size_t)q * HEADS + h] = fast_exp(lrelu(a_s[csr_src[q] * HEADS + h] + adi + csr_ea[q] * ceh) - m) * inv;
+            alpha_loop[i * HEADS + h] = wl * inv;
+        }
+    };
+
+    for (int i = r.begin + hw; i < r.end; i += 2 * HW_PER_BLOCK) {
+        AggNode A, B;
+        level1(A, i);
+        level1(B, i + HW_PER_BLOCK);
+        level2(A);
+        level2(B);
+        level3(A);
+        level3(B);
+        if (A.deg <= 3) finish_small(A); else finish_long(A);
+        if (B.valid) {
+            if (B.deg <= 3) finish_small(B); else finish_long(B);
         }
     }
 }
@@ -470,10 +561,18 @@ __global__ __launch_bounds__(256) void k_reduce_cols(int nb, int width, const fl
     if (t == 0) out[c] = red[0];
 }
 
+// Grid of the node-parallel kernels: a multiple of 8 (XCD grouping), at least 8 nodes per half-wave
+// before more blocks are added, capped at 2048 (measured: finer cuts than co-residency win here).
+// AIG_GAT_GRID_CAP overrides the cap (tuning aid).
 int grid_blocks(int64_t n) {
-    int64_t g = (n + 63) / 64;         // at least 8 targets per half-wave before adding blocks
+    static const int cap = [] {
+        const char* e = getenv("AIG_GAT_GRID_CAP");
+        int c = e ? atoi(e) : 0;
+        return c >= 8 ? c / 8 * 8 : 2048;
+    }();
+    int64_t g = (n + 63) / 64;
     g = (g + 7) / 8 * 8;
-    if (g > 2048) g = 2048;
+    if (g > cap) g = cap;
     if (g < 8) g = 8;
     return (int)g;
 }
