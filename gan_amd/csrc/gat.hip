@@ -161,23 +161,21 @@ __global__ __launch_bounds__(THREADS) void k_gat_node_alpha(int n, const float* 
 // out[i] = elu( sum_e alpha_e * xw[src_e] + bias ),  alpha = softmax_e leaky_relu(a_s[src]+a_d[i]+ea*ce)
 // over the edges entering i plus its self loop (taken last).  alpha is kept for the backward pass.
 //
-// The kernel is latency-bound unless loads are kept in flight: a node needs row_ptr -> sources ->
-// rows, three dependent round trips.  An AIG node has at most two fan-ins (three entering edges with
-// the self loop in the forward orientation), so the common case is a straight-line path that issues
-// every load of a dependency level at once, for TWO nodes per half-wave at a time; longer lists
-// (fan-out lists of the dataset orientation) take the looped path.
+// One half-wave per node.  The kernel is latency-bound unless loads are kept in flight, and a node
+// needs row_ptr -> sources -> rows, three dependent round trips, so every level issues all of its
+// loads at once, unconditionally (a load under a condition compiles to a branch with a wait behind
+// it; indices are clamped instead):
+//   level 1  row_ptr[i], row_ptr[i+1], a_d[i] (four heads), loop_ea[i]
+//   level 2  lane k reads entry k of the node's list: source and edge attribute, coalesced; the
+//            self loop is entry `deg`
+//   level 3  lane k reads a_s[source_k] (four heads, 16 bytes); the first four source ids are
+//            broadcast and their rows fetched, 16 bytes per lane
+// Scores, softmax and alpha are computed entry-per-lane for the four heads, reduced across lanes
+// (two DPP steps when the list has at most four entries, the usual case for an AIG), alpha is
+// stored 16 bytes per lane and handed to the row accumulation through LDS.
 // exp through the hardware exp2 (v_exp_f32, ~1 ulp of the scaled argument): the accurate library
-// routines cost tens of instructions per call and made this bandwidth kernel ALU-bound
+// routines cost tens of instructions per call and made this bandwidth kernel ALU-bound.
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-
-struct AggNode {
-    int i, beg, deg;
-    bool valid;
-    float adi, asl, lea;
-    int s[3];
-    float ea[3], as[3];
-    float4 r[3], rl;
-};
 
 __device__ __forceinline__ float4 elu4(float4 o) {
     o.x = o.x > 0.f ? o.x : fast_exp(o.x) - 1.f; o.y = o.y > 0.f ? o.y : fast_exp(o.y) - 1.f;
@@ -188,125 +186,158 @@ __device__ __forceinline__ void axpy4(float4& acc, float w, float4 r) {
     acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
 }
 
+// value of the lane selected by a DPP control word within the row of 16
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
+
+struct MaxOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
+};
+struct SumOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+// reduction over the lanes of a half-wave, result in every lane; `wide` (uniform per half-wave)
+// says whether lanes beyond the first quad hold data at all
+template <class Op>
+__device__ __forceinline__ float4 halfwave_reduce(float4 v, bool wide, Op op) {
+    v.x = op(v.x, dpp<DPP_XOR1>(v.x)); v.y = op(v.y, dpp<DPP_XOR1>(v.y));
+    v.z = op(v.z, dpp<DPP_XOR1>(v.z)); v.w = op(v.w, dpp<DPP_XOR1>(v.w));
+    v.x = op(v.x, dpp<DPP_XOR2>(v.x)); v.y = op(v.y, dpp<DPP_XOR2>(v.y));
+    v.z = op(v.z, dpp<DPP_XOR2>(v.z)); v.w = op(v.w, dpp<DPP_XOR2>(v.w));
+    if (wide) {
+#pragma unroll
+        for (int off = 4; off < 32; off <<= 1) {
+            v.x = op(v.x, __shfl_xor(v.x, off, 32)); v.y = op(v.y, __shfl_xor(v.y, off, 32));
+            v.z = op(v.z, __shfl_xor(v.z, off, 32)); v.w = op(v.w, __shfl_xor(v.w, off, 32));
+        }
+    } else {  // every lane learns the first quad's result
+        v.x = __shfl(v.x, 0, 32); v.y = __shfl(v.y, 0, 32); v.z = __shfl(v.z, 0, 32); v.w = __shfl(v.w, 0, 32);
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
     int n, const float* __restrict__ xw, const float* __restrict__ a_s, const float* __restrict__ a_d,
     const float* __restrict__ ce, const float* __restrict__ bias, const int* __restrict__ row_ptr,
     const int* __restrict__ csr_src, const float* __restrict__ csr_ea, const float* __restrict__ loop_ea,
     float* __restrict__ out, float* __restrict__ alpha_e, float* __restrict__ alpha_loop) {
+    __shared__ float s_alpha[HW_PER_BLOCK][32][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
-    const float ceh = ce[h];
+    const float4 ce4 = make_float4(ce[0], ce[1], ce[2], ce[3]);
     const float4 b4 = reinterpret_cast<const float4*>(bias)[l];
     const float4* xw4 = reinterpret_cast<const float4*>(xw);
+    const float4* as4p = reinterpret_cast<const float4*>(a_s);
+    const float4* ad4p = reinterpret_cast<const float4*>(a_d);
+    float4* alpha_e4 = reinterpret_cast<float4*>(alpha_e);
+    float4* alpha_loop4 = reinterpret_cast<float4*>(alpha_loop);
+    // clamped list reads need one valid element even when the graph has no edge at all
+    const bool has_edges = row_ptr[n] > 0;
+    const int* src_safe = has_edges ? csr_src : row_ptr;
+    const float* ea_safe = has_edges ? csr_ea : loop_ea;
     NodeRange r = block_nodes(n);
+    const float NEG_INF = -__builtin_huge_valf();
 
-    auto level1 = [&](AggNode& nd, int i) {
-        nd.i = i;
-        nd.valid = i < r.end;
-        const int ii = nd.valid ? i : r.begin;
-        nd.beg = row_ptr[ii];
-        nd.deg = row_ptr[ii + 1] - nd.beg;
-        nd.adi = a_d[ii * HEADS + h];
-        nd.asl = a_s[ii * HEADS + h];
-        nd.lea = loop_ea[ii];
-        nd.rl = xw4[(size_t)ii * 32 + l];
-    };
-    auto level2 = [&](AggNode& nd) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const bool on = nd.valid && nd.deg <= 3 && k < nd.deg;
-            nd.s[k] = on ? csr_src[nd.beg + k] : nd.i < r.end ? nd.i : r.begin;
-            nd.ea[k] = on ? csr_ea[nd.beg + k] : 0.f;
-        }
-    };
-    auto level3 = [&](AggNode& nd) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            nd.r[k] = xw4[(size_t)nd.s[k] * 32 + l];
-            nd.as[k] = a_s[nd.s[k] * HEADS + h];
-        }
-    };
-    auto finish_small = [&](const AggNode& nd) {
-        const float e_loop = lrelu(nd.asl + nd.adi + nd.lea * ceh);
-        float e[3], m = e_loop;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            e[k] = lrelu(nd.as[k] + nd.adi + nd.ea[k] * ceh);
-            if (k < nd.deg) m = fmaxf(m, e[k]);
-        }
-        float den = 0.f, w[3];
+    for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
+        const int beg = row_ptr[i], deg = row_ptr[i + 1] - beg;
+        const float4 ad4 = ad4p[i];
+        const float lea = loop_ea[i];
+        // entry idx of the list: edges 0..deg-1, then the self loop
+        auto entry = [&](int idx, int& s, float4& e) {
+            const bool is_edge = idx < deg;
+            const int p = is_edge ? beg + idx : 0;
+            const int sv = src_safe[p];
+            const float eav = ea_safe[p];
+            s = is_edge ? sv : i;
+            const float ea = is_edge ? eav : lea;
+            const float4 as4 = as4p[s];
+            e.x = lrelu(as4.x + ad4.x + ea * ce4.x); e.y = lrelu(as4.y + ad4.y + ea * ce4.y);
+            e.z = lrelu(as4.z + ad4.z + ea * ce4.z); e.w = lrelu(as4.w + ad4.w + ea * ce4.w);
+            if (idx > deg) e = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+        };
+        auto put_alpha = [&](int idx, float4 al) {
+            if (idx < deg) alpha_e4[beg + idx] = al;
+            if (idx == deg) alpha_loop4[i] = al;
+            *reinterpret_cast<float4*>(&s_alpha[hw][l][0]) = al;
+        };
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            w[k] = k < nd.deg ? fast_exp(e[k] - m) : 0.f;
-            den += w[k];
-            axpy4(acc, w[k], nd.r[k]);
+        if (deg < 32) {
+            int s;
+            float4 e;
+            entry(l, s, e);
+            const int s0 = __shfl(s, 0, 32), s1 = __shfl(s, 1, 32), s2 = __shfl(s, 2, 32), s3 = __shfl(s, 3, 32);
+            const float4 r0 = xw4[(size_t)s0 * 32 + l], r1 = xw4[(size_t)s1 * 32 + l], r2 = xw4[(size_t)s2 * 32 + l],
+                         r3 = xw4[(size_t)s3 * 32 + l];
+            const bool wide = deg > 3;
+            const float4 m = halfwave_reduce(e, wide, MaxOp());
+            float4 w = make_float4(fast_exp(e.x - m.x), fast_exp(e.y - m.y), fast_exp(e.z - m.z), fast_exp(e.w - m.w));
+            const float4 den = halfwave_reduce(w, wide, SumOp());
+            w.x *= 1.f / (den.x + SOFTMAX_EPS); w.y *= 1.f / (den.y + SOFTMAX_EPS);
+            w.z *= 1.f / (den.z + SOFTMAX_EPS); w.w *= 1.f / (den.w + SOFTMAX_EPS);
+            put_alpha(l, w);
+            __builtin_amdgcn_wave_barrier();
+            axpy4(acc, s_alpha[hw][0][h], r0);
+            axpy4(acc, s_alpha[hw][1][h], r1);
+            axpy4(acc, s_alpha[hw][2][h], r2);
+            axpy4(acc, s_alpha[hw][3][h], r3);
+            for (int k0 = 4; k0 <= deg; k0 += 4) {  // lanes past the list carry alpha 0 and the node's own id
+                const int t0 = __shfl(s, k0, 32), t1 = __shfl(s, k0 + 1, 32), t2 = __shfl(s, k0 + 2, 32),
+                          t3 = __shfl(s, k0 + 3, 32);
+                const float4 q0 = xw4[(size_t)t0 * 32 + l], q1 = xw4[(size_t)t1 * 32 + l],
+                             q2 = xw4[(size_t)t2 * 32 + l], q3 = xw4[(size_t)t3 * 32 + l];
+                axpy4(acc, s_alpha[hw][k0][h], q0);
+                axpy4(acc, s_alpha[hw][k0 + 1][h], q1);
+                axpy4(acc, s_alpha[hw][k0 + 2][h], q2);
+                axpy4(acc, s_alpha[hw][k0 + 3][h], q3);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // long list: chunks of 32 entries, three sweeps (max, denominator, alpha + rows)
+            const int cnt = deg + 1;
+            float4 m = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            for (int c0 = 0; c0 < cnt; c0 += 32) {
+                int s;
+                float4 e;
+                entry(c0 + l, s, e);
+                m.x = fmaxf(m.x, e.x); m.y = fmaxf(m.y, e.y); m.z = fmaxf(m.z, e.z); m.w = fmaxf(m.w, e.w);
+            }
+            m = halfwave_reduce(m, true, MaxOp());
+            float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c0 = 0; c0 < cnt; c0 += 32) {
+                int s;
+                float4 e;
+                entry(c0 + l, s, e);
+                den.x += fast_exp(e.x - m.x); den.y += fast_exp(e.y - m.y);
+                den.z += fast_exp(e.z - m.z); den.w += fast_exp(e.w - m.w);
+            }
+            den = halfwave_reduce(den, true, SumOp());
+            const float4 inv = make_float4(1.f / (den.x + SOFTMAX_EPS), 1.f / (den.y + SOFTMAX_EPS),
+                                           1.f / (den.z + SOFTMAX_EPS), 1.f / (den.w + SOFTMAX_EPS));
+            for (int c0 = 0; c0 < cnt; c0 += 32) {
+                int s;
+                float4 e;
+                entry(c0 + l, s, e);
+                put_alpha(c0 + l, make_float4(fast_exp(e.x - m.x) * inv.x, fast_exp(e.y - m.y) * inv.y,
+                                              fast_exp(e.z - m.z) * inv.z, fast_exp(e.w - m.w) * inv.w));
+                __builtin_amdgcn_wave_barrier();
+                const int lim = min(32, cnt - c0);
+                for (int k0 = 0; k0 < lim; k0 += 4) {
+                    const int t0 = __shfl(s, k0, 32), t1 = __shfl(s, k0 + 1, 32), t2 = __shfl(s, k0 + 2, 32),
+                              t3 = __shfl(s, k0 + 3, 32);
+                    const float4 q0 = xw4[(size_t)t0 * 32 + l], q1 = xw4[(size_t)t1 * 32 + l],
+                                 q2 = xw4[(size_t)t2 * 32 + l], q3 = xw4[(size_t)t3 * 32 + l];
+                    axpy4(acc, s_alpha[hw][k0][h], q0);
+                    axpy4(acc, s_alpha[hw][k0 + 1][h], q1);
+                    axpy4(acc, s_alpha[hw][k0 + 2][h], q2);
+                    axpy4(acc, s_alpha[hw][k0 + 3][h], q3);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        const float wl = fast_exp(e_loop - m);
-        den += wl;
-        axpy4(acc, wl, nd.rl);
-        const float inv = 1.f / (den + SOFTMAX_EPS);
-        float4 o = make_float4(acc.x * inv + b4.x, acc.y * inv + b4.y, acc.z * inv + b4.z, acc.w * inv + b4.w);
-        reinterpret_cast<float4*>(out + (size_t)nd.i * H)[l] = elu4(o);
-        if ((l & 7) == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (k < nd.deg) alpha_e[(size_t)(nd.beg + k) * HEADS + h] = w[k] * inv;
-            alpha_loop[nd.i * HEADS + h] = wl * inv;
-        }
-    };
-    auto finish_long = [&](const AggNode& nd) {
-        const int i = nd.i, beg = nd.beg, end = nd.beg + nd.deg;
-        const float adi = nd.adi;
-        const float e_loop = lrelu(nd.asl + adi + nd.lea * ceh);
-        float m = e_loop;
-        for (int p = beg; p < end; ++p) m = fmaxf(m, lrelu(a_s[csr_src[p] * HEADS + h] + adi + csr_ea[p] * ceh));
-        float den = 0.f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int p = beg;
-        for (; p + 4 <= end; p += 4) {  // four row gathers in flight
-            int s0 = csr_src[p], s1 = csr_src[p + 1], s2 = csr_src[p + 2], s3 = csr_src[p + 3];
-            float4 r0 = xw4[(size_t)s0 * 32 + l], r1 = xw4[(size_t)s1 * 32 + l], r2 = xw4[(size_t)s2 * 32 + l],
-                   r3 = xw4[(size_t)s3 * 32 + l];
-            float w0 = fast_exp(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m);
-            float w1 = fast_exp(lrelu(a_s[s1 * HEADS + h] + adi + csr_ea[p + 1] * ceh) - m);
-            float w2 = fast_exp(lrelu(a_s[s2 * HEADS + h] + adi + csr_ea[p + 2] * ceh) - m);
-            float w3 = fast_exp(lrelu(a_s[s3 * HEADS + h] + adi + csr_ea[p + 3] * ceh) - m);
-            den += w0; axpy4(acc, w0, r0);
-            den += w1; axpy4(acc, w1, r1);
-            den += w2; axpy4(acc, w2, r2);
-            den += w3; axpy4(acc, w3, r3);
-        }
-        for (; p < end; ++p) {
-            const int s0 = csr_src[p];
-            const float4 r0 = xw4[(size_t)s0 * 32 + l];
-            const float w0 = fast_exp(lrelu(a_s[s0 * HEADS + h] + adi + csr_ea[p] * ceh) - m);
-            den += w0; axpy4(acc, w0, r0);
-        }
-        const float wl = fast_exp(e_loop - m);
-        den += wl;
-        axpy4(acc, wl, nd.rl);
-        const float inv = 1.f / (den + SOFTMAX_EPS);
-        float4 o = make_float4(acc.x * inv + b4.x, acc.y * inv + b4.y, acc.z * inv + b4.z, acc.w * inv + b4.w);
+        const float4 o = make_float4(acc.x + b4.x, acc.y + b4.y, acc.z + b4.z, acc.w + b4.w);
         reinterpret_cast<float4*>(out + (size_t)i * H)[l] = elu4(o);
-        if ((l & 7) == 0) {
-            for (int q = beg; q < end; ++q)
-                alpha_e[(size_t)q * HEADS + h] = fast_exp(lrelu(a_s[csr_src[q] * HEADS + h] + adi + csr_ea[q] * ceh) - m) * inv;
-            alpha_loop[i * HEADS + h] = wl * inv;
-        }
-    };
-
-    for (int i = r.begin + hw; i < r.end; i += 2 * HW_PER_BLOCK) {
-        AggNode A, B;
-        level1(A, i);
-        level1(B, i + HW_PER_BLOCK);
-        level2(A);
-        level2(B);
-        level3(A);
-        level3(B);
-        if (A.deg <= 3) finish_small(A); else finish_long(A);
-        if (B.valid) {
-            if (B.deg <= 3) finish_small(B); else finish_long(B);
-        }
     }
 }
 
