@@ -108,6 +108,21 @@ __global__ void k_seg_count(int n, const int* __restrict__ col_ptr, int* __restr
     }
 }
 
+// descriptor of every segment: {owner j, first position, one past the last position, segments of j}
+__global__ void k_seg_desc(int n, int nseg_cap, const int* __restrict__ seg_base, const int* __restrict__ col_ptr,
+                           int4* __restrict__ desc) {
+    const int nseg = min(seg_base[n], nseg_cap);
+    for (int sgm = blockIdx.x * blockDim.x + threadIdx.x; sgm < nseg; sgm += gridDim.x * blockDim.x) {
+        int lo = 0, hi = n;  // owner: the last node j with seg_base[j] <= sgm
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_base[mid] <= sgm) lo = mid; else hi = mid;
+        }
+        const int first = seg_base[lo], beg = col_ptr[lo] + (sgm - first) * SEG;
+        desc[sgm] = make_int4(lo, beg, min(col_ptr[lo + 1], beg + SEG), seg_base[lo + 1] - first);
+    }
+}
+
 size_t scan_temp_bytes(int64_t n) {
     size_t bytes = 0;
     int* p = nullptr;
@@ -131,10 +146,18 @@ __device__ __forceinline__ NodeRange block_nodes(int n) {
     return {b, e};
 }
 
+// value of the lane selected by a DPP control word within the row of 16
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;           // lane j <-> 7-j within each group of 8
+
 __device__ __forceinline__ float head_sum(float v) {  // sum over the 8 lanes of one head, result in all 8
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
+    v += dpp<DPP_XOR1>(v);
+    v += dpp<DPP_XOR2>(v);
+    v += dpp<DPP_HALF_MIRROR>(v);  // quads are uniform by now, the mirror lane sits in the other quad
     return v;
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -185,13 +208,6 @@ __device__ __forceinline__ float4 elu4(float4 o) {
 __device__ __forceinline__ void axpy4(float4& acc, float w, float4 r) {
     acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
 }
-
-// value of the lane selected by a DPP control word within the row of 16
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
 
 struct MaxOp {
     __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
@@ -345,6 +361,10 @@ __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
 // Target side.  g = g_out * elu'(out);  dalpha_e = <g_h, xw[src_e]_h>;  softmax and leaky-relu
 // derivatives give d_raw_e (per edge and head) and d_a_d[i]; per-block partial sums of g (bias
 // gradient) and of d_raw*ea (edge-coefficient gradient) go to `partial`.
+// Same shape as the forward kernel: half-wave per node, list entry k (edges, then the self loop)
+// lives in lane k with its four heads, loads of a level issued together with clamped indices; the
+// dot products against the gathered rows are made row-per-half-wave and handed to the entry lanes
+// through LDS.
 __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
     int n, const float* __restrict__ g_out, const float* __restrict__ out, const float* __restrict__ xw,
     const float* __restrict__ a_s, const float* __restrict__ a_d, const float* __restrict__ ce,
@@ -353,54 +373,132 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
     float* __restrict__ g_pre, float* __restrict__ d_raw_e, float* __restrict__ d_raw_loop,
     float* __restrict__ d_a_d, float* __restrict__ partial /*[grid][H + HEADS]*/) {
     __shared__ float red[HW_PER_BLOCK][H + HEADS];
+    __shared__ float s_da[HW_PER_BLOCK][32][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
-    const float ceh = ce[h];
+    const float4 ce4 = make_float4(ce[0], ce[1], ce[2], ce[3]);
     const float4* xw4 = reinterpret_cast<const float4*>(xw);
-    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dce = 0.f;
+    const float4* as4p = reinterpret_cast<const float4*>(a_s);
+    const float4* ad4p = reinterpret_cast<const float4*>(a_d);
+    const float4* al_loop4 = reinterpret_cast<const float4*>(alpha_loop);
+    float4* d_raw_e4 = reinterpret_cast<float4*>(d_raw_e);
+    float4* d_raw_loop4 = reinterpret_cast<float4*>(d_raw_loop);
+    float4* d_a_d4 = reinterpret_cast<float4*>(d_a_d);
+    const bool has_edges = row_ptr[n] > 0;  // clamped list reads need one valid element
+    const int* src_safe = has_edges ? csr_src : row_ptr;
+    const float* ea_safe = has_edges ? csr_ea : loop_ea;
+    const float4* al_safe = reinterpret_cast<const float4*>(has_edges ? alpha_e : alpha_loop);
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f), dce = gsum;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     NodeRange r = block_nodes(n);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
-        float4 o = reinterpret_cast<const float4*>(out + (size_t)i * H)[l];
+        const float4 o = reinterpret_cast<const float4*>(out + (size_t)i * H)[l];
         float4 g = reinterpret_cast<const float4*>(g_out + (size_t)i * H)[l];
+        const int beg = row_ptr[i], deg = row_ptr[i + 1] - beg;
+        const float4 ad4 = ad4p[i];
+        const float lea = loop_ea[i];
+        const float4 all4 = al_loop4[i];
         g.x *= o.x > 0.f ? 1.f : o.x + 1.f; g.y *= o.y > 0.f ? 1.f : o.y + 1.f;
         g.z *= o.z > 0.f ? 1.f : o.z + 1.f; g.w *= o.w > 0.f ? 1.f : o.w + 1.f;
         reinterpret_cast<float4*>(g_pre + (size_t)i * H)[l] = g;
         gsum.x += g.x; gsum.y += g.y; gsum.z += g.z; gsum.w += g.w;
-        const int beg = row_ptr[i], end = row_ptr[i + 1];
-        const float adi = a_d[i * HEADS + h];
-        // pass A: sdot = sum_e alpha_e * dalpha_e (self loop included)
-        const float al_loop = alpha_loop[i * HEADS + h];
-        const float da_loop = head_sum(dot4(g, xw4[(size_t)i * 32 + l]));
-        float sdot = al_loop * da_loop;
-        for (int p = beg; p < end; ++p) {
-            float da = head_sum(dot4(g, xw4[(size_t)csr_src[p] * 32 + l]));
-            sdot += alpha_e[(size_t)p * HEADS + h] * da;
-        }
-        // pass B: d_raw = alpha (dalpha - sdot) * lrelu'(raw)
-        float dad = 0.f;
-        for (int p = beg; p < end; ++p) {
-            const int s = csr_src[p];
-            float da = head_sum(dot4(g, xw4[(size_t)s * 32 + l]));
-            float raw = a_s[s * HEADS + h] + adi + csr_ea[p] * ceh;
-            float dr = alpha_e[(size_t)p * HEADS + h] * (da - sdot) * (raw > 0.f ? 1.f : NEG_SLOPE);
-            dad += dr;
-            dce += (l & 7) == 0 ? dr * csr_ea[p] : 0.f;
-            if ((l & 7) == 0) d_raw_e[(size_t)p * HEADS + h] = dr;
-        }
-        {
-            float raw = a_s[i * HEADS + h] + adi + loop_ea[i] * ceh;
-            float dr = al_loop * (da_loop - sdot) * (raw > 0.f ? 1.f : NEG_SLOPE);
-            dad += dr;
-            dce += (l & 7) == 0 ? dr * loop_ea[i] : 0.f;
+        // entry idx: edges 0..deg-1, then the self loop; lanes past the list get alpha 0
+        auto entry = [&](int idx, int& s, float& ea, float4& al, float4& slope) {
+            const bool is_edge = idx < deg;
+            const int p = is_edge ? beg + idx : 0;
+            const int sv = src_safe[p];
+            const float eav = ea_safe[p];
+            const float4 alv = al_safe[p];
+            s = is_edge ? sv : i;
+            ea = is_edge ? eav : lea;
+            al = is_edge ? alv : (idx == deg ? all4 : zero4);
+            const float4 as4 = as4p[s];
+            slope.x = as4.x + ad4.x + ea * ce4.x > 0.f ? 1.f : NEG_SLOPE;
+            slope.y = as4.y + ad4.y + ea * ce4.y > 0.f ? 1.f : NEG_SLOPE;
+            slope.z = as4.z + ad4.z + ea * ce4.z > 0.f ? 1.f : NEG_SLOPE;
+            slope.w = as4.w + ad4.w + ea * ce4.w > 0.f ? 1.f : NEG_SLOPE;
+        };
+        // dalpha of entries k0..k0+3 of the chunk held in `s`, left in s_da[hw][k0..k0+3]
+        auto dots = [&](int s, int k0) {
+            const int t0 = __shfl(s, k0, 32), t1 = __shfl(s, k0 + 1, 32), t2 = __shfl(s, k0 + 2, 32),
+                      t3 = __shfl(s, k0 + 3, 32);
+            const float4 q0 = xw4[(size_t)t0 * 32 + l], q1 = xw4[(size_t)t1 * 32 + l], q2 = xw4[(size_t)t2 * 32 + l],
+                         q3 = xw4[(size_t)t3 * 32 + l];
+            const float v0 = head_sum(dot4(g, q0)), v1 = head_sum(dot4(g, q1)), v2 = head_sum(dot4(g, q2)),
+                        v3 = head_sum(dot4(g, q3));
             if ((l & 7) == 0) {
-                d_raw_loop[i * HEADS + h] = dr;
-                d_a_d[i * HEADS + h] = dad;
+                s_da[hw][k0][h] = v0;
+                s_da[hw][k0 + 1][h] = v1;
+                s_da[hw][k0 + 2][h] = v2;
+                s_da[hw][k0 + 3][h] = v3;
             }
+        };
+        auto put = [&](int idx, float4 dr) {
+            if (idx < deg) d_raw_e4[beg + idx] = dr;
+            if (idx == deg) d_raw_loop4[i] = dr;
+        };
+        if (deg < 32) {
+            int s;
+            float ea;
+            float4 al, slope;
+            entry(l, s, ea, al, slope);
+            dots(s, 0);
+            for (int k0 = 4; k0 <= deg; k0 += 4) dots(s, k0);
+            __builtin_amdgcn_wave_barrier();
+            float4 da = *reinterpret_cast<const float4*>(&s_da[hw][l][0]);
+            if (l > deg) da = zero4;  // never written for this node
+            __builtin_amdgcn_wave_barrier();
+            const bool wide = deg > 3;
+            const float4 sdot = halfwave_reduce(make_float4(al.x * da.x, al.y * da.y, al.z * da.z, al.w * da.w), wide, SumOp());
+            const float4 dr = make_float4(al.x * (da.x - sdot.x) * slope.x, al.y * (da.y - sdot.y) * slope.y,
+                                          al.z * (da.z - sdot.z) * slope.z, al.w * (da.w - sdot.w) * slope.w);
+            const float4 dad = halfwave_reduce(dr, wide, SumOp());
+            put(l, dr);
+            if (l == 0) d_a_d4[i] = dad;
+            dce.x += dr.x * ea; dce.y += dr.y * ea; dce.z += dr.z * ea; dce.w += dr.w * ea;
+        } else {
+            // long list: chunks of 32 entries, two sweeps (sdot, then d_raw)
+            const int cnt = deg + 1;
+            float4 sdot = zero4;
+            for (int c0 = 0; c0 < cnt; c0 += 32) {
+                int s;
+                float ea;
+                float4 al, slope;
+                entry(c0 + l, s, ea, al, slope);
+                const int lim = min(32, cnt - c0);
+                for (int k0 = 0; k0 < lim; k0 += 4) dots(s, k0);
+                __builtin_amdgcn_wave_barrier();
+                float4 da = *reinterpret_cast<const float4*>(&s_da[hw][l][0]);
+                if (l >= lim) da = zero4;
+                __builtin_amdgcn_wave_barrier();
+                sdot.x += al.x * da.x; sdot.y += al.y * da.y; sdot.z += al.z * da.z; sdot.w += al.w * da.w;
+            }
+            sdot = halfwave_reduce(sdot, true, SumOp());
+            float4 dad = zero4;
+            for (int c0 = 0; c0 < cnt; c0 += 32) {
+                int s;
+                float ea;
+                float4 al, slope;
+                entry(c0 + l, s, ea, al, slope);
+                const int lim = min(32, cnt - c0);
+                for (int k0 = 0; k0 < lim; k0 += 4) dots(s, k0);
+                __builtin_amdgcn_wave_barrier();
+                float4 da = *reinterpret_cast<const float4*>(&s_da[hw][l][0]);
+                if (l >= lim) da = zero4;
+                __builtin_amdgcn_wave_barrier();
+                const float4 dr = make_float4(al.x * (da.x - sdot.x) * slope.x, al.y * (da.y - sdot.y) * slope.y,
+                                              al.z * (da.z - sdot.z) * slope.z, al.w * (da.w - sdot.w) * slope.w);
+                put(c0 + l, dr);
+                dad.x += dr.x; dad.y += dr.y; dad.z += dr.z; dad.w += dr.w;
+                dce.x += dr.x * ea; dce.y += dr.y * ea; dce.z += dr.z * ea; dce.w += dr.w * ea;
+            }
+            dad = halfwave_reduce(dad, true, SumOp());
+            if (l == 0) d_a_d4[i] = dad;
         }
     }
     // block partials, summed over the 8 half-waves in fixed order
+    dce = halfwave_reduce(dce, true, SumOp());
     reinterpret_cast<float4*>(&red[hw][0])[l] = gsum;
-    if ((l & 7) == 0) red[hw][H + h] = dce;
+    if (l == 0) *reinterpret_cast<float4*>(&red[hw][H]) = dce;
     __syncthreads();
     if (threadIdx.x < H + HEADS) {
         float s = 0.f;
@@ -412,29 +510,39 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
 // Source side.  d_xw[j] = sum_{e: src=j} alpha_e g_pre[dst_e] + alpha_loop g_pre[j]
 //                        + d_a_s[j] att_src + d_a_d[j] att_dst,   d_a_s[j] = sum d_raw over out-edges.
 // Fan-out is heavily skewed (a generated graph can hang thousands of gates on one source), so the
-// out-edge lists are cut into segments of SEG edges and a half-wave owns one SEGMENT: a node with a
-// single segment is finished on the spot, a longer list leaves one partial row per segment and is
-// finished by k_gat_bwd_src_heavy, which adds the partials in segment order (reproducible).
+// out-edge lists are cut into segments of SEG edges and a half-wave owns one SEGMENT, described by
+// seg_desc (owner, first and last position in the by-source list, segments of the owner): a node
+// with a single segment is finished on the spot, a longer list leaves one partial row per segment
+// and is finished by k_gat_bwd_src_heavy, which adds the partials in segment order (reproducible).
 struct SrcFinish {
     float4 as4, ad4;
 };
-__device__ __forceinline__ void src_finish(int j, int l, int h, float4 acc, float das, const SrcFinish& f,
-                                           const float4* __restrict__ g4, const float* __restrict__ xw,
-                                           const float* __restrict__ alpha_loop,
-                                           const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d,
+struct SrcNode {  // what finishing node j needs besides the accumulated row
+    float drl, al, dad;
+    float4 gj, xj;
+};
+__device__ __forceinline__ SrcNode src_node_load(int j, int l, int h, const float4* __restrict__ g4,
+                                                 const float* __restrict__ xw, const float* __restrict__ alpha_loop,
+                                                 const float* __restrict__ d_raw_loop,
+                                                 const float* __restrict__ d_a_d) {
+    SrcNode v;
+    v.drl = d_raw_loop[j * HEADS + h];
+    v.al = alpha_loop[j * HEADS + h];
+    v.dad = d_a_d[j * HEADS + h];
+    v.gj = g4[(size_t)j * 32 + l];
+    v.xj = reinterpret_cast<const float4*>(xw + (size_t)j * H)[l];
+    return v;
+}
+__device__ __forceinline__ void src_finish(int j, int l, float4 acc, float das, const SrcFinish& f, const SrcNode& v,
                                            float* __restrict__ d_xw, float4& ps, float4& pd) {
-    das += d_raw_loop[j * HEADS + h];
-    const float al = alpha_loop[j * HEADS + h];
-    const float4 gj = g4[(size_t)j * 32 + l];
-    const float dad = d_a_d[j * HEADS + h];
-    acc.x += al * gj.x + das * f.as4.x + dad * f.ad4.x;
-    acc.y += al * gj.y + das * f.as4.y + dad * f.ad4.y;
-    acc.z += al * gj.z + das * f.as4.z + dad * f.ad4.z;
-    acc.w += al * gj.w + das * f.as4.w + dad * f.ad4.w;
+    das += v.drl;
+    acc.x += v.al * v.gj.x + das * f.as4.x + v.dad * f.ad4.x;
+    acc.y += v.al * v.gj.y + das * f.as4.y + v.dad * f.ad4.y;
+    acc.z += v.al * v.gj.z + das * f.as4.z + v.dad * f.ad4.z;
+    acc.w += v.al * v.gj.w + das * f.as4.w + v.dad * f.ad4.w;
     reinterpret_cast<float4*>(d_xw + (size_t)j * H)[l] = acc;
-    const float4 x = reinterpret_cast<const float4*>(xw + (size_t)j * H)[l];
-    ps.x += das * x.x; ps.y += das * x.y; ps.z += das * x.z; ps.w += das * x.w;
-    pd.x += dad * x.x; pd.y += dad * x.y; pd.z += dad * x.z; pd.w += dad * x.w;
+    ps.x += das * v.xj.x; ps.y += das * v.xj.y; ps.z += das * v.xj.z; ps.w += das * v.xj.w;
+    pd.x += v.dad * v.xj.x; pd.y += v.dad * v.xj.y; pd.z += v.dad * v.xj.z; pd.w += v.dad * v.xj.w;
 }
 
 __device__ __forceinline__ void block_partial_2h(float4 ps, float4 pd, float* __restrict__ partial) {
@@ -448,53 +556,63 @@ __device__ __forceinline__ void block_partial_2h(float4 ps, float4 pd, float* __
     partial[(size_t)blockIdx.x * (2 * H) + threadIdx.x] = s;
 }
 
+__device__ __forceinline__ float pick(float4 v, int h) { return h == 0 ? v.x : h == 1 ? v.y : h == 2 ? v.z : v.w; }
+
 __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
     int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
-    const float* __restrict__ att_dst, const int* __restrict__ col_ptr, const int* __restrict__ seg_base,
+    const float* __restrict__ att_dst, const int* __restrict__ seg_base, const int4* __restrict__ seg_desc,
     const int* __restrict__ csc_pos, const int* __restrict__ csc_dst, const float* __restrict__ alpha_e,
     const float* __restrict__ alpha_loop, const float* __restrict__ d_raw_e, const float* __restrict__ d_raw_loop,
     const float* __restrict__ d_a_d, float* __restrict__ d_xw, float* __restrict__ part_acc /*[nseg][H]*/,
     float* __restrict__ part_das /*[nseg][HEADS]*/, float* __restrict__ partial /*[grid][2H]*/) {
+    __shared__ float s_alpha[HW_PER_BLOCK][32][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
     SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
     const float4* g4 = reinterpret_cast<const float4*>(g_pre);
+    const float4* alpha_e4 = reinterpret_cast<const float4*>(alpha_e);
+    const float4* d_raw_e4 = reinterpret_cast<const float4*>(d_raw_e);
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
+    const float4 zero4 = ps;
     const int nseg = seg_base[n];
     NodeRange r = block_nodes(nseg);   // a contiguous range of segments per block, XCD-grouped
     for (int sgm = r.begin + hw; sgm < r.end; sgm += HW_PER_BLOCK) {
-        // owner of segment sgm: the last node j with seg_base[j] <= sgm
-        int lo = 0, hi = n;
-        while (lo + 1 < hi) {
-            int mid = (lo + hi) >> 1;
-            if (seg_base[mid] <= sgm) lo = mid; else hi = mid;
+        const int4 d = seg_desc[sgm];
+        const int j = d.x, beg = d.y, cnt = d.z - d.y, nsg = d.w;
+        const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
+        // lane k: edge k of the segment (position in the by-target order, target id); a segment
+        // with no edge belongs to a node without out-edges and reads nothing
+        const bool on = l < cnt;
+        const int q = on ? beg + l : 0;
+        int p = 0, dst = j;
+        float4 al = zero4, dr = zero4;
+        if (cnt > 0) {
+            const int pv = csc_pos[q], dv = csc_dst[q];
+            p = on ? pv : 0;
+            dst = on ? dv : j;
+            const float4 alv = alpha_e4[p], drv = d_raw_e4[p];
+            al = on ? alv : zero4;
+            dr = on ? drv : zero4;
         }
-        const int j = lo;
-        const int first = seg_base[j], nsg = seg_base[j + 1] - first;
-        const int beg = col_ptr[j] + (sgm - first) * SEG, end = min(col_ptr[j + 1], beg + SEG);
-        float das = 0.f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int q = beg;
-        for (; q + 2 <= end; q += 2) {
-            int p0 = csc_pos[q], p1 = csc_pos[q + 1];
-            float4 r0 = g4[(size_t)csc_dst[q] * 32 + l], r1 = g4[(size_t)csc_dst[q + 1] * 32 + l];
-            float a0 = alpha_e[(size_t)p0 * HEADS + h], a1 = alpha_e[(size_t)p1 * HEADS + h];
-            das += d_raw_e[(size_t)p0 * HEADS + h];
-            das += d_raw_e[(size_t)p1 * HEADS + h];
-            acc.x += a0 * r0.x; acc.y += a0 * r0.y; acc.z += a0 * r0.z; acc.w += a0 * r0.w;
-            acc.x += a1 * r1.x; acc.y += a1 * r1.y; acc.z += a1 * r1.z; acc.w += a1 * r1.w;
+        *reinterpret_cast<float4*>(&s_alpha[hw][l][0]) = al;
+        __builtin_amdgcn_wave_barrier();
+        float4 acc = zero4;
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            const int t0 = __shfl(dst, k0, 32), t1 = __shfl(dst, k0 + 1, 32), t2 = __shfl(dst, k0 + 2, 32),
+                      t3 = __shfl(dst, k0 + 3, 32);
+            const float4 r0 = g4[(size_t)t0 * 32 + l], r1 = g4[(size_t)t1 * 32 + l], r2 = g4[(size_t)t2 * 32 + l],
+                         r3 = g4[(size_t)t3 * 32 + l];
+            axpy4(acc, s_alpha[hw][k0][h], r0);
+            axpy4(acc, s_alpha[hw][k0 + 1][h], r1);
+            axpy4(acc, s_alpha[hw][k0 + 2][h], r2);
+            axpy4(acc, s_alpha[hw][k0 + 3][h], r3);
         }
-        if (q < end) {
-            int p0 = csc_pos[q];
-            float4 r0 = g4[(size_t)csc_dst[q] * 32 + l];
-            float a0 = alpha_e[(size_t)p0 * HEADS + h];
-            das += d_raw_e[(size_t)p0 * HEADS + h];
-            acc.x += a0 * r0.x; acc.y += a0 * r0.y; acc.z += a0 * r0.z; acc.w += a0 * r0.w;
-        }
+        __builtin_amdgcn_wave_barrier();
+        const float4 das4 = halfwave_reduce(dr, cnt > 4, SumOp());
         if (nsg == 1) {
-            src_finish(j, l, h, acc, das, f, g4, xw, alpha_loop, d_raw_loop, d_a_d, d_xw, ps, pd);
+            src_finish(j, l, acc, pick(das4, h), f, v, d_xw, ps, pd);
         } else {
             reinterpret_cast<float4*>(part_acc + (size_t)sgm * H)[l] = acc;
-            if ((l & 7) == 0) part_das[(size_t)sgm * HEADS + h] = das;
+            if (l == 0) reinterpret_cast<float4*>(part_das)[sgm] = das4;
         }
     }
     block_partial_2h(ps, pd, partial);
@@ -508,29 +626,31 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
     const float* __restrict__ att_dst, const int* __restrict__ seg_base, const float* __restrict__ alpha_loop,
     const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, const float* __restrict__ part_acc,
     const float* __restrict__ part_das, float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
-    constexpr int LIST = 256;
-    __shared__ int s_list[LIST];
-    __shared__ int s_n, s_cursor;
+    __shared__ int s_list[THREADS];
+    __shared__ int s_wcnt[THREADS / 64];
     __shared__ float s_acc[HW_PER_BLOCK][H];
     __shared__ float s_das[HW_PER_BLOCK][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
     const float4* g4 = reinterpret_cast<const float4*>(g_pre);
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
     NodeRange r = block_nodes(n);
-    if (threadIdx.x == 0) s_cursor = r.begin;
-    __syncthreads();
-    while (true) {
-        if (threadIdx.x == 0) {  // next batch of heavy nodes of this block's range, in node order
-            int c = s_cursor, m = 0;
-            for (; c < r.end && m < LIST; ++c)
-                if (seg_base[c + 1] - seg_base[c] > 1) s_list[m++] = c;
-            s_cursor = c;
-            s_n = m;
-        }
+    for (int base = r.begin; base < r.end; base += THREADS) {
+        // heavy nodes among the next THREADS nodes of the block's range, listed in node order
+        const int c = base + threadIdx.x;
+        const bool heavy = c < r.end && seg_base[c + 1] - seg_base[c] > 1;
+        const unsigned long long bal = __ballot(heavy);
+        if (lane == 0) s_wcnt[wv] = __popcll(bal);
         __syncthreads();
-        const int m = s_n;
-        if (m == 0) break;
+        int off = 0, m = 0;
+#pragma unroll
+        for (int k = 0; k < THREADS / 64; ++k) {
+            off += k < wv ? s_wcnt[k] : 0;
+            m += s_wcnt[k];
+        }
+        if (heavy) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+        __syncthreads();
         for (int t = 0; t < m; ++t) {
             const int j = s_list[t];
             const int first = seg_base[j], nsg = seg_base[j + 1] - first;
@@ -560,6 +680,7 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
             if ((l & 7) == 0) s_das[hw][h] = das;
             __syncthreads();
             if (hw == 0) {
+                const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
                 float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
                 float dt = 0.f;
                 for (int q = 0; q < HW_PER_BLOCK; ++q) {
@@ -567,7 +688,7 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
                     tot.x += a.x; tot.y += a.y; tot.z += a.z; tot.w += a.w;
                     dt += s_das[q][h];
                 }
-                src_finish(j, l, h, tot, dt, f, g4, xw, alpha_loop, d_raw_loop, d_a_d, d_xw, ps, pd);
+                src_finish(j, l, tot, dt, f, v, d_xw, ps, pd);
             }
             __syncthreads();
         }
@@ -614,24 +735,40 @@ int grid_blocks(int64_t n) {
 using namespace aig;
 
 extern "C" size_t aig_gat_csr_ws_bytes(int64_t n, int64_t E) {
-    if (E <= 0) return 256;
+    if (E <= 0) return align_up((size_t)(n + 1) * 4) + align_up(scan_temp_bytes(n + 1)) + 256;
     size_t t = sort_temp_bytes(E, key_bits(n)), t2 = scan_temp_bytes(n + 1);
     return 4 * align_up((size_t)E * 4) + align_up((size_t)(n + 1) * 4) + align_up(t > t2 ? t : t2) + 256;
 }
 
 extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_attr,
                            int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
-                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* seg_base, void* ws,
-                           size_t ws_bytes, void* stream) {
+                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* seg_base,
+                           int32_t* seg_desc, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0 && E < INT_MAX, "aig_gat_csr: bad sizes n=%lld E=%lld", (long long)n,
                 (long long)E);
-    AIG_REQUIRE(row_ptr && col_ptr && seg_base && (n == 0 || loop_ea), "aig_gat_csr: null output");
+    AIG_REQUIRE(row_ptr && col_ptr && seg_base && seg_desc && (n == 0 || loop_ea), "aig_gat_csr: null output");
+    const int nseg_cap = (int)(n + E / SEG + 1);
+    int4* desc = reinterpret_cast<int4*>(seg_desc);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (E == 0) {
         AIG_HIP_CHECK(hipMemsetAsync(row_ptr, 0, (size_t)(n + 1) * 4, s));
         AIG_HIP_CHECK(hipMemsetAsync(col_ptr, 0, (size_t)(n + 1) * 4, s));
         if (n) AIG_HIP_CHECK(hipMemsetAsync(loop_ea, 0, (size_t)n * 4, s));
-        AIG_HIP_CHECK(hipMemsetAsync(seg_base, 0, (size_t)(n + 1) * 4, s));  // never used without edges
+        // one empty segment per node
+        hipLaunchKernelGGL(k_seg_count, dim3(grid_for(n + 1, 256, 4096)), dim3(256), 0, s, (int)n, col_ptr, seg_base);
+        AIG_LAUNCH_CHECK();
+        if (n) {
+            Carver c0(ws);
+            AIG_REQUIRE(ws && ws_bytes >= aig_gat_csr_ws_bytes(n, 0), "aig_gat_csr: workspace too small");
+            int* nch0 = c0.take<int>(n + 1);
+            size_t tb0 = scan_temp_bytes(n + 1);
+            void* temp0 = c0.take<char>(tb0);
+            AIG_HIP_CHECK(hipMemcpyAsync(nch0, seg_base, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, s));
+            AIG_HIP_CHECK(rocprim::exclusive_scan(temp0, tb0, nch0, seg_base, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
+            hipLaunchKernelGGL(k_seg_desc, dim3(grid_for(nseg_cap, 256, 4096)), dim3(256), 0, s, (int)n, nseg_cap,
+                               seg_base, col_ptr, desc);
+            AIG_LAUNCH_CHECK();
+        }
         return AIG_OK;
     }
     AIG_REQUIRE(edge_index && csr_src && csr_ea && csr_eid && csc_pos && csc_dst && ws, "aig_gat_csr: null pointer");
@@ -666,6 +803,9 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     hipLaunchKernelGGL(k_seg_count, dim3(gn), dim3(256), 0, s, (int)n, col_ptr, nch);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, nch, seg_base, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_seg_desc, dim3(grid_for(nseg_cap, 256, 4096)), dim3(256), 0, s, (int)n, nseg_cap, seg_base,
+                       col_ptr, desc);
+    AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 
@@ -704,7 +844,8 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
                            const float* att_src, const float* att_dst, const float* ce, const float* a_s,
                            const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
                            const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
-                           const int32_t* csc_dst, const int32_t* seg_base, const float* alpha_e,
+                           const int32_t* csc_dst, const int32_t* seg_base, const int32_t* seg_desc,
+                           const float* alpha_e,
                            const float* alpha_loop, float* d_xw,
                            float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, void* ws,
                            size_t ws_bytes, void* stream) {
@@ -719,7 +860,7 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
         return AIG_OK;
     }
     AIG_REQUIRE(g_out && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
-                    seg_base && alpha_loop && d_xw && ws,
+                    seg_base && seg_desc && alpha_loop && d_xw && ws,
                 "aig_gat_bwd: null pointer");
     if (ws_bytes < aig_gat_bwd_ws_bytes(n, E))
         return fail(AIG_EWORKSPACE, "aig_gat_bwd: workspace %zu < %zu", ws_bytes, aig_gat_bwd_ws_bytes(n, E));
@@ -741,9 +882,9 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     AIG_HIP_CHECK(hipMemcpyAsync(d_bias, partial + (size_t)g * (H + HEADS), H * 4, hipMemcpyDeviceToDevice, s));
     AIG_HIP_CHECK(hipMemcpyAsync(d_ce, partial + (size_t)g * (H + HEADS) + H, HEADS * 4, hipMemcpyDeviceToDevice, s));
     const int gs = grid_blocks((int64_t)nseg_max);
-    hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, col_ptr,
-                       seg_base, csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw, part_acc,
-                       part_das, partial);
+    hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
+                       reinterpret_cast<const int4*>(seg_desc), csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e,
+                       d_raw_loop, d_a_d, d_xw, part_acc, part_das, partial);
     hipLaunchKernelGGL(k_gat_bwd_src_heavy, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
                        alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();

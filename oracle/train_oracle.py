@@ -68,7 +68,7 @@ class CpuTrainer:
             pen = pen * scale
         loss_g = loss_adv + self.lambda_cons * pen
         loss_g.backward()      # reaches only the critic's parameters, as in the reference
-        m.update(loss_G=float(loss_g), pen=float(pen))
+        m.update(loss_G=float(loss_g.detach()), pen=float(pen.detach()))
         ei_r, _ = _sanitize(real_padded)
         ei_f, _ = _sanitize(fake_padded)
         m["edges"] = int(ei_r.size(1) + ei_f.size(1))
