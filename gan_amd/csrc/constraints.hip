@@ -185,6 +185,155 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs)
     if (tid == 0 && popped) *popped = s_total;
 }
 
+// ------------------------------------------------------------------------------------------ traversal, LDS-resident
+// The same walks with the per-level latency cut to about one global round trip: a level of an AIG
+// holds a few hundred nodes, so a level-synchronous walk is a chain of dependent memory accesses
+// and nothing else.  Here
+//   - the frontier queues live in LDS (entries beyond TRAV_QCAP spill to the global queues),
+//   - MODE 0 keeps its visited set as a bitmap in LDS (test-and-set there; depth[] is only stored),
+//   - the adjacency header of a node and its first two neighbours come in one 16-byte record,
+//   - one barrier per level (three rotating counters), a second one only on levels that expand
+//     a heavy node.
+// Used while the bitmap fits (n <= TRAV_LDS_MAX_N); larger graphs take k_traverse.
+constexpr int TRAV_QCAP = 3072;
+constexpr int TRAV_LDS_MAX_N = 1 << 20;
+constexpr int TRAV_HEAVY_CAP = 1024;  // heavy nodes remembered per level (the rest are expanded in place)
+
+// {first, one past last, neighbour 0, neighbour 1} of every node's adjacency list
+__global__ void k_node_rec(int n, const int* __restrict__ ptr, const int* __restrict__ adj, int4* __restrict__ rec) {
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+        const int b = ptr[u], e = ptr[u + 1];
+        rec[u] = make_int4(b, e, b < e ? adj[b] : -1, b + 1 < e ? adj[b + 1] : -1);
+    }
+}
+
+struct TravLds {
+    unsigned* bits;  // MODE 0 only
+    int* lq[2];
+    int* gq[2];
+    int* cnt;  // three rotating frontier sizes
+};
+
+template <int MODE>
+__device__ __forceinline__ void visit_lds(int v, int level, const TravLds& t, int nx, int ncnt, int* __restrict__ state,
+                                          int* __restrict__ depth) {
+    if (MODE == 0) {
+        const unsigned m = 1u << (v & 31);
+        if (t.bits[v >> 5] & m) return;  // peek: a popular node is claimed once and then only read
+        if (atomicOr(&t.bits[v >> 5], m) & m) return;
+    } else {
+        if (atomicSub(&state[v], 1) != 1) return;
+    }
+    depth[v] = level + 1;
+    const int idx = atomicAdd(&t.cnt[ncnt], 1);
+    if (idx < TRAV_QCAP) t.lq[nx][idx] = v; else t.gq[nx][idx - TRAV_QCAP] = v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs jobs, const int4* __restrict__ rec0,
+                                                               const int4* __restrict__ rec1) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const TravJob jb = jobs.j[blockIdx.x];
+    const int4* __restrict__ rec = blockIdx.x ? rec1 : rec0;
+    const int* __restrict__ adj = jb.adj;
+    int* __restrict__ state = jb.state;
+    int* __restrict__ depth = jb.depth;
+    __shared__ int s_cnt[3];
+    __shared__ int s_total;
+    __shared__ int s_nheavy[2];
+    __shared__ int s_heavy[TRAV_HEAVY_CAP];
+    const int tid = threadIdx.x;
+    const int nwords = MODE == 0 ? (n + 31) >> 5 : 0;
+    TravLds t;
+    t.bits = reinterpret_cast<unsigned*>(smem);
+    t.lq[0] = smem + nwords;
+    t.lq[1] = t.lq[0] + TRAV_QCAP;
+    t.gq[0] = jb.q0;
+    t.gq[1] = jb.q1;
+    t.cnt = s_cnt;
+    if (tid == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; s_total = 0; s_nheavy[0] = s_nheavy[1] = 0; }
+    for (int w = tid; w < nwords; w += TRAV_THREADS) t.bits[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += TRAV_THREADS) {
+        bool start;
+        if (MODE == 0) start = depth[i] == 0;
+        else { start = state[i] == 0; depth[i] = 0; }
+        if (start) {
+            if (MODE == 0) atomicOr(&t.bits[i >> 5], 1u << (i & 31));
+            const int idx = atomicAdd(&s_cnt[0], 1);
+            if (idx < TRAV_QCAP) t.lq[0][idx] = i; else t.gq[0][idx - TRAV_QCAP] = i;
+        }
+    }
+    // level L reads queue L&1 / counter L%3, fills queue (L+1)&1 / counter (L+1)%3, and clears
+    // counter (L+2)%3, which nobody touches during L.  Every wave leaves through the same `break`.
+    for (int level = 0; level <= n; ++level) {
+        const int cur = level & 1, nx = cur ^ 1, ccnt = level % 3, ncnt = (level + 1) % 3;
+        __syncthreads();
+        // heavy nodes set aside by the previous level: their neighbours belong to THIS frontier
+        const int nh = min(s_nheavy[cur], TRAV_HEAVY_CAP);
+        if (nh > 0) {
+            for (int hidx = 0; hidx < nh; ++hidx) {
+                const int u = s_heavy[hidx];
+                const int4 r = rec[u];
+                for (int k = r.x + tid; k < r.y; k += TRAV_THREADS)
+                    visit_lds<MODE>(adj[k], level - 1, t, cur, ccnt, state, depth);
+            }
+            __syncthreads();
+        }
+        const int c = s_cnt[ccnt];
+        if (c == 0) break;
+        if (tid == 0) { s_cnt[(level + 2) % 3] = 0; s_total += c; s_nheavy[cur] = 0; }
+        // (s_nheavy[cur] was read above by everyone before this point only if nh > 0 took the
+        //  barrier; otherwise the value read was 0 and resetting it to 0 changes nothing)
+        for (int idx = tid; idx < c; idx += TRAV_THREADS) {
+            const int u = idx < TRAV_QCAP ? t.lq[cur][idx] : t.gq[cur][idx - TRAV_QCAP];
+            const int4 r = rec[u];
+            const int deg = r.y - r.x;
+            if (deg > HEAVY_DEG) {
+                const int slot = atomicAdd(&s_nheavy[nx], 1);
+                if (slot < TRAV_HEAVY_CAP) { s_heavy[slot] = u; continue; }
+            }
+            if (deg > 0) visit_lds<MODE>(r.z, level, t, nx, ncnt, state, depth);
+            if (deg > 1) visit_lds<MODE>(r.w, level, t, nx, ncnt, state, depth);
+            for (int k = r.x + 2; k < r.y; k += 4) {  // four neighbours fetched before any is visited
+                const int k1 = min(k + 1, r.y - 1), k2 = min(k + 2, r.y - 1), k3 = min(k + 3, r.y - 1);
+                const int v0 = adj[k], v1 = adj[k1], v2 = adj[k2], v3 = adj[k3];
+                visit_lds<MODE>(v0, level, t, nx, ncnt, state, depth);
+                if (k + 1 < r.y) visit_lds<MODE>(v1, level, t, nx, ncnt, state, depth);
+                if (k + 2 < r.y) visit_lds<MODE>(v2, level, t, nx, ncnt, state, depth);
+                if (k + 3 < r.y) visit_lds<MODE>(v3, level, t, nx, ncnt, state, depth);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && jb.popped) *jb.popped = s_total;
+}
+
+
+// rec0 / rec1: one 16-byte record per node for job 0 / job 1 (workspace of n entries each)
+template <int MODE>
+int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* rec0, int4* rec1) {
+    if (N > TRAV_LDS_MAX_N) {
+        hipLaunchKernelGGL(k_traverse<MODE>, dim3(njobs), dim3(TRAV_THREADS), 0, s, N, jobs);
+        AIG_LAUNCH_CHECK();
+        return AIG_OK;
+    }
+    static bool attr_set = false;  // idempotent; racing threads set the same value
+    if (!attr_set) {
+        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<MODE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (TRAV_LDS_MAX_N / 8) + 2 * TRAV_QCAP * 4));
+        attr_set = true;
+    }
+    const int g = (N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096;
+    hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[0].ptr, jobs.j[0].adj, rec0);
+    if (njobs > 1) hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[1].ptr, jobs.j[1].adj, rec1);
+    const size_t lds = (MODE == 0 ? (size_t)((N + 31) >> 5) * 4 : 0) + (size_t)2 * TRAV_QCAP * 4;
+    hipLaunchKernelGGL(k_traverse_lds<MODE>, dim3(njobs), dim3(TRAV_THREADS), lds, s, N, jobs, rec0, rec1);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
 // adjacency in sorted order: adj[p] = other endpoint of edge sid[p]
 __global__ void k_gather_adj(int m, const int* __restrict__ sid, const long long* __restrict__ endpoint,
                              int* __restrict__ adj) {
@@ -473,7 +622,7 @@ extern "C" size_t aig_enforce_ws_bytes(int64_t n, int64_t E) {
     size_t tmax = t64 > t32 ? t64 : t32;
     tmax = tmax > ts ? tmax : ts;
     return 2 * align_up((N + 1) * sizeof(Cnt4)) + 6 * align_up((N + 2) * 4) + align_up(N * sizeof(Pick)) +
-           2 * align_up(M * 8) + 5 * align_up(M * 4) + align_up(M * 8) + align_up(tmax) + 1024;
+           2 * align_up(M * 8) + 5 * align_up(M * 4) + align_up(M * 8) + align_up((N + 2) * 16) + align_up(tmax) + 1024;
 }
 
 extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
@@ -510,6 +659,7 @@ extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* 
     int* adj = c.take<int>(M);
     long long* minv = c.take<long long>(M);
     int* small = c.take<int>(64);
+    int4* rec = c.take<int4>(N + 2);
     const int kb = bits_for((unsigned long long)n * (unsigned long long)n + (unsigned long long)n);
     size_t t64 = sort_temp<unsigned long long>(E, kb), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
     size_t tb = t64 > t32 ? t64 : t32;
@@ -544,7 +694,7 @@ extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* 
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, nullptr, depth32, q0, q1, nullptr};
-    hipLaunchKernelGGL(k_traverse<0>, dim3(1), dim3(TRAV_THREADS), 0, s, N, jobs);
+    if ((rc = run_traverse<0>(s, N, jobs, 1, rec, nullptr))) return rc;
     hipLaunchKernelGGL(k_widen_i32_i64, dim3(g256(N)), dim3(256), 0, s, N, depth32, reinterpret_cast<long long*>(node_depth));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -558,7 +708,7 @@ static size_t graph_checks_ws_bytes(int64_t n, int64_t E) {
     size_t tmax = t64 > t32 ? t64 : t32;
     tmax = tmax > ts ? tmax : ts;
     return 2 * align_up((N + 1) * sizeof(Cnt4)) + 12 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
-           8 * align_up(M * 4) + align_up(tmax) + 2048;
+           8 * align_up(M * 4) + 2 * align_up((N + 2) * 16) + align_up(tmax) + 2048;
 }
 
 // shared body: counters (penalties) and/or flags (validator)
@@ -599,6 +749,8 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
     int* dadj = c.take<int>(M);
     int* q1 = qx;                                  // second queue (n entries)
     int* counters = c.take<int>(64);               // [0..7] counts, [8] Kahn popped
+    int4* rec0 = c.take<int4>(N + 2);
+    int4* rec1 = c.take<int4>(N + 2);
     const int kb = bits_for((unsigned long long)n * (unsigned long long)n + (unsigned long long)n);
     size_t t64 = sort_temp<unsigned long long>(E, kb), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
     size_t tb = t64 > t32 ? t64 : t32;
@@ -625,7 +777,7 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
     TravJobs jobs{};  // the two reachability walks are independent: one launch, one block each
     jobs.j[0] = TravJob{sptr, sadj, nullptr, fwd, q0, q1, nullptr};
     jobs.j[1] = TravJob{dptr, dadj, nullptr, rev, q2, q3, nullptr};
-    hipLaunchKernelGGL(k_traverse<0>, dim3(2), dim3(TRAV_THREADS), 0, s, N, jobs);
+    if ((rc = run_traverse<0>(s, N, jobs, 2, rec0, rec1))) return rc;
     hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, fwd, rev, counters, on_path);
     AIG_LAUNCH_CHECK();
     if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3(1), dim3(1), 0, s, counters, pen_out);
@@ -635,7 +787,7 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
         if (indeg_out) AIG_HIP_CHECK(hipMemcpyAsync(indeg_out, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
         TravJobs kj{};
         kj.j[0] = TravJob{sptr, sadj, kdeg, kdepth, q0, q1, counters + 8};
-        hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, kj);
+        if ((rc = run_traverse<1>(s, N, kj, 1, rec0, nullptr))) return rc;
         hipLaunchKernelGGL(k_val_summary, dim3(1), dim3(1), 0, s, N, counters + 8, counters, summary);
     }
     AIG_LAUNCH_CHECK();
@@ -664,7 +816,7 @@ extern "C" int aig_validate(int64_t n, int64_t E, const float* x, const int64_t*
 // ============================================================================================ resync
 extern "C" size_t aig_resync_ws_bytes(int64_t n, int64_t E) {
     size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
-    return 7 * align_up((N + 2) * 4) + 5 * align_up(M * 4) + align_up(sort_temp<unsigned>(E, 32)) + 1024;
+    return 7 * align_up((N + 2) * 4) + 5 * align_up(M * 4) + align_up((N + 2) * 16) + align_up(sort_temp<unsigned>(E, 32)) + 1024;
 }
 
 extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
@@ -687,6 +839,7 @@ extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const
     int* ids = c.take<int>(M);
     int* sid = c.take<int>(M);
     int* adj = c.take<int>(M);
+    int4* rec = c.take<int4>(N + 2);
     size_t tb = sort_temp<unsigned>(E, 32);
     void* temp = c.take<char>(tb);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
@@ -699,7 +852,7 @@ extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const
     if (rc) return rc;
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, popped};
-    hipLaunchKernelGGL(k_traverse<1>, dim3(1), dim3(TRAV_THREADS), 0, s, N, jobs);
+    if ((rc = run_traverse<1>(s, N, jobs, 1, rec, nullptr))) return rc;
     hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, N, popped, d32, icnt,
                        reinterpret_cast<long long*>(depth), reinterpret_cast<long long*>(inv_cnt));
     AIG_LAUNCH_CHECK();
