@@ -192,12 +192,14 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs)
 //   - the frontier queues live in LDS (entries beyond TRAV_QCAP spill to the global queues),
 //   - MODE 0 keeps its visited set as a bitmap in LDS (test-and-set there; depth[] is only stored),
 //   - the adjacency header of a node and its first two neighbours come in one 16-byte record,
-//   - one barrier per level (three rotating counters), a second one only on levels that expand
-//     a heavy node.
+//   - two barriers per level (three rotating counters): frontier nodes take the two neighbours
+//     that came with their record, longer lists are set aside and walked by a wave or the block,
+//   - depth[] is written by a wave of its own, so that no expanding wave waits behind stores.
 // Used while the bitmap fits (n <= TRAV_LDS_MAX_N); larger graphs take k_traverse.
-constexpr int TRAV_QCAP = 3072;
+constexpr int TRAV_QCAP = 2048;
 constexpr int TRAV_LDS_MAX_N = 1 << 20;
-constexpr int TRAV_HEAVY_CAP = 1024;  // heavy nodes remembered per level (the rest are expanded in place)
+constexpr int TRAV_BIG_CAP = 960;   // adjacency lists set aside per level for a wave each
+constexpr int TRAV_HEAVY_CAP = 32;  // ... and for the whole block (beyond either: walked in place)
 
 // {first, one past last, neighbour 0, neighbour 1} of every node's adjacency list
 __global__ void k_node_rec(int n, const int* __restrict__ ptr, const int* __restrict__ adj, int4* __restrict__ rec) {
@@ -209,14 +211,30 @@ __global__ void k_node_rec(int n, const int* __restrict__ ptr, const int* __rest
 
 struct TravLds {
     unsigned* bits;  // MODE 0 only
-    int* lq[2];
-    int* gq[2];
-    int* cnt;  // three rotating frontier sizes
+    unsigned* dummy; // 64 scratch words
+    int* lq;         // two LDS queues of TRAV_QCAP entries, back to back
+    int* gq0;        // their global spill areas
+    int* gq1;
+    int* cnt;        // three rotating frontier sizes
 };
+// queue `which`, entry idx.  Written as explicit LDS / global branches: a pointer picked at run time
+// between the two memories turns every access into a flat instruction, and those make the
+// compiler drain all outstanding stores before each one.
+__device__ __forceinline__ void q_put(const TravLds& t, int which, int idx, int v) {
+    if (idx < TRAV_QCAP) t.lq[which * TRAV_QCAP + idx] = v;
+    else if (which) t.gq1[idx - TRAV_QCAP] = v;
+    else t.gq0[idx - TRAV_QCAP] = v;
+}
+__device__ __forceinline__ int q_get(const TravLds& t, int which, int idx) {
+    if (idx < TRAV_QCAP) return t.lq[which * TRAV_QCAP + idx];
+    return which ? t.gq1[idx - TRAV_QCAP] : t.gq0[idx - TRAV_QCAP];
+}
 
+// Claims v for the next frontier.  No global store here: in-order completion counting would make
+// the next level's record load wait for this level's scattered depth stores (measured: +1400
+// cycles per level); depth[] is written by a wave of its own, see k_traverse_lds.
 template <int MODE>
-__device__ __forceinline__ void visit_lds(int v, int level, const TravLds& t, int nx, int ncnt, int* __restrict__ state,
-                                          int* __restrict__ depth) {
+__device__ __forceinline__ void visit_lds(int v, const TravLds& t, int nx, int ncnt, int* __restrict__ state) {
     if (MODE == 0) {
         const unsigned m = 1u << (v & 31);
         if (t.bits[v >> 5] & m) return;  // peek: a popular node is claimed once and then only read
@@ -224,9 +242,42 @@ __device__ __forceinline__ void visit_lds(int v, int level, const TravLds& t, in
     } else {
         if (atomicSub(&state[v], 1) != 1) return;
     }
-    depth[v] = level + 1;
-    const int idx = atomicAdd(&t.cnt[ncnt], 1);
-    if (idx < TRAV_QCAP) t.lq[nx][idx] = v; else t.gq[nx][idx - TRAV_QCAP] = v;
+    q_put(t, nx, atomicAdd(&t.cnt[ncnt], 1), v);
+}
+
+// The two neighbours that come with a node's record, claimed side by side: both bitmap reads, then
+// both test-and-sets, are in flight together, and one counter update covers the pair.  An absent
+// neighbour (on == false) goes through the same instructions with an empty mask.
+template <int MODE>
+__device__ __forceinline__ void visit2_lds(int self, int v0, bool on0, int v1, bool on1, const TravLds& t, int nx,
+                                           int ncnt, int* __restrict__ state) {
+    bool c0, c1;
+    if (MODE == 0) {
+        // (an absent neighbour aims at a per-lane dummy word: same-address atomics are served one
+        //  lane at a time, a shared dummy would serialise the idle lanes of every wave)
+        unsigned* const dummy = t.dummy + (threadIdx.x & 63);
+        unsigned* const q0 = on0 ? &t.bits[v0 >> 5] : dummy;
+        unsigned* const q1 = on1 ? &t.bits[v1 >> 5] : dummy;
+        const unsigned m0 = on0 ? 1u << (v0 & 31) : 0u, m1 = on1 && v1 != v0 ? 1u << (v1 & 31) : 0u;
+        const unsigned p0 = *q0, p1 = *q1;
+        const unsigned a0 = m0 & ~p0, a1 = m1 & ~p1;  // still unclaimed at the peek
+        const unsigned o0 = atomicOr(q0, a0), o1 = atomicOr(q1, a1);
+        c0 = (a0 & ~o0) != 0u;
+        c1 = (a1 & ~o1) != 0u;
+    } else {
+        // both counter updates in flight together; an absent neighbour subtracts 0 from the
+        // expanding node's own (already released) counter, a distinct address per lane
+        const int o0 = atomicSub(&state[on0 ? v0 : self], on0 ? 1 : 0);
+        const int o1 = atomicSub(&state[on1 ? v1 : self], on1 ? 1 : 0);
+        c0 = on0 && o0 == 1;
+        c1 = on1 && o1 == 1;
+    }
+    const int k = (int)c0 + (int)c1;
+    if (k) {
+        const int base = atomicAdd(&t.cnt[ncnt], k);
+        if (c0) q_put(t, nx, base, v0);
+        if (c1) q_put(t, nx, base + (int)c0, v1);
+    }
 }
 
 template <int MODE>
@@ -240,18 +291,19 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
     int* __restrict__ depth = jb.depth;
     __shared__ int s_cnt[3];
     __shared__ int s_total;
-    __shared__ int s_nheavy[2];
-    __shared__ int s_heavy[TRAV_HEAVY_CAP];
+    __shared__ int s_nbig[2], s_nheavy[2];
+    __shared__ int2 s_big[TRAV_BIG_CAP], s_heavy[TRAV_HEAVY_CAP];
+    __shared__ unsigned s_dummy[64];
     const int tid = threadIdx.x;
     const int nwords = MODE == 0 ? (n + 31) >> 5 : 0;
     TravLds t;
     t.bits = reinterpret_cast<unsigned*>(smem);
-    t.lq[0] = smem + nwords;
-    t.lq[1] = t.lq[0] + TRAV_QCAP;
-    t.gq[0] = jb.q0;
-    t.gq[1] = jb.q1;
+    t.dummy = s_dummy;
+    t.lq = smem + nwords;
+    t.gq0 = jb.q0;
+    t.gq1 = jb.q1;
     t.cnt = s_cnt;
-    if (tid == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; s_total = 0; s_nheavy[0] = s_nheavy[1] = 0; }
+    if (tid == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; s_total = 0; s_nbig[0] = s_nbig[1] = 0; s_nheavy[0] = s_nheavy[1] = 0; }
     for (int w = tid; w < nwords; w += TRAV_THREADS) t.bits[w] = 0u;
     __syncthreads();
     for (int i = tid; i < n; i += TRAV_THREADS) {
@@ -260,55 +312,62 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
         else { start = state[i] == 0; depth[i] = 0; }
         if (start) {
             if (MODE == 0) atomicOr(&t.bits[i >> 5], 1u << (i & 31));
-            const int idx = atomicAdd(&s_cnt[0], 1);
-            if (idx < TRAV_QCAP) t.lq[0][idx] = i; else t.gq[0][idx - TRAV_QCAP] = i;
+            q_put(t, 0, atomicAdd(&s_cnt[0], 1), i);
         }
     }
+    // The last wave only writes depth[] (level of every node of the current frontier) and never
+    // waits for those stores; the other waves expand the frontier and never store.
+    constexpr int EXPANDERS = TRAV_THREADS - 64;
+    const bool writer = tid >= EXPANDERS;
+    const int lane = tid & 63, wave = tid >> 6;
     // level L reads queue L&1 / counter L%3, fills queue (L+1)&1 / counter (L+1)%3, and clears
-    // counter (L+2)%3, which nobody touches during L.  Every wave leaves through the same `break`.
+    // counter (L+2)%3 and the list sizes of parity (L+1)&1, which nobody touches during L.
+    // Every wave leaves through the same `break`.
+    constexpr int XWAVES = EXPANDERS / 64;
     for (int level = 0; level <= n; ++level) {
         const int cur = level & 1, nx = cur ^ 1, ccnt = level % 3, ncnt = (level + 1) % 3;
         __syncthreads();
-        // heavy nodes set aside by the previous level: their neighbours belong to THIS frontier
-        const int nh = min(s_nheavy[cur], TRAV_HEAVY_CAP);
-        if (nh > 0) {
-            for (int hidx = 0; hidx < nh; ++hidx) {
-                const int u = s_heavy[hidx];
-                const int4 r = rec[u];
-                for (int k = r.x + tid; k < r.y; k += TRAV_THREADS)
-                    visit_lds<MODE>(adj[k], level - 1, t, cur, ccnt, state, depth);
-            }
-            __syncthreads();
-        }
         const int c = s_cnt[ccnt];
         if (c == 0) break;
-        if (tid == 0) { s_cnt[(level + 2) % 3] = 0; s_total += c; s_nheavy[cur] = 0; }
-        // (s_nheavy[cur] was read above by everyone before this point only if nh > 0 took the
-        //  barrier; otherwise the value read was 0 and resetting it to 0 changes nothing)
-        for (int idx = tid; idx < c; idx += TRAV_THREADS) {
-            const int u = idx < TRAV_QCAP ? t.lq[cur][idx] : t.gq[cur][idx - TRAV_QCAP];
-            const int4 r = rec[u];
-            const int deg = r.y - r.x;
-            if (deg > HEAVY_DEG) {
-                const int slot = atomicAdd(&s_nheavy[nx], 1);
-                if (slot < TRAV_HEAVY_CAP) { s_heavy[slot] = u; continue; }
+        if (tid == 0) { s_cnt[(level + 2) % 3] = 0; s_total += c; s_nbig[nx] = 0; s_nheavy[nx] = 0; }
+        // phase A: one thread per frontier node takes the two neighbours that came with the record;
+        // a longer list is set aside so that a wave (or, when very long, the block) walks it
+        if (writer) {
+            for (int idx = lane; idx < c; idx += 64) depth[q_get(t, cur, idx)] = level;
+        } else {
+            for (int idx = tid; idx < c; idx += EXPANDERS) {
+                const int u = q_get(t, cur, idx);
+                const int4 r = rec[u];
+                const int deg = r.y - r.x;
+                visit2_lds<MODE>(u, r.z, deg > 0, r.w, deg > 1, t, nx, ncnt, state);
+                if (deg > 2) {
+                    const bool heavy = deg - 2 > HEAVY_DEG;
+                    const int slot = atomicAdd(heavy ? &s_nheavy[cur] : &s_nbig[cur], 1);
+                    if (slot < (heavy ? TRAV_HEAVY_CAP : TRAV_BIG_CAP)) {
+                        (heavy ? s_heavy : s_big)[slot] = make_int2(r.x + 2, r.y);
+                    } else {  // list full: walk it here
+                        for (int k = r.x + 2; k < r.y; ++k) visit_lds<MODE>(adj[k], t, nx, ncnt, state);
+                    }
+                }
             }
-            if (deg > 0) visit_lds<MODE>(r.z, level, t, nx, ncnt, state, depth);
-            if (deg > 1) visit_lds<MODE>(r.w, level, t, nx, ncnt, state, depth);
-            for (int k = r.x + 2; k < r.y; k += 4) {  // four neighbours fetched before any is visited
-                const int k1 = min(k + 1, r.y - 1), k2 = min(k + 2, r.y - 1), k3 = min(k + 3, r.y - 1);
-                const int v0 = adj[k], v1 = adj[k1], v2 = adj[k2], v3 = adj[k3];
-                visit_lds<MODE>(v0, level, t, nx, ncnt, state, depth);
-                if (k + 1 < r.y) visit_lds<MODE>(v1, level, t, nx, ncnt, state, depth);
-                if (k + 2 < r.y) visit_lds<MODE>(v2, level, t, nx, ncnt, state, depth);
-                if (k + 3 < r.y) visit_lds<MODE>(v3, level, t, nx, ncnt, state, depth);
+        }
+        __syncthreads();
+        // phase B
+        const int nb = min(s_nbig[cur], TRAV_BIG_CAP), nh = min(s_nheavy[cur], TRAV_HEAVY_CAP);
+        if (!writer) {
+            for (int i = wave; i < nb; i += XWAVES) {
+                const int2 be = s_big[i];
+                for (int k = be.x + lane; k < be.y; k += 64) visit_lds<MODE>(adj[k], t, nx, ncnt, state);
+            }
+            for (int i = 0; i < nh; ++i) {
+                const int2 be = s_heavy[i];
+                for (int k = be.x + tid; k < be.y; k += EXPANDERS) visit_lds<MODE>(adj[k], t, nx, ncnt, state);
             }
         }
     }
     __syncthreads();
     if (tid == 0 && jb.popped) *jb.popped = s_total;
 }
-
 
 // rec0 / rec1: one 16-byte record per node for job 0 / job 1 (workspace of n entries each)
 template <int MODE>
