@@ -22,6 +22,7 @@ struct Chunk {          // one 128-column slice of the output
     const float* bias;  // [128] or nullptr
     float* out;         // [M][128]
     int ldw;
+    int wt;             // 1: w is stored [in][out] (ldw = row length of that layout)
 };
 struct ChunkSet {
     Chunk c[4];
@@ -44,83 +45,132 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
 
 // Y[:, chunk] = act(X W_chunk^T + bias_chunk) for a persistent grid of row tiles.
 // FROM_X2: the input tile is relu(enc0(x)) computed on the fly from the [M,2] features.
+//
+// LDS: the weight slice (padded rows) stays for the life of the block; input tiles of BM rows are
+// double-buffered.  A plain input tile goes global -> LDS by direct 16-byte loads (no register
+// stop), one wave instruction per pair of 512-byte rows, so its image cannot be padded; instead
+// the 16-byte chunk c of row r is kept at position c ^ (r & 15) (the permutation is applied to the
+// global address of each lane), which spreads the matrix-core fragment reads - 32 rows, one chunk
+// each - over all banks.  Rows past M read row M-1 and are never stored.
+__device__ __forceinline__ void load_to_lds16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 template <bool RELU, bool FROM_X2>
 __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __restrict__ X,
                                                        const float* __restrict__ enc_w,
                                                        const float* __restrict__ enc_b, ChunkSet cs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                       // [128][LDS_LD]
-    float* Xl = lds + H * LDS_LD;          // [2][BM][LDS_LD]
+    float* Xl = lds + H * LDS_LD;          // [2][BM][H], chunks permuted within a row
     const Chunk ck = cs.c[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = (M + BM - 1) / BM;
 
-    // stage the weight slice once: 128 rows x 32 float4
+    // stage the weight slice once: 128 rows x 32 float4 (row = output column)
+    if (ck.wt) {  // the slice is stored [in][out]: transpose while staging
+        for (int idx = tid; idx < H * H; idx += THREADS) {
+            const int k = idx >> 7, j = idx & (H - 1);
+            Wl[j * LDS_LD + k] = ck.w[static_cast<size_t>(k) * ck.ldw + j];
+        }
+    } else {
 #pragma unroll
-    for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
-        int idx = q * THREADS + tid, row = idx >> 5, c4 = idx & 31;
-        float4 v = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(row) * ck.ldw + c4 * 4);
-        *reinterpret_cast<float4*>(Wl + row * LDS_LD + c4 * 4) = v;
+        for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
+            int idx = q * THREADS + tid, row = idx >> 5, c4 = idx & 31;
+            float4 v = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(row) * ck.ldw + c4 * 4);
+            *reinterpret_cast<float4*>(Wl + row * LDS_LD + c4 * 4) = v;
+        }
     }
 
-    float4 stage[(BM * H / 4) / THREADS];  // 8 float4 per thread = one tile
-    auto load_tile = [&](int tile) {
+    // plain input: wave w, instruction q fills tile rows 2(4q+w) and 2(4q+w)+1
+    auto fetch = [&](int tile, int buf) {
 #pragma unroll
-        for (int q = 0; q < (BM * H / 4) / THREADS; ++q) {
-            int idx = q * THREADS + tid, row = idx >> 5, c4 = idx & 31;
-            int gr = tile * BM + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr < M) {
-                if constexpr (FROM_X2) {
-                    float2 xi = *reinterpret_cast<const float2*>(X + static_cast<size_t>(gr) * 2);
-                    float o[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int j = c4 * 4 + u;
-                        float s = fmaf(xi.y, enc_w[2 * j + 1], xi.x * enc_w[2 * j]) + enc_b[j];
-                        o[u] = fmaxf(s, 0.f);
-                    }
-                    v = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    v = *reinterpret_cast<const float4*>(X + static_cast<size_t>(gr) * H + c4 * 4);
-                }
-            }
-            stage[q] = v;
+        for (int q = 0; q < BM / 8; ++q) {
+            const int pr = 2 * (4 * q + wave);
+            const int row = pr + (lane >> 5);
+            const int gr = min(tile * BM + row, M - 1);
+            const int c4 = (lane & 31) ^ (row & 15);
+            load_to_lds16(X + static_cast<size_t>(gr) * H + 4 * c4, Xl + (buf * BM + pr) * H);
         }
     };
-    auto store_tile = [&](int buf) {
+    // FROM_X2: raw features of 8 rows per thread, encoded when they are written to LDS
+    float2 xs[BM / 8];
+    auto fetch_x2 = [&](int tile) {
 #pragma unroll
-        for (int q = 0; q < (BM * H / 4) / THREADS; ++q) {
-            int idx = q * THREADS + tid, row = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<float4*>(Xl + (buf * BM + row) * LDS_LD + c4 * 4) = stage[q];
+        for (int q = 0; q < BM / 8; ++q) {
+            const int gr = min(tile * BM + q * 8 + (tid >> 5), M - 1);
+            xs[q] = *reinterpret_cast<const float2*>(X + static_cast<size_t>(gr) * 2);
+        }
+    };
+    auto stash_x2 = [&](int buf) {
+        const int c4 = tid & 31;
+        float w0[4], w1[4], bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w0[u] = enc_w[2 * (c4 * 4 + u)];
+            w1[u] = enc_w[2 * (c4 * 4 + u) + 1];
+            bb[u] = enc_b[c4 * 4 + u];
+        }
+#pragma unroll
+        for (int q = 0; q < BM / 8; ++q) {
+            const int row = q * 8 + (tid >> 5);
+            float o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaf(xs[q].y, w1[u], xs[q].x * w0[u]) + bb[u], 0.f);
+            *reinterpret_cast<float4*>(Xl + (buf * BM + row) * H + 4 * (c4 ^ (row & 15))) =
+                make_float4(o[0], o[1], o[2], o[3]);
         }
     };
 
     int tile = blockIdx.x;
     if (tile < ntiles) {
-        load_tile(tile);
-        store_tile(0);
+        if constexpr (FROM_X2) {
+            fetch_x2(tile);
+            stash_x2(0);
+        } else {
+            fetch(tile, 0);
+        }
     }
-    __syncthreads();
 
     const int frow = lane & 31, fh = lane >> 5;
     const float* Wfrag = Wl + (wave * 32 + frow) * LDS_LD + 4 * fh;
     float bias_v = ck.bias ? ck.bias[wave * 32 + frow] : 0.f;
+    const int swz = frow & 15;  // rows frow and frow+32 share it
 
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
         const int next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
+        if constexpr (FROM_X2) {
+            __syncthreads();
+            if (next < ntiles) fetch_x2(next);
+        } else {
+            // the tile's direct loads are older than the 32 output stores of the previous trip:
+            // wait until only those stores may be outstanding, then meet the other waves
+            // (first trip: nothing but the tile and the weight slice is in flight - wait for all)
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (next < ntiles) fetch(next, buf ^ 1);
+        }
 
         f32x16 acc0 = {0}, acc1 = {0};
-        const float* Xf0 = Xl + (buf * BM + frow) * LDS_LD + 4 * fh;
-        const float* Xf1 = Xf0 + 32 * LDS_LD;
+        const float* Xf0 = Xl + (buf * BM + frow) * H;
+        const float* Xf1 = Xf0 + 32 * H;
+        // lane half fh takes k = 8g + 4fh + t at step t: A and B agree, so any k order is a valid sum.
+        // The fragments of group g+1 are requested before the eight products of group g are issued.
+        float4 a0 = *reinterpret_cast<const float4*>(Xf0 + 4 * (fh ^ swz));
+        float4 a1 = *reinterpret_cast<const float4*>(Xf1 + 4 * (fh ^ swz));
+        float4 b = *reinterpret_cast<const float4*>(Wfrag);
 #pragma unroll
         for (int g = 0; g < H / 8; ++g) {
-            // lane half fh takes k = 8g + 4fh + t at step t: A and B agree, so any k order is a valid sum
-            float4 a0 = *reinterpret_cast<const float4*>(Xf0 + 8 * g);
-            float4 a1 = *reinterpret_cast<const float4*>(Xf1 + 8 * g);
-            float4 b = *reinterpret_cast<const float4*>(Wfrag + 8 * g);
+            float4 n0 = a0, n1 = a1, nb = b;
+            if (g + 1 < H / 8) {
+                const int pc = 4 * ((2 * (g + 1) + fh) ^ swz);
+                n0 = *reinterpret_cast<const float4*>(Xf0 + pc);
+                n1 = *reinterpret_cast<const float4*>(Xf1 + pc);
+                nb = *reinterpret_cast<const float4*>(Wfrag + 8 * (g + 1));
+            }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
@@ -129,27 +179,35 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+            a0 = n0; a1 = n1; b = nb;
+            // pin the issue order: this group's three LDS reads first, then its eight products
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
         // epilogue: register r of a 32x32 tile is row (r&3) + 8(r>>2) + 4*fh, column = frow
         const int col = wave * 32 + frow;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-            int g0 = tile * BM + row, g1 = g0 + 32;
+            // rows past M land on row M-1 of the same column with the value that row has anyway
+            // (their input was row M-1): every trip issues exactly 32 stores, which the counted
+            // wait above relies on
+            int g0 = min(tile * BM + row, M - 1), g1 = min(tile * BM + row + 32, M - 1);
             float y0 = acc0[r] + bias_v, y1 = acc1[r] + bias_v;
             if (RELU) {
                 y0 = fmaxf(y0, 0.f);
                 y1 = fmaxf(y1, 0.f);
             }
-            if (g0 < M) ck.out[static_cast<size_t>(g0) * H + col] = y0;
-            if (g1 < M) ck.out[static_cast<size_t>(g1) * H + col] = y1;
+            ck.out[static_cast<size_t>(g0) * H + col] = y0;
+            ck.out[static_cast<size_t>(g1) * H + col] = y1;
         }
-        if (next < ntiles) store_tile(buf ^ 1);
-        __syncthreads();
+        if constexpr (FROM_X2) {
+            if (next < ntiles) stash_x2(buf ^ 1);
+        }
     }
 }
 
-constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * LDS_LD) * sizeof(float);
+constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * H) * sizeof(float);
 
 template <bool RELU, bool FROM_X2>
 int launch_linear(hipStream_t s, int M, const float* X, const float* enc_w, const float* enc_b, const ChunkSet& cs,
@@ -202,20 +260,20 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
     ChunkSet cs{};
     int rc;
     // node_enc: Linear(2,128)+ReLU computed while staging, Linear(128,128)+ReLU on the matrix cores
-    cs.c[0] = Chunk{w->enc2_w, w->enc2_b, bufA, H};
+    cs.c[0] = Chunk{w->enc2_w, w->enc2_b, bufA, H, 0};
     if ((rc = launch_linear<true, true>(s, M, x, w->enc0_w, w->enc0_b, cs, 1))) return rc;
     // node_proj.0 on cat[h, z]: the z block is the bias vector zb[0]
-    cs.c[0] = Chunk{w->proj0_w, zb, bufB, 2 * H};
+    cs.c[0] = Chunk{w->proj0_w, zb, bufB, 2 * H, 0};
     if ((rc = launch_linear<true, false>(s, M, bufA, nullptr, nullptr, cs, 1))) return rc;
     float* hc = h_cond ? h_cond : bufA;
-    cs.c[0] = Chunk{w->proj2_w, w->proj2_b, hc, H};
+    cs.c[0] = Chunk{w->proj2_w, w->proj2_b, hc, H, 0};
     if ((rc = launch_linear<true, false>(s, M, bufB, nullptr, nullptr, cs, 1))) return rc;
     // first Linear of both edge MLPs, split into source block / target block (+ z block and bias)
     const size_t plane = static_cast<size_t>(n) * H;
-    cs.c[0] = Chunk{w->sc0_w, nullptr, proj, 3 * H};
-    cs.c[1] = Chunk{w->sc0_w + H, zb + H, proj + plane, 3 * H};
-    cs.c[2] = Chunk{w->at0_w, nullptr, proj + 2 * plane, 3 * H};
-    cs.c[3] = Chunk{w->at0_w + H, zb + 2 * H, proj + 3 * plane, 3 * H};
+    cs.c[0] = Chunk{w->sc0_w, nullptr, proj, 3 * H, 0};
+    cs.c[1] = Chunk{w->sc0_w + H, zb + H, proj + plane, 3 * H, 0};
+    cs.c[2] = Chunk{w->at0_w, nullptr, proj + 2 * plane, 3 * H, 0};
+    cs.c[3] = Chunk{w->at0_w + H, zb + 2 * H, proj + 3 * plane, 3 * H, 0};
     if ((rc = launch_linear<false, false>(s, M, hc, nullptr, nullptr, cs, 4))) return rc;
     return AIG_OK;
 }
