@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 import torch
 import torch.distributed as dist
 
+MFMA_F32_PEAK_TF = 157.3  # dense f32 matrix peak of MI355X
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak; ~6300 GB/s is the measured copy ceiling
 
 
@@ -132,6 +133,9 @@ def main():
         trainer.step(batch)
     barrier()
     _abi.timeline.reset()
+    # Only the kernel the roofline reports on is bracketed with events inside the timed region: an
+    # event pair costs queue time, and bracketing every entry point slowed the step by 10-50 %.
+    _abi.timeline.only = {"aig_gat_fwd"}
     _abi.timeline.enabled = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -141,6 +145,16 @@ def main():
     _abi.timeline.enabled = False
     tl = _abi.timeline.totals_ms()
     tl_meta = dict(_abi.timeline.meta)
+    # per-entry-point GPU time from a few extra, untimed, fully instrumented steps
+    inst_steps = min(3, a.steps)
+    _abi.timeline.reset()
+    _abi.timeline.only = None
+    _abi.timeline.enabled = True
+    for _ in range(inst_steps):
+        trainer.step(batch)
+    barrier()
+    _abi.timeline.enabled = False
+    tl_all = _abi.timeline.totals_ms()
 
     edges_rank = trainer.edges_last_step * a.steps
     stat = torch.tensor([elapsed, float(edges_rank)], dtype=torch.float64, device=dev)
@@ -184,6 +198,16 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches": launches, "avg_launch_us": round(ms_fwd * 1e3 / launches, 2),
                     "algorithmic_bytes_per_launch_avg": int(total_bytes / launches)}
+        # the dense contraction of the path: node projections of the generator (7 products of
+        # [n,128]x[128,128] per sample) on the f32 matrix cores, flops executed / event time
+        mfma = None
+        ms_proj, n_proj = tl_all.get("aig_gen_node_proj", (0.0, 0))
+        if n_proj:
+            flops = 7 * 2.0 * nodes_per_iter * 128 * 128 * n_proj
+            tf = flops / (ms_proj * 1e-3) / 1e12
+            mfma = {"kernel": "k_linear128 (entry point aig_gen_node_proj)", "bound": "mfma", "achieved": round(tf, 1),
+                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                    "launches": n_proj, "avg_launch_us": round(ms_proj * 1e3 / n_proj, 2)}
         out = {
             "metric": "train edges/sec (AIG nodes/sec sampled at k=64 in sample_nodes_per_sec)",
             "value": round(edges_total / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps,
@@ -194,7 +218,9 @@ def main():
                        "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
             "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
             "roofline": roof,
-            "timeline_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(tl.items())},
+            "roofline_mfma": mfma,
+            "timeline_ms_per_step": {k: round(v[0] / inst_steps, 3) for k, v in sorted(tl_all.items())},
+            "timeline_note": f"GPU ms per step by entry point, from {inst_steps} extra instrumented steps outside the timed region",
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

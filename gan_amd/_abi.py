@@ -47,6 +47,7 @@ SIGNATURES = {
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_bwd": (INT, [I64, I64] + [P] * 24 + [P, SZ, P]),
+    "aig_linear128": (INT, [I64, P, P, INT, P, INT, P, P]),
     "aig_wgrad_ws_bytes": (SZ, [I64, I64]),
     "aig_wgrad": (INT, [I64, I64, P, P, P, P, SZ, P]),
     "aig_level_plan_ws_bytes": (SZ, [I64, I64]),
@@ -92,6 +93,7 @@ class _Timeline:
         self.enabled = False
         self.events = {}
         self.meta = {}
+        self.only = None
 
     def reset(self):
         self.events = {}
@@ -107,8 +109,10 @@ timeline = _Timeline()
 
 def timed(name: str, fn, *args, meta=None):
     """Call an entry point; when the timeline is on, bracket it with events on the current stream
-    (the stream the kernels are enqueued on) and remember ``meta`` (problem sizes) per launch."""
-    if not timeline.enabled:
+    (the stream the kernels are enqueued on) and remember ``meta`` (problem sizes) per launch.
+    ``timeline.only`` (a set of names, or None) restricts the bracketing: an event pair costs tens
+    of microseconds of queue time, so a timed run keeps only the entry point it reports on."""
+    if not timeline.enabled or (timeline.only is not None and name not in timeline.only):
         return fn(*args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

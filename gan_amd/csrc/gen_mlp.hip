@@ -69,10 +69,20 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
     const int ntiles = (M + BM - 1) / BM;
 
     // stage the weight slice once: 128 rows x 32 float4 (row = output column)
-    if (ck.wt) {  // the slice is stored [in][out]: transpose while staging
-        for (int idx = tid; idx < H * H; idx += THREADS) {
-            const int k = idx >> 7, j = idx & (H - 1);
-            Wl[j * LDS_LD + k] = ck.w[static_cast<size_t>(k) * ck.ldw + j];
+    if (ck.wt) {  // the slice is stored [in][out]: transpose while staging (all loads first)
+        float4 v[(H * H / 4) / THREADS];
+#pragma unroll
+        for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
+            const int idx = q * THREADS + tid, k = idx >> 5, c4 = idx & 31;
+            v[q] = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(k) * ck.ldw + c4 * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
+            const int idx = q * THREADS + tid, k = idx >> 5, j = 4 * (idx & 31);
+            Wl[j * LDS_LD + k] = v[q].x;
+            Wl[(j + 1) * LDS_LD + k] = v[q].y;
+            Wl[(j + 2) * LDS_LD + k] = v[q].z;
+            Wl[(j + 3) * LDS_LD + k] = v[q].w;
         }
     } else {
 #pragma unroll
@@ -276,4 +286,17 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
     cs.c[3] = Chunk{w->at0_w + H, zb + 2 * H, proj + 3 * plane, 3 * H, 0};
     if ((rc = launch_linear<false, false>(s, M, hc, nullptr, nullptr, cs, 4))) return rc;
     return AIG_OK;
+}
+
+extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int relu,
+                             float* y, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT32_MAX, "aig_linear128: n=%lld out of range", (long long)n);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(x && w && y, "aig_linear128: null pointer");
+    AIG_REQUIRE(x != y, "aig_linear128: in-place operation is not supported");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ChunkSet cs{};
+    cs.c[0] = Chunk{w, bias, y, H, w_in_major ? 1 : 0};
+    if (relu) return launch_linear<true, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
+    return launch_linear<false, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
 }

@@ -23,6 +23,8 @@ import math
 from collections import OrderedDict
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -158,7 +160,33 @@ class _WGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gg):
         g, x = ctx.saved_tensors
-        return x @ gg.t(), g @ gg
+        return _matmul_wt(x, gg), _matmul_w(g, gg)
+
+
+def _linear128(x: torch.Tensor, w: torch.Tensor, in_major: bool) -> torch.Tensor:
+    """x w^T (in_major False) or x w (in_major True) for x [n,128], w [128,128] on the projection kernel."""
+    x, w = x.contiguous(), w.contiguous()
+    y = torch.empty_like(x)
+    _abi.check(_abi.timed("aig_linear128", _abi.lib().aig_linear128, int(x.size(0)), _abi.ptr(x), _abi.ptr(w),
+                          1 if in_major else 0, None, 0, _abi.ptr(y), _abi.stream()), "aig_linear128")
+    return y
+
+
+_USE_LINEAR128 = os.environ.get("AIG_NO_LINEAR128", "") == ""
+
+
+def _is128(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return _USE_LINEAR128 and x.dim() == 2 and x.size(1) == HIDDEN and tuple(w.shape) == (HIDDEN, HIDDEN) and x.dtype == torch.float32
+
+
+def _matmul_wt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x @ w.t(), differentiable (through _Project) when the shapes fit the kernel."""
+    return _Project.apply(x, w) if _is128(x, w) else x @ w.t()
+
+
+def _matmul_w(g: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """g @ w, differentiable (through _ProjectBack) when the shapes fit the kernel."""
+    return _ProjectBack.apply(g, w) if _is128(g, w) else g @ w
 
 
 class _Project(torch.autograd.Function):
@@ -168,7 +196,7 @@ class _Project(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return x @ w.t()
+        return _linear128(x, w, False) if _is128(x, w) else x @ w.t()
 
     @staticmethod
     def backward(ctx, g):
@@ -185,12 +213,12 @@ class _ProjectBack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, w):
         ctx.save_for_backward(g, w)
-        return g @ w
+        return _linear128(g, w, True) if _is128(g, w) else g @ w
 
     @staticmethod
     def backward(ctx, gg):
         g, w = ctx.saved_tensors
-        d_g = gg @ w.t() if ctx.needs_input_grad[0] else None
+        d_g = _matmul_wt(gg, w) if ctx.needs_input_grad[0] else None
         d_w = _WGrad.apply(g, gg) if ctx.needs_input_grad[1] else None
         return d_g, d_w
 

@@ -165,6 +165,13 @@ int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, cons
                 float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
                 void* ws, size_t ws_bytes, void* stream);
 
+/* Dense projection of the critic's second attention layer, y = x W^T (+ bias, optionally ReLU) with x [n,128],
+ * y [n,128] on the f32 matrix cores - torch.nn.functional.linear inside GATConv.lin (discriminator.py:61) and
+ * its input gradient g W.  w_in_major = 0: w is [out,in] as PyTorch stores a Linear weight; 1: w is [in,out]
+ * (so that passing the same Linear weight computes g W).  bias [128] or NULL.  x and y must not overlap. */
+int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int relu,
+                  float* y, void* stream);
+
 /* Weight gradient of a dense projection xw = x W^T over the nodes (the reduction torch.nn.functional.linear's
  * backward performs for gat{1,2}.lin at discriminator.py:60-61): dW[j][f] = sum_n g[n][j] * x[n][f],
  * g [n,128], x [n,F], dW [128,F]; F in {1, 2, 4, 128}. */

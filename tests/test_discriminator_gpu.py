@@ -195,3 +195,23 @@ def test_critic_rejects_cpu_tensors():
     D, _ = make_critic()
     with pytest.raises(_abi.AigAbiError):
         D(Data(x=torch.zeros(4, 2), edge_index=torch.zeros((2, 0), dtype=torch.long)))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 100003])
+@pytest.mark.parametrize("in_major", [False, True])
+def test_linear128_matches_fp32_matmul(n, in_major):
+    """aig_linear128 against a plain fp32 product of the same operands (tolerance 1e-5 of the row scale)."""
+    from gan_amd.discriminator import _linear128
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 128, generator=gen).to(DEV)
+    w = (torch.randn(128, 128, generator=gen) / 11.3).to(DEV)
+    got = _linear128(x, w, in_major)
+    want = (x.double() @ (w.double() if in_major else w.double().t())).float()
+    assert got.shape == want.shape
+    scale = want.abs().max().item() + 1e-6
+    assert (got - want).abs().max().item() <= 1e-5 * scale
+    # identical rows give identical outputs wherever they sit in a tile
+    if n >= 65:
+        x2 = x.clone(); x2[64] = x2[0]
+        y2 = _linear128(x2, w, in_major)
+        assert torch.equal(y2[64], y2[0])
