@@ -23,8 +23,9 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-6)
 
 
+@pytest.mark.parametrize("capture", [False, True], ids=["eager", "hip_graph"])
 @pytest.mark.parametrize("batch", [1, 3])
-def test_training_step_matches_cpu_checker(batch):
+def test_training_step_matches_cpu_checker(batch, capture):
     graphs = [synth_aig(6 + 2 * i, 50 + 20 * i, 4 + i, seed=40 + i, window=24, orientation="dataset")
               for i in range(batch)]
     max_nodes = max(g.x.size(0) for g in graphs)
@@ -44,7 +45,11 @@ def test_training_step_matches_cpu_checker(batch):
     tr.draw_alpha = lambda: next(ai).to(DEV)
     real = Batch.from_data_list(padded)
     real.sample_ids = list(range(batch))
-    out = tr.step(Batch.from_data_list(padded).to(DEV))
+    step_batch = Batch.from_data_list(padded).to(DEV)
+    if capture:                      # minibatches that carry sample ids replay the recorded critic terms
+        step_batch.sample_ids = list(range(batch))
+    out = tr.step(step_batch)
+    assert (len(tr._captured) == 1) == capture
     got = {k: float(v) for k, v in out.items()}
 
     cpu_tr = CpuTrainer(gs, dparams, 16, max_nodes, max_edges)
