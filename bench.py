@@ -47,6 +47,17 @@ def workload_graphs(name: str, rank: int):
     raise SystemExit(f"unknown workload {name}")
 
 
+def pmc_traffic(workload: str):
+    """HBM bytes per launch of k_gat_aggregate on this workload from the committed PMC passes
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see profiles/pmc_traffic.json); None when not collected."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[workload]["k_gat_aggregate"]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def gat_fwd_bytes(n: int, e: int) -> int:
     """Algorithmic bytes of one fused aggregate launch (E' = e + n edges incl. self loops):
     gather 512 B per edge, write 512 B per node, int32 source + fp32 attribute per real edge,
@@ -195,7 +206,7 @@ def main():
         if launches:
             achieved = total_bytes / (ms_fwd * 1e-3) / 1e9
             roof = {"kernel": "k_gat_aggregate (entry point aig_gat_fwd)", "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload),
                     "launches": launches, "avg_launch_us": round(ms_fwd * 1e3 / launches, 2),
                     "algorithmic_bytes_per_launch_avg": int(total_bytes / launches)}
         # the dense contraction of the path: node projections of the generator (7 products of
