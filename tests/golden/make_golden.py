@@ -46,9 +46,23 @@ def import_reference():
     sys.path.insert(0, REF)
     from models.generator import AIGGenerator
     from models import constraints
-    from utilities import data_process
+    assert os.path.realpath(constraints.__file__).startswith(os.path.realpath(REF)), constraints.__file__
+    # the reference's utilities/ has no __init__.py, so a regular package of that name elsewhere on
+    # the path would win whatever the order: load its files by path
+    data_process = load_reference_file("utilities/data_process.py")
+    sys.modules.setdefault("utilities.data_process", data_process)
     import AIGgan
+    assert os.path.realpath(AIGgan.__file__).startswith(os.path.realpath(REF)), AIGgan.__file__
     return AIGGenerator, constraints, data_process, AIGgan
+
+
+def load_reference_file(rel_path: str):
+    import importlib.util
+    name = "reference_" + rel_path.replace("/", "_").replace(".py", "")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel_path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def np_of(t):
