@@ -43,7 +43,7 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
     out[v * H + j] = acc + b[j];
 }
 
-// Y[:, chunk] = act(X W_chunk^T + bias_chunk) for a persistent grid of row tiles.
+// Y[:, chunk] = act(X W_chunk^T + bias_chunk) for a persistent grid of row tiles (ACT 0 none, 1 ReLU, 2 ELU).
 // FROM_X2: the input tile is relu(enc0(x)) computed on the fly from the [M,2] features.
 //
 // LDS: the weight slice (padded rows) stays for the life of the block; input tiles of BM rows are
@@ -57,7 +57,7 @@ __device__ __forceinline__ void load_to_lds16(const float* src, float* lds_dst) 
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <bool RELU, bool FROM_X2>
+template <int ACT, bool FROM_X2>
 __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __restrict__ X,
                                                        const float* __restrict__ enc_w,
                                                        const float* __restrict__ enc_b, ChunkSet cs) {
@@ -204,9 +204,12 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
             // wait above relies on
             int g0 = min(tile * BM + row, M - 1), g1 = min(tile * BM + row + 32, M - 1);
             float y0 = acc0[r] + bias_v, y1 = acc1[r] + bias_v;
-            if (RELU) {
+            if (ACT == 1) {
                 y0 = fmaxf(y0, 0.f);
                 y1 = fmaxf(y1, 0.f);
+            } else if (ACT == 2) {  // ELU
+                y0 = y0 > 0.f ? y0 : expm1f(y0);
+                y1 = y1 > 0.f ? y1 : expm1f(y1);
             }
             ck.out[static_cast<size_t>(g0) * H + col] = y0;
             ck.out[static_cast<size_t>(g1) * H + col] = y1;
@@ -219,18 +222,18 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
 
 constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * H) * sizeof(float);
 
-template <bool RELU, bool FROM_X2>
+template <int ACT, bool FROM_X2>
 int launch_linear(hipStream_t s, int M, const float* X, const float* enc_w, const float* enc_b, const ChunkSet& cs,
                   int nchunks) {
     static bool attr_set = false;  // raising the dynamic LDS limit is idempotent; racing threads set the same value
     if (!attr_set) {
-        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear128<RELU, FROM_X2>),
+        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear128<ACT, FROM_X2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LINEAR_LDS));
         attr_set = true;
     }
     int ntiles = (M + BM - 1) / BM;
     int gx = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL((k_linear128<RELU, FROM_X2>), dim3(gx, nchunks), dim3(THREADS), LINEAR_LDS, s, M, X, enc_w,
+    hipLaunchKernelGGL((k_linear128<ACT, FROM_X2>), dim3(gx, nchunks), dim3(THREADS), LINEAR_LDS, s, M, X, enc_w,
                        enc_b, cs);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -271,24 +274,24 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
     int rc;
     // node_enc: Linear(2,128)+ReLU computed while staging, Linear(128,128)+ReLU on the matrix cores
     cs.c[0] = Chunk{w->enc2_w, w->enc2_b, bufA, H, 0};
-    if ((rc = launch_linear<true, true>(s, M, x, w->enc0_w, w->enc0_b, cs, 1))) return rc;
+    if ((rc = launch_linear<1, true>(s, M, x, w->enc0_w, w->enc0_b, cs, 1))) return rc;
     // node_proj.0 on cat[h, z]: the z block is the bias vector zb[0]
     cs.c[0] = Chunk{w->proj0_w, zb, bufB, 2 * H, 0};
-    if ((rc = launch_linear<true, false>(s, M, bufA, nullptr, nullptr, cs, 1))) return rc;
+    if ((rc = launch_linear<1, false>(s, M, bufA, nullptr, nullptr, cs, 1))) return rc;
     float* hc = h_cond ? h_cond : bufA;
     cs.c[0] = Chunk{w->proj2_w, w->proj2_b, hc, H, 0};
-    if ((rc = launch_linear<true, false>(s, M, bufB, nullptr, nullptr, cs, 1))) return rc;
+    if ((rc = launch_linear<1, false>(s, M, bufB, nullptr, nullptr, cs, 1))) return rc;
     // first Linear of both edge MLPs, split into source block / target block (+ z block and bias)
     const size_t plane = static_cast<size_t>(n) * H;
     cs.c[0] = Chunk{w->sc0_w, nullptr, proj, 3 * H, 0};
     cs.c[1] = Chunk{w->sc0_w + H, zb + H, proj + plane, 3 * H, 0};
     cs.c[2] = Chunk{w->at0_w, nullptr, proj + 2 * plane, 3 * H, 0};
     cs.c[3] = Chunk{w->at0_w + H, zb + 2 * H, proj + 3 * plane, 3 * H, 0};
-    if ((rc = launch_linear<false, false>(s, M, hc, nullptr, nullptr, cs, 4))) return rc;
+    if ((rc = launch_linear<0, false>(s, M, hc, nullptr, nullptr, cs, 4))) return rc;
     return AIG_OK;
 }
 
-extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int relu,
+extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,
                              float* y, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT32_MAX, "aig_linear128: n=%lld out of range", (long long)n);
     if (n == 0) return AIG_OK;
@@ -297,6 +300,8 @@ extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in
     hipStream_t s = static_cast<hipStream_t>(stream);
     ChunkSet cs{};
     cs.c[0] = Chunk{w, bias, y, H, w_in_major ? 1 : 0};
-    if (relu) return launch_linear<true, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
-    return launch_linear<false, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
+    AIG_REQUIRE(act >= 0 && act <= 2, "aig_linear128: act=%d (0 none, 1 ReLU, 2 ELU)", act);
+    if (act == 1) return launch_linear<1, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
+    if (act == 2) return launch_linear<2, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
+    return launch_linear<0, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
 }

@@ -245,16 +245,36 @@ class _LevelPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        # Linear in g with constant coefficients, written with differentiable torch ops so that the
-        # gradient penalty can back-propagate through it a second time.
-        plan: LevelPlan = ctx.plan
         (argmax,) = ctx.saved_tensors
-        n = ctx.n
-        d_h = g[:, :HIDDEN] * plan.w[:n].unsqueeze(1)
-        has = (argmax >= 0)
-        src = (g[:, HIDDEN:] / float(plan.L + 1)).expand(plan.L + 1, HIDDEN) * has
-        d_h = d_h.scatter_add(0, argmax.clamp(min=0).long(), src)
-        return d_h, None
+        return _LevelPoolBwd.apply(g, ctx.plan, argmax, ctx.n), None
+
+
+class _LevelPoolBwd(torch.autograd.Function):
+    """Gradient of the readout w.r.t. the node rows; linear in ``g``, so its own backward (reached
+    when the gradient penalty differentiates a second time) is the adjoint map."""
+
+    @staticmethod
+    def forward(ctx, g, plan: LevelPlan, argmax, n: int):
+        g = g.contiguous()
+        d_h = torch.empty((n, HIDDEN), dtype=torch.float32, device=g.device)
+        _abi.check(_abi.lib().aig_level_pool_bwd(n, plan.L, _abi.ptr(g), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+                                                 _abi.ptr(argmax), _abi.ptr(d_h), _abi.stream()), "aig_level_pool_bwd")
+        ctx.plan, ctx.n = plan, n
+        ctx.save_for_backward(argmax)
+        return d_h
+
+    @staticmethod
+    def backward(ctx, gg):
+        lib = _abi.lib()
+        (argmax,) = ctx.saved_tensors
+        plan, n = ctx.plan, ctx.n
+        gg = gg.contiguous()
+        out = torch.empty((1, 2 * HIDDEN), dtype=torch.float32, device=gg.device)
+        ws = _abi.workspace(lib.aig_level_pool_bwd_adj_ws_bytes(n), gg.device)
+        _abi.check(lib.aig_level_pool_bwd_adj(n, plan.L, _abi.ptr(gg), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+                                              _abi.ptr(argmax), _abi.ptr(out), _abi.ptr(ws), ws.numel(), _abi.stream()),
+                   "aig_level_pool_bwd_adj")
+        return out, None, None, None
 
 
 def _glorot_(t: torch.Tensor) -> torch.Tensor:
@@ -346,6 +366,70 @@ class AIGDiscriminator(nn.Module):
     def level_plan(self, node_depth, n, device) -> LevelPlan:
         key = (_tkey(node_depth), n)
         return self._lvl_cache.lookup(key, lambda: (LevelPlan(node_depth, n, device), node_depth))[0]
+
+    def gradient_penalty_closed_form(self, x_real: torch.Tensor, x_fake: torch.Tensor, alpha: torch.Tensor,
+                                     node_depth: Optional[torch.Tensor]):
+        """``gradient_penalty(use_edges=False)`` of train.py:133-152 and its gradient w.r.t. the critic's
+        parameters without autograd on the node tensors: on an empty edge list each attention layer
+        is ``elu(x W^T + b)``, which makes the penalty a closed form (four [n,128]x[128,128]
+        products, three node-dimension weight gradients, a few row-wise passes).  Only the small
+        head is differentiated by autograd.  Returns ``(gp, grad_norm, grads)`` with ``grads`` a dict
+        parameter -> gradient of ``gp`` (parameters the edge-free pass never touches are absent)."""
+        lib = _abi.lib()
+        dev = x_real.device
+        n = int(x_real.size(0))
+        f32 = dict(dtype=torch.float32, device=dev)
+        xr, xf = x_real.float().contiguous(), x_fake.float().contiguous()
+        al = alpha.reshape(-1)[:1].float().contiguous()
+        W1, b1 = self.gat1.lin.weight.detach().contiguous(), self.gat1.bias.detach().contiguous()
+        W2, b2 = self.gat2.lin.weight.detach().contiguous(), self.gat2.bias.detach().contiguous()
+        if tuple(W1.shape) != (HIDDEN, 2):
+            raise NotImplementedError("closed-form gradient penalty is built for in_dim=2")
+        plan = self.level_plan(node_depth, n, dev)
+        st = _abi.stream()
+        xhat = torch.empty((n, 2), **f32)
+        h1, h2 = torch.empty((n, HIDDEN), **f32), torch.empty((n, HIDDEN), **f32)
+        _abi.check(lib.aig_gp_forward(n, _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(al), _abi.ptr(W1), _abi.ptr(b1),
+                                      _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(xhat), _abi.ptr(h1), _abi.ptr(h2), st),
+                   "aig_gp_forward")
+        r = torch.empty((1, 2 * HIDDEN), **f32)
+        argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
+        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(n, plan.L), dev)
+        _abi.check(lib.aig_level_pool_fwd(n, plan.nvalid, plan.L, _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
+                                          _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(r), _abi.ptr(argmax),
+                                          _abi.ptr(ws), ws.numel(), st), "aig_level_pool_fwd")
+        # head: s = out(mlp(r)); g_r = ds/dr stays attached to the head's weights
+        head = [p for p in list(self.mlp.parameters()) + list(self.out.parameters())]
+        with torch.enable_grad():
+            r = r.requires_grad_(True)
+            s = self.out(self.mlp(r)).sum()
+            (g_r,) = torch.autograd.grad(s, [r], create_graph=True)
+        g_r_c = g_r.detach().contiguous()
+        g_z2, g_h1, g_z1 = (torch.empty((n, HIDDEN), **f32) for _ in range(3))
+        g_x, norm_sq = torch.empty((n, 2), **f32), torch.empty(1, **f32)
+        ws = _abi.workspace(lib.aig_gp_input_grad_ws_bytes(n), dev)
+        _abi.check(lib.aig_gp_input_grad(n, plan.L, _abi.ptr(g_r_c), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+                                         _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(h1), _abi.ptr(h2),
+                                         _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(norm_sq),
+                                         _abi.ptr(ws), ws.numel(), st), "aig_gp_input_grad")
+        norm = torch.sqrt(norm_sq[0])
+        gp = (norm - 1.0) ** 2
+        coef = (2.0 * (norm - 1.0) / norm).reshape(1).contiguous()
+        dW1, db1 = torch.empty((HIDDEN, 2), **f32), torch.empty(HIDDEN, **f32)
+        dW2, db2 = torch.empty((HIDDEN, HIDDEN), **f32), torch.empty(HIDDEN, **f32)
+        u_gr = torch.empty((1, 2 * HIDDEN), **f32)
+        ws = _abi.workspace(lib.aig_gp_param_grad_ws_bytes(n), dev)
+        _abi.check(lib.aig_gp_param_grad(n, plan.L, _abi.ptr(coef), _abi.ptr(g_r_c), _abi.ptr(plan.node_level),
+                                         _abi.ptr(plan.w), _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(xhat),
+                                         _abi.ptr(h1), _abi.ptr(h2), _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1),
+                                         _abi.ptr(g_x), _abi.ptr(dW1), _abi.ptr(db1), _abi.ptr(dW2), _abi.ptr(db2),
+                                         _abi.ptr(u_gr), _abi.ptr(ws), ws.numel(), st), "aig_gp_param_grad")
+        grads = {self.gat1.lin.weight: dW1, self.gat1.bias: db1, self.gat2.lin.weight: dW2, self.gat2.bias: db2}
+        head_grads = torch.autograd.grad(g_r, head, grad_outputs=u_gr, allow_unused=True)
+        for p_, g_ in zip(head, head_grads):
+            if g_ is not None:
+                grads[p_] = g_
+        return gp.detach(), norm.detach(), grads
 
     def forward(self, data: Data) -> torch.Tensor:
         x = data.x.float()

@@ -15,7 +15,9 @@ What differs, on purpose:
 * the real-side critic term and the gradient penalty of a minibatch are recorded as a HIP graph
   and replayed (``CapturedCriticTerms``; ``--no-graph-capture`` keeps the eager path);
 * extension flags: ``--seed``, ``--unpad-templates`` (the reference's templates stay padded,
-  see gan_amd/dataset.py), ``--no-progress``, ``--no-graph-capture``.
+  see gan_amd/dataset.py), ``--no-progress``, ``--no-graph-capture``, ``--autograd-gp``;
+* the gradient penalty and its parameter gradient come from a closed form
+  (``AIGDiscriminator.gradient_penalty_closed_form``) unless ``--autograd-gp`` is given.
 """
 from __future__ import annotations
 
@@ -118,7 +120,7 @@ class CapturedCriticTerms:
     floating-point addition per parameter."""
 
     def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], real_padded: Batch, real_for_D: Data,
-                 gp_lambda: float, device: torch.device):
+                 gp_lambda: float, device: torch.device, closed_form_gp: bool = True):
         self.x_fake = torch.empty_like(real_padded.x, dtype=torch.float32)
         self.x_fake.copy_(real_padded.x)
         self.alpha = torch.full((1, 1), 0.5, device=device)
@@ -128,6 +130,13 @@ class CapturedCriticTerms:
 
         def compute():
             d_real = torch.mean(D(real_for_D))
+            if closed_form_gp:
+                grads = list(torch.autograd.grad(-d_real, params, allow_unused=True))
+                gp, gn, gp_grads = D.gradient_penalty_closed_form(real_pad.x, fake_pad.x, self.alpha, real_pad.node_depth)
+                for k, p in enumerate(params):
+                    if p in gp_grads:
+                        grads[k] = gp_lambda * gp_grads[p] if grads[k] is None else grads[k] + gp_lambda * gp_grads[p]
+                return d_real.detach(), gp, gn, grads
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha)
             grads = torch.autograd.grad(gp_lambda * gp - d_real, params, allow_unused=True)
             return d_real.detach(), gp.detach(), gn, grads
@@ -177,6 +186,7 @@ class Trainer:
         self._captured: "OrderedDict[tuple, CapturedCriticTerms]" = OrderedDict()
         self._real_for_D: Dict[tuple, Data] = {}
         self.graph_capture = bool(getattr(args, "graph_capture", True))
+        self.closed_form_gp = bool(getattr(args, "closed_form_gp", True))
         self.global_step = 0
         self._templates: Dict[int, Data] = {}
         self.last: Dict[str, torch.Tensor] = {}
@@ -222,7 +232,7 @@ class Trainer:
             self._captured.move_to_end(key)
             return self._captured[key]
         terms = CapturedCriticTerms(self.D, self._d_params, real_padded, sanitize_for_D(real_padded),
-                                    self.args.gp_lambda, self.device)
+                                    self.args.gp_lambda, self.device, closed_form_gp=self.closed_form_gp)
         self._captured[key] = terms
         if len(self._captured) > 4:       # every entry pins the activations of its graph
             self._captured.popitem(last=False)
@@ -269,10 +279,18 @@ class Trainer:
                         D_real_mean = torch.mean(D(real_for_D))
                         D_fake_mean = torch.mean(D(fake_for_D))
                         gap = D_real_mean - D_fake_mean
-                        gp_term, grad_norm = gradient_penalty(D, real_padded, fake_padded, dev, use_edges=False,
-                                                              alpha=self.draw_alpha())
-                        loss_D = (D_fake_mean - D_real_mean) + a.gp_lambda * gp_term
-                        loss_D.backward()
+                        if self.closed_form_gp:
+                            gp_term, grad_norm, gp_grads = D.gradient_penalty_closed_form(
+                                real_padded.x, fake_padded.x, self.draw_alpha(), real_padded.node_depth)
+                            (D_fake_mean - D_real_mean).backward()
+                            for p_, g_ in gp_grads.items():
+                                p_.grad = a.gp_lambda * g_ if p_.grad is None else p_.grad.add_(g_, alpha=a.gp_lambda)
+                            loss_D = (D_fake_mean - D_real_mean).detach() + a.gp_lambda * gp_term
+                        else:
+                            gp_term, grad_norm = gradient_penalty(D, real_padded, fake_padded, dev, use_edges=False,
+                                                                  alpha=self.draw_alpha())
+                            loss_D = (D_fake_mean - D_real_mean) + a.gp_lambda * gp_term
+                            loss_D.backward()
                     self.last = dict(D_real=D_real_mean.detach(), D_fake=D_fake_mean.detach(), gap=gap.detach(),
                                      gp=gp_term.detach(), grad_norm=grad_norm.detach(), loss_D=loss_D.detach())
                 except Exception as e:
@@ -411,6 +429,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--unpad-templates", action="store_true",
                    help="Strip padding rows from templates (the reference keeps them padded).")
     p.add_argument("--no-progress", action="store_true")
+    p.add_argument("--autograd-gp", dest="closed_form_gp", action="store_false",
+                   help="compute the gradient penalty by double backward (autograd) instead of its closed form")
     p.add_argument("--no-graph-capture", dest="graph_capture", action="store_false",
                    help="evaluate the real-side critic term and the gradient penalty eagerly instead of replaying a HIP graph")
     return p

@@ -165,11 +165,12 @@ int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, cons
                 float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
                 void* ws, size_t ws_bytes, void* stream);
 
-/* Dense projection of the critic's second attention layer, y = x W^T (+ bias, optionally ReLU) with x [n,128],
+/* Dense projection of the critic's second attention layer, y = act(x W^T + bias) with x [n,128],
  * y [n,128] on the f32 matrix cores - torch.nn.functional.linear inside GATConv.lin (discriminator.py:61) and
  * its input gradient g W.  w_in_major = 0: w is [out,in] as PyTorch stores a Linear weight; 1: w is [in,out]
- * (so that passing the same Linear weight computes g W).  bias [128] or NULL.  x and y must not overlap. */
-int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int relu,
+ * (so that passing the same Linear weight computes g W).  bias [128] or NULL; act 0 none, 1 ReLU, 2 ELU (the
+ * F.elu of discriminator.py:61 on the edge-free path).  x and y must not overlap. */
+int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,
                   float* y, void* stream);
 
 /* Weight gradient of a dense projection xw = x W^T over the nodes (the reduction torch.nn.functional.linear's
@@ -198,6 +199,43 @@ size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L);
 int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const float* h, const int32_t* perm,
                        const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
                        float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of the readout (what autograd derives from discriminator.py:64-91): with g = dLoss/d out [256],
+ *   d_h[i,c] = w[i] g[c] + [argmax[level(i),c] == i] g[128+c] / (L+1)
+ * and its adjoint (needed when the gradient penalty differentiates a second time): for gg [n,128]
+ *   out[c] = sum_i w[i] gg[i,c],   out[128+c] = sum_i [argmax[level(i),c] == i] gg[i,c] / (L+1). */
+int aig_level_pool_bwd(int64_t n, int64_t L, const float* g, const int32_t* node_level, const float* w,
+                       const int32_t* argmax, float* d_h, void* stream);
+size_t aig_level_pool_bwd_adj_ws_bytes(int64_t n);
+int aig_level_pool_bwd_adj(int64_t n, int64_t L, const float* gg, const int32_t* node_level, const float* w,
+                           const int32_t* argmax, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gradient penalty on the edge-free interpolate - gradient_penalty(use_edges=False), train.py:133-152, through
+ * AIGDiscriminator.forward on an empty edge list (discriminator.py:42-100), in closed form.  Without edges a
+ * GAT layer is elu(x W^T + b), so with r = readout(h2), s = head(r):
+ *   aig_gp_forward     x^ = alpha x_real + (1-alpha) x_fake [n,2]; h1 = elu(x^ W1^T + b1); h2 = elu(h1 W2^T + b2)
+ *                      (the caller runs aig_level_pool_fwd on h2 and its own head, and hands back g_r = ds/dr [256])
+ *   aig_gp_input_grad  g_z2 = (readout^T g_r) * elu'(z2); g_h1 = g_z2 W2; g_z1 = g_h1 * elu'(z1); g_x = g_z1 W1 [n,2];
+ *                      *norm_sq = sum g_x^2      (the caller forms gp = (sqrt(norm_sq) - 1)^2 and
+ *                      coef = d gp / d norm / norm = 2 (norm - 1) / norm)
+ *   aig_gp_param_grad  gradient of gp w.r.t. W1 [128,2], b1, W2 [128,128], b2 and ubar_gr = d gp / d g_r [256]
+ *                      (the caller back-propagates ubar_gr through its head to get the head's weight gradients).
+ * W1/b1 = gat1.lin.weight / gat1.bias, W2/b2 = gat2.lin.weight / gat2.bias; alpha, norm_sq, coef are device scalars.
+ * ------------------------------------------------------------------------------------------- */
+int aig_gp_forward(int64_t n, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
+                   const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2, void* stream);
+size_t aig_gp_input_grad_ws_bytes(int64_t n);
+int aig_gp_input_grad(int64_t n, int64_t L, const float* g_r, const int32_t* node_level, const float* w,
+                      const int32_t* argmax, const float* W1, const float* W2, const float* h1, const float* h2,
+                      float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
+                      void* ws, size_t ws_bytes, void* stream);
+size_t aig_gp_param_grad_ws_bytes(int64_t n);
+int aig_gp_param_grad(int64_t n, int64_t L, const float* coef, const float* g_r, const int32_t* node_level,
+                      const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* xhat,
+                      const float* h1, const float* h2, const float* g_z2, const float* g_h1, const float* g_z1,
+                      const float* g_x, float* dW1, float* db1, float* dW2, float* db2, float* ubar_gr,
+                      void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Structural constraints - models/constraints.py.  One graph per call, n > 0 and E > 0 (the callers

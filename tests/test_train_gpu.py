@@ -23,15 +23,17 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-6)
 
 
+@pytest.mark.parametrize("gp", ["closed_form", "autograd"])
 @pytest.mark.parametrize("capture", [False, True], ids=["eager", "hip_graph"])
 @pytest.mark.parametrize("batch", [1, 3])
-def test_training_step_matches_cpu_checker(batch, capture):
+def test_training_step_matches_cpu_checker(batch, capture, gp):
     graphs = [synth_aig(6 + 2 * i, 50 + 20 * i, 4 + i, seed=40 + i, window=24, orientation="dataset")
               for i in range(batch)]
     max_nodes = max(g.x.size(0) for g in graphs)
     max_edges = max(g.edge_index.size(1) for g in graphs)
     padded = [pad_data(g, max_nodes, max_edges) for g in graphs]
-    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1"])
+    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1"] +
+                                     (["--autograd-gp"] if gp == "autograd" else []))
     tr = Trainer(args, max_nodes, max_edges, DEV)
     gs = gen_state()
     dparams = omodel.init_discriminator_params(11)
