@@ -214,7 +214,7 @@ def main():
         mfma = None
         ms_proj, n_proj = tl_all.get("aig_gen_node_proj", (0.0, 0))
         if n_proj:
-            flops = 7 * 2.0 * nodes_per_iter * 128 * 128 * n_proj
+            flops = 7 * 2.0 * 128 * 128 * nodes_per_iter * (n_proj / max(len(templates), 1))   # one launch per template
             tf = flops / (ms_proj * 1e-3) / 1e12
             mfma = {"kernel": "k_linear128 (entry point aig_gen_node_proj)", "bound": "mfma", "achieved": round(tf, 1),
                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
