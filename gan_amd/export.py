@@ -251,3 +251,233 @@ def main(argv=None) -> None:
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------- direct exporter
+# utilities/pt2bench.py of the reference: `.pt` -> `.bench` in one step, with inverters written as
+# NOT gates.  Edges are first cleaned and oriented (pt2bench.py:9-173), then only the region on a
+# PI -> PO path is written (pt2bench.py:216-428).
+def _orient_edges(src, dst, inv, types, depth):
+    """Cleaning and orientation of pt2bench.py:34-102 as array operations: drop out-of-range and
+    self edges and PI-PI / PO-PO pairs, turn an edge round when it enters a PI, leaves a PO, goes
+    down in depth or down in type priority (PI < AND < PO), drop exact repeats (first kept), and
+    keep only depth-increasing edges unless that would cost more than 30 % of them."""
+    n = types.shape[0]
+    ok = (src >= 0) & (dst >= 0) & (src < n) & (dst < n) & (src != dst)
+    src, dst, inv = src[ok], dst[ok], inv[ok]
+    ts, td = types[src], types[dst]
+    same = ((ts == PI) & (td == PI)) | ((ts == PO) & (td == PO))
+    src, dst, inv, ts, td = src[~same], dst[~same], inv[~same], ts[~same], td[~same]
+
+    def swap(mask):
+        nonlocal src, dst, ts, td
+        src, dst = np.where(mask, dst, src), np.where(mask, src, dst)
+        ts, td = np.where(mask, td, ts), np.where(mask, ts, td)
+    swap((td == PI) & (ts != PI))
+    swap((ts == PO) & (td != PO))
+    if depth is not None:
+        swap(depth[src] > depth[dst])
+    rank_s = np.select([ts == PI, ts == AND, ts == PO], [0, 1, 2], 9)
+    rank_d = np.select([td == PI, td == AND, td == PO], [0, 1, 2], -1)
+    swap(rank_s > rank_d)
+    same = ((ts == PI) & (td == PI)) | ((ts == PO) & (td == PO))
+    src, dst, inv = src[~same], dst[~same], inv[~same]
+    if src.size:
+        _, first = np.unique(np.stack([src, dst, inv], 1), axis=0, return_index=True)
+        keep = np.sort(first)
+        src, dst, inv = src[keep], dst[keep], inv[keep]
+    if depth is not None and src.size:
+        up = depth[src] < depth[dst]
+        if (~up).sum() <= 0.3 * src.size:
+            src, dst, inv = src[up], dst[up], inv[up]
+    return src, dst, inv
+
+
+def _break_cycles(src, dst, inv, n, depth):
+    """pt2bench.py:105-152: while a Kahn peel leaves nodes behind, take the smallest such node and
+    delete one edge entering it - the first that does not go up in depth, else the first."""
+    src, dst, inv = src.tolist(), dst.tolist(), inv.tolist()
+    while src:
+        indeg = np.bincount(np.asarray(dst), minlength=n)
+        order = np.argsort(np.asarray(src), kind="stable")
+        s_sorted = np.asarray(src)[order]
+        d_sorted = np.asarray(dst)[order]
+        ptr = np.searchsorted(s_sorted, np.arange(n + 1))
+        indeg = indeg.copy()
+        frontier = np.nonzero(indeg == 0)[0]
+        seen = 0
+        while frontier.size:
+            seen += frontier.size
+            beg, end = ptr[frontier], ptr[frontier + 1]
+            cnt = end - beg
+            if cnt.sum() == 0:
+                break
+            idx = np.repeat(beg, cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+            tgt = d_sorted[idx]
+            np.subtract.at(indeg, tgt, 1)
+            cand = np.unique(tgt)
+            frontier = cand[indeg[cand] == 0]
+        if seen == n:
+            break
+        left = np.nonzero(indeg > 0)[0]
+        if left.size == 0:
+            break
+        victim = int(left[0])
+        pick = -1
+        for k, d in enumerate(dst):
+            if d == victim:
+                if depth is not None and not (float(depth[src[k]]) < float(depth[d])):
+                    pick = k
+                    break
+                if pick == -1:
+                    pick = k
+        if pick == -1:
+            break
+        del src[pick], dst[pick], inv[pick]
+    return np.asarray(src, np.int64), np.asarray(dst, np.int64), np.asarray(inv, np.int64)
+
+
+def _closure(starts, ptr, adj, n):
+    seen = np.zeros(n, bool)
+    seen[starts] = True
+    frontier = starts
+    while frontier.size:
+        beg, end = ptr[frontier], ptr[frontier + 1]
+        cnt = end - beg
+        if cnt.sum() == 0:
+            break
+        idx = np.repeat(beg, cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+        nb = np.unique(adj[idx])
+        frontier = nb[~seen[nb]]
+        seen[frontier] = True
+    return seen
+
+
+def bench_text_with_inverters(data, name: str = "graph.pt") -> str:
+    """The text utilities/pt2bench.py:216-428 writes for ``data`` (``name`` = basename of the
+    ``.pt`` file, which the header line quotes).  No trailing newline, as there."""
+    x = _np(data.x)
+    n = int(x.shape[0])
+    types = x[:, 0].astype(np.int64)
+    depth = _np(getattr(data, "node_depth", None))
+    if depth is not None:
+        depth = depth.astype(np.float64).reshape(-1)
+    ei = _np(getattr(data, "edge_index", None), np.int64)
+    if ei is None or ei.size == 0:
+        src = dst = inv = np.zeros(0, np.int64)
+    else:
+        src, dst = ei[0].reshape(-1), ei[1].reshape(-1)
+        ea = _np(getattr(data, "edge_attr", None))
+        inv = np.zeros(src.size, np.int64) if ea is None else ea.reshape(-1).astype(np.int64)
+    src, dst, inv = _orient_edges(src, dst, inv, types, depth)
+    src, dst, inv = _break_cycles(src, dst, inv, n, depth)
+
+    # predecessor lists in edge order; successor / predecessor CSR for the two closures
+    by_dst = np.argsort(dst, kind="stable")
+    p_src, p_inv = src[by_dst], inv[by_dst]
+    p_ptr = np.searchsorted(dst[by_dst], np.arange(n + 1))
+    by_src = np.argsort(src, kind="stable")
+    s_ptr = np.searchsorted(src[by_src], np.arange(n + 1))
+    reach = _closure(np.nonzero(types == PI)[0], s_ptr, dst[by_src], n)
+    rev = _closure(np.nonzero(types == PO)[0], p_ptr, p_src, n)
+    on_path = reach & rev
+    if on_path.any():
+        active = on_path
+    elif reach.any():
+        active = reach
+    elif rev.any():
+        active = rev
+    else:
+        active = (types == PI) | (types == AND) | (types == PO)
+
+    lines = [f'# Benchmark "{name}" written by AIG-GAN']
+    names = [f"n{i}" for i in range(n)]
+    for k, i in enumerate(np.nonzero(types == PI)[0].tolist(), start=1):
+        names[i] = f"N{k}"
+        lines.append(f"INPUT(N{k})")
+
+    def preds_of(i):
+        return list(zip(p_src[p_ptr[i]:p_ptr[i + 1]].tolist(), p_inv[p_ptr[i]:p_ptr[i + 1]].tolist()))
+
+    body, nots = [], set()
+    defined_and = np.zeros(n, bool)
+    usable = active & ((types == PI) | (types == AND))
+    for i in np.nonzero((types == AND) & active)[0].tolist():
+        preds = [(s, v) for s, v in preds_of(i) if usable[s]]
+        if not preds:
+            continue
+        preds.sort(key=(lambda t: (depth[t[0]], t[0])) if depth is not None else (lambda t: t[0]))
+        terms = []
+        for s, v in preds:
+            sig = names[s]
+            if v:
+                sig += "_not"
+                if sig not in nots:
+                    body.append(f"{sig} = NOT({names[s]})")
+                    nots.add(sig)
+            terms.append(sig)
+        if len(terms) == 1:
+            terms.append(terms[0])
+        acc = terms[0]
+        for k, term in enumerate(terms[1:-1], start=1):
+            body.append(f"{names[i]}_and{k} = AND({acc}, {term})")
+            acc = f"{names[i]}_and{k}"
+        body.append(f"{names[i]} = AND({acc}, {terms[-1]})")
+        defined_and[i] = True
+
+    counter, emitted, used = 1, 0, set()
+    any_on_path = bool(on_path.any())
+    for i in np.nonzero(types == PO)[0].tolist():
+        every = preds_of(i)
+        if not (on_path[i] or (not any_on_path and (active[i] or every))):
+            continue
+        preds = [t for t in every if on_path[t[0]]] or [t for t in every if active[t[0]]] or every
+        if not preds:
+            continue
+        preds.sort(key=lambda t: (0 if types[t[0]] == AND else 1, depth[t[0]] if depth is not None else 0.0, t[0]))
+        # an AND that was never written cannot drive an output; anything else can
+        drive = next(((s, v) for s, v in preds if not (types[s] == AND and not defined_and[s])), None)
+        if drive is None:
+            continue
+        sig = names[drive[0]]
+        if drive[1]:
+            body.append(f"{sig}_not_out{counter} = NOT({sig})")
+            sig = f"{sig}_not_out{counter}"
+        if sig in used:
+            sig = f"{sig}_dup{counter}"
+        lines.append(f"OUTPUT({sig})")
+        used.add(sig)
+        counter += 1
+        emitted += 1
+
+    if emitted == 0:
+        cand = np.nonzero((types == AND) & active & defined_and)[0]
+        if cand.size == 0:
+            cand = np.nonzero((types == AND) & defined_and)[0]
+        if cand.size:
+            key = sorted(cand.tolist(), key=(lambda i: (depth[i], i)) if depth is not None else (lambda i: i), reverse=True)
+            for i in key[:2]:
+                if names[i] not in used:
+                    lines.append(f"OUTPUT({names[i]})")
+                    used.add(names[i])
+        elif reach.any():
+            pis = np.nonzero(types == PI)[0].tolist()
+            for i in pis[:max(1, min(2, len(pis)))]:
+                if names[i] not in used:
+                    lines.append(f"OUTPUT({names[i]})")
+                    used.add(names[i])
+    return "\n".join(lines + body)
+
+
+def pt_to_bench(pt_path: str, out_path: str, verbose: bool = True) -> None:
+    """``utilities/pt2bench.py:216`` - same arguments, same file content."""
+    from .dataset import _read, _to_graph
+    data = _to_graph(_read(pt_path))
+    text = bench_text_with_inverters(data, os.path.basename(pt_path))
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    with open(out_path, "w") as f:
+        f.write(text)
+    if verbose:
+        ands = sum(" = AND(" in ln for ln in text.splitlines())
+        outs = sum(ln.startswith("OUTPUT(") for ln in text.splitlines())
+        print(f"[INFO] Saved .bench: {out_path} (nodes={int(data.x.size(0))}, outputs={outs}, ANDs={ands})")

@@ -77,3 +77,41 @@ def test_graphml_file_chain_gives_the_same_text(key, tmp_path):
     pt_to_graphml(str(tmp_path / "g.pt"), str(tmp_path / "g.graphml"), verbose=False)
     convert_graphml_to_bench(str(tmp_path / "g.graphml"), str(tmp_path / "g.bench"))
     assert (tmp_path / "g.bench").read_text() == TEXT[key]
+
+
+# ------------------------------------------------------------------ direct exporter (pt2bench.pt_to_bench)
+DIRECT = _G["direct"]
+
+
+def _graph_direct(key):
+    parts = key.split("|")
+    name, which = parts[0], parts[1] if len(parts) > 1 else ""
+    if name.startswith("extra_"):
+        return _graph(key)
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if which == "rs":
+        d = Data(x=torch.from_numpy(z["rs_x"]), edge_index=torch.from_numpy(z["enf_edge_index"]),
+                 edge_attr=torch.from_numpy(z["enf_edge_attr"]))
+        d.node_depth = torch.from_numpy(z["rs_node_depth"])
+        return d
+    d = _graph("|".join(parts[:2]))
+    pre = {"in": "", "enf": "enf_", "out": "", "padded": "pad_", "plain": ""}[which]
+    if "nodepth" not in parts and (pre + "node_depth") in z.files:
+        d.node_depth = torch.from_numpy(z[pre + "node_depth"])
+    return d
+
+
+@pytest.mark.parametrize("key", sorted(DIRECT))
+def test_direct_exporter_matches_reference(key):
+    from gan_amd.export import bench_text_with_inverters
+    assert bench_text_with_inverters(_graph_direct(key), "g.pt") == DIRECT[key]
+
+
+def test_direct_exporter_file(tmp_path):
+    from utilities.pt2bench import pt_to_bench
+    key = "cons_valid_fwd|enf"
+    g = _graph_direct(key)
+    torch.save({"x": g.x, "edge_index": g.edge_index, "edge_attr": g.edge_attr, "node_depth": g.node_depth},
+               str(tmp_path / "g.pt"))
+    pt_to_bench(str(tmp_path / "g.pt"), str(tmp_path / "o" / "g.bench"), verbose=False)
+    assert (tmp_path / "o" / "g.bench").read_text() == DIRECT[key]
