@@ -98,7 +98,7 @@ size_t sort_temp_bytes(int64_t E, int bits) {
     return bytes;
 }
 
-constexpr int SEG = 32;  // edges per by-source segment: long fan-out lists are cut into pieces of this size
+constexpr int SEG = 32;   // edges per by-source segment: long fan-out lists are cut into pieces of this size
 
 // number of segments of node j's out-edge list (at least one, so every node owns a segment)
 __global__ void k_seg_count(int n, const int* __restrict__ col_ptr, int* __restrict__ nch) {
@@ -579,34 +579,33 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
         const int4 d = seg_desc[sgm];
         const int j = d.x, beg = d.y, cnt = d.z - d.y, nsg = d.w;
         const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
-        // lane k: edge k of the segment (position in the by-target order, target id); a segment
-        // with no edge belongs to a node without out-edges and reads nothing
-        const bool on = l < cnt;
-        const int q = on ? beg + l : 0;
-        int p = 0, dst = j;
-        float4 al = zero4, dr = zero4;
-        if (cnt > 0) {
+        // lane k: edge k of a 32-edge piece of the segment (position in the by-target order, target
+        // id); a segment with no edge belongs to a node without out-edges and reads nothing
+        float4 acc = zero4, dr = zero4;
+        for (int c0 = 0; c0 < cnt; c0 += 32) {
+            const bool on = c0 + l < cnt;
+            const int q = on ? beg + c0 + l : beg;
             const int pv = csc_pos[q], dv = csc_dst[q];
-            p = on ? pv : 0;
-            dst = on ? dv : j;
+            const int p = on ? pv : 0;
+            const int dst = on ? dv : j;
             const float4 alv = alpha_e4[p], drv = d_raw_e4[p];
-            al = on ? alv : zero4;
-            dr = on ? drv : zero4;
+            const float4 al = on ? alv : zero4;
+            if (on) { dr.x += drv.x; dr.y += drv.y; dr.z += drv.z; dr.w += drv.w; }
+            *reinterpret_cast<float4*>(&s_alpha[hw][l][0]) = al;
+            __builtin_amdgcn_wave_barrier();
+            const int lim = min(32, cnt - c0);
+            for (int k0 = 0; k0 < lim; k0 += 4) {
+                const int t0 = __shfl(dst, k0, 32), t1 = __shfl(dst, k0 + 1, 32), t2 = __shfl(dst, k0 + 2, 32),
+                          t3 = __shfl(dst, k0 + 3, 32);
+                const float4 r0 = g4[(size_t)t0 * 32 + l], r1 = g4[(size_t)t1 * 32 + l], r2 = g4[(size_t)t2 * 32 + l],
+                             r3 = g4[(size_t)t3 * 32 + l];
+                axpy4(acc, s_alpha[hw][k0][h], r0);
+                axpy4(acc, s_alpha[hw][k0 + 1][h], r1);
+                axpy4(acc, s_alpha[hw][k0 + 2][h], r2);
+                axpy4(acc, s_alpha[hw][k0 + 3][h], r3);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        *reinterpret_cast<float4*>(&s_alpha[hw][l][0]) = al;
-        __builtin_amdgcn_wave_barrier();
-        float4 acc = zero4;
-        for (int k0 = 0; k0 < cnt; k0 += 4) {
-            const int t0 = __shfl(dst, k0, 32), t1 = __shfl(dst, k0 + 1, 32), t2 = __shfl(dst, k0 + 2, 32),
-                      t3 = __shfl(dst, k0 + 3, 32);
-            const float4 r0 = g4[(size_t)t0 * 32 + l], r1 = g4[(size_t)t1 * 32 + l], r2 = g4[(size_t)t2 * 32 + l],
-                         r3 = g4[(size_t)t3 * 32 + l];
-            axpy4(acc, s_alpha[hw][k0][h], r0);
-            axpy4(acc, s_alpha[hw][k0 + 1][h], r1);
-            axpy4(acc, s_alpha[hw][k0 + 2][h], r2);
-            axpy4(acc, s_alpha[hw][k0 + 3][h], r3);
-        }
-        __builtin_amdgcn_wave_barrier();
         const float4 das4 = halfwave_reduce(dr, cnt > 4, SumOp());
         if (nsg == 1) {
             src_finish(j, l, acc, pick(das4, h), f, v, d_xw, ps, pd);
@@ -878,9 +877,8 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
                        csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial);
     AIG_LAUNCH_CHECK();
     // bias gradient = first H columns, edge-coefficient gradient = last HEADS columns
-    hipLaunchKernelGGL(k_reduce_cols, dim3(H + HEADS), dim3(256), 0, s, g, H + HEADS, partial, partial + (size_t)g * (H + HEADS));
-    AIG_HIP_CHECK(hipMemcpyAsync(d_bias, partial + (size_t)g * (H + HEADS), H * 4, hipMemcpyDeviceToDevice, s));
-    AIG_HIP_CHECK(hipMemcpyAsync(d_ce, partial + (size_t)g * (H + HEADS) + H, HEADS * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, g, H + HEADS, partial, d_bias);
+    hipLaunchKernelGGL(k_reduce_cols, dim3(HEADS), dim3(256), 0, s, g, H + HEADS, partial + H, d_ce);
     const int gs = grid_blocks((int64_t)nseg_max);
     hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
                        reinterpret_cast<const int4*>(seg_desc), csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e,
@@ -888,9 +886,8 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     hipLaunchKernelGGL(k_gat_bwd_src_heavy, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
                        alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();
-    float* red = partial + (size_t)(gs + g) * 2 * H;
-    hipLaunchKernelGGL(k_reduce_cols, dim3(2 * H), dim3(256), 0, s, gs + g, 2 * H, partial, red);
-    AIG_HIP_CHECK(hipMemcpyAsync(d_att_src, red, H * 4, hipMemcpyDeviceToDevice, s));
-    AIG_HIP_CHECK(hipMemcpyAsync(d_att_dst, red + H, H * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, gs + g, 2 * H, partial, d_att_src);
+    hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, gs + g, 2 * H, partial + H, d_att_dst);
+    AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
