@@ -564,7 +564,8 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
     const int* __restrict__ csc_pos, const int* __restrict__ csc_dst, const float* __restrict__ alpha_e,
     const float* __restrict__ alpha_loop, const float* __restrict__ d_raw_e, const float* __restrict__ d_raw_loop,
     const float* __restrict__ d_a_d, float* __restrict__ d_xw, float* __restrict__ part_acc /*[nseg][H]*/,
-    float* __restrict__ part_das /*[nseg][HEADS]*/, float* __restrict__ partial /*[grid][2H]*/) {
+    float* __restrict__ part_das /*[nseg][HEADS]*/, int* __restrict__ part_flag /*[nseg]*/,
+    float* __restrict__ partial /*[grid][2H]*/) {
     __shared__ float s_alpha[HW_PER_BLOCK][32][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
     SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
@@ -575,6 +576,20 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
     const float4 zero4 = ps;
     const int nseg = seg_base[n];
     NodeRange r = block_nodes(nseg);   // a contiguous range of segments per block, XCD-grouped
+    // A half-wave that meets several segments of one long list in a row adds them up and leaves ONE
+    // partial row (in the slot of the first of them, part_flag = 1; the other slots get flag 0),
+    // so a list of thousands of segments leaves a few hundred rows for k_gat_bwd_src_heavy.
+    int run_owner = -1, run_slot = 0;
+    float4 run_acc = zero4, run_das = zero4;
+    auto flush = [&]() {
+        if (run_owner < 0) return;
+        reinterpret_cast<float4*>(part_acc + (size_t)run_slot * H)[l] = run_acc;
+        if (l == 0) {
+            reinterpret_cast<float4*>(part_das)[run_slot] = run_das;
+            part_flag[run_slot] = 1;
+        }
+        run_owner = -1;
+    };
     for (int sgm = r.begin + hw; sgm < r.end; sgm += HW_PER_BLOCK) {
         const int4 d = seg_desc[sgm];
         const int j = d.x, beg = d.y, cnt = d.z - d.y, nsg = d.w;
@@ -609,11 +624,19 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
         const float4 das4 = halfwave_reduce(dr, cnt > 4, SumOp());
         if (nsg == 1) {
             src_finish(j, l, acc, pick(das4, h), f, v, d_xw, ps, pd);
+        } else if (j == run_owner) {
+            run_acc.x += acc.x; run_acc.y += acc.y; run_acc.z += acc.z; run_acc.w += acc.w;
+            run_das.x += das4.x; run_das.y += das4.y; run_das.z += das4.z; run_das.w += das4.w;
+            if (l == 0) part_flag[sgm] = 0;
         } else {
-            reinterpret_cast<float4*>(part_acc + (size_t)sgm * H)[l] = acc;
-            if (l == 0) reinterpret_cast<float4*>(part_das)[sgm] = das4;
+            flush();
+            run_owner = j;
+            run_slot = sgm;
+            run_acc = acc;
+            run_das = das4;
         }
     }
+    flush();
     block_partial_2h(ps, pd, partial);
 }
 
@@ -624,7 +647,8 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
     int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
     const float* __restrict__ att_dst, const int* __restrict__ seg_base, const float* __restrict__ alpha_loop,
     const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, const float* __restrict__ part_acc,
-    const float* __restrict__ part_das, float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
+    const float* __restrict__ part_das, const int* __restrict__ part_flag, float* __restrict__ d_xw,
+    float* __restrict__ partial /*[grid][2H]*/) {
     __shared__ int s_list[THREADS];
     __shared__ int s_wcnt[THREADS / 64];
     __shared__ float s_acc[HW_PER_BLOCK][H];
@@ -655,25 +679,39 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
             const int first = seg_base[j], nsg = seg_base[j + 1] - first;
             float das = 0.f;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int k = hw;
-            for (; k + 3 * HW_PER_BLOCK < nsg; k += 4 * HW_PER_BLOCK) {
-                const float4 a0 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k) * H)[l];
-                const float4 a1 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k + HW_PER_BLOCK) * H)[l];
-                const float4 a2 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k + 2 * HW_PER_BLOCK) * H)[l];
-                const float4 a3 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k + 3 * HW_PER_BLOCK) * H)[l];
-                const float d0 = part_das[(size_t)(first + k) * HEADS + h];
-                const float d1 = part_das[(size_t)(first + k + HW_PER_BLOCK) * HEADS + h];
-                const float d2 = part_das[(size_t)(first + k + 2 * HW_PER_BLOCK) * HEADS + h];
-                const float d3 = part_das[(size_t)(first + k + 3 * HW_PER_BLOCK) * HEADS + h];
-                acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w; das += d0;
-                acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w; das += d1;
-                acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w; das += d2;
-                acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w; das += d3;
-            }
-            for (; k < nsg; k += HW_PER_BLOCK) {
-                const float4 a0 = reinterpret_cast<const float4*>(part_acc + (size_t)(first + k) * H)[l];
-                acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
-                das += part_das[(size_t)(first + k) * HEADS + h];
+            // lane q of a half-wave looks at the flag of one slot; rows exist only where it is set
+            for (int k0 = hw * 32; k0 < nsg; k0 += HW_PER_BLOCK * 32) {
+                const int slot = k0 + l;
+                const bool has = slot < nsg && part_flag[first + slot] != 0;
+                unsigned m = (unsigned)(__ballot(has) >> (threadIdx.x & 32));   // this half-wave's 32 flags
+                while (m) {
+                    // up to four rows in flight
+                    int q[4];
+                    int cntq = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        q[u] = -1;
+                        if (m) {
+                            q[u] = __ffs((int)m) - 1;
+                            m &= m - 1;
+                            ++cntq;
+                        }
+                    }
+                    float4 a[4];
+                    float dd[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const size_t sl = (size_t)(first + k0 + (q[u] >= 0 ? q[u] : q[0]));
+                        a[u] = reinterpret_cast<const float4*>(part_acc + sl * H)[l];
+                        dd[u] = part_das[sl * HEADS + h];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < cntq) {
+                            acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w;
+                            das += dd[u];
+                        }
+                }
             }
             reinterpret_cast<float4*>(&s_acc[hw][0])[l] = acc;
             if ((l & 7) == 0) s_das[hw][h] = das;
@@ -836,7 +874,7 @@ extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const f
 extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {
     size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1), nseg = N + M / SEG + 1;
     return align_up(N * H * 4) /*g_pre*/ + align_up(M * HEADS * 4) + 2 * align_up(N * HEADS * 4) +
-           align_up(nseg * H * 4) + align_up(nseg * HEADS * 4) + align_up((size_t)4097 * 2 * H * 4) + 256;
+           align_up(nseg * H * 4) + align_up(nseg * HEADS * 4) + align_up(nseg * 4) + align_up((size_t)4097 * 2 * H * 4) + 256;
 }
 
 extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
@@ -871,6 +909,7 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     const size_t nseg_max = (size_t)n + (size_t)(E > 0 ? E : 1) / SEG + 1;
     float* part_acc = c.take<float>(nseg_max * H);
     float* part_das = c.take<float>(nseg_max * HEADS);
+    int* part_flag = c.take<int>(nseg_max);
     float* partial = c.take<float>((size_t)4097 * 2 * H);
     const int g = grid_blocks(n);
     hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
@@ -882,9 +921,9 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     const int gs = grid_blocks((int64_t)nseg_max);
     hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
                        reinterpret_cast<const int4*>(seg_desc), csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e,
-                       d_raw_loop, d_a_d, d_xw, part_acc, part_das, partial);
+                       d_raw_loop, d_a_d, d_xw, part_acc, part_das, part_flag, partial);
     hipLaunchKernelGGL(k_gat_bwd_src_heavy, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
-                       alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, d_xw, partial + (size_t)gs * 2 * H);
+                       alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, part_flag, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, gs + g, 2 * H, partial, d_att_src);
     hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, gs + g, 2 * H, partial + H, d_att_dst);
