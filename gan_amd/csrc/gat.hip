@@ -674,26 +674,22 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
         }
         if (heavy) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c;
         __syncthreads();
-        for (int t = 0; t < m; ++t) {
-            const int j = s_list[t];
-            const int first = seg_base[j], nsg = seg_base[j + 1] - first;
-            float das = 0.f;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            // lane q of a half-wave looks at the flag of one slot; rows exist only where it is set
-            for (int k0 = hw * 32; k0 < nsg; k0 += HW_PER_BLOCK * 32) {
+        // rows of node j in slots k_begin, k_begin + 32, ... (step k_step) of its list, added in slot
+        // order; lane q of the half-wave looks at the flag of one slot, rows exist only where it is set
+        auto sum_slots = [&](int first, int nsg, int k_begin, int k_step, float4& acc, float& das) {
+            for (int k0 = k_begin; k0 < nsg; k0 += k_step) {
                 const int slot = k0 + l;
                 const bool has = slot < nsg && part_flag[first + slot] != 0;
-                unsigned m = (unsigned)(__ballot(has) >> (threadIdx.x & 32));   // this half-wave's 32 flags
-                while (m) {
-                    // up to four rows in flight
-                    int q[4];
+                unsigned mk = (unsigned)(__ballot(has) >> (threadIdx.x & 32));   // this half-wave's 32 flags
+                while (mk) {
+                    int q[4];   // up to four rows in flight
                     int cntq = 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         q[u] = -1;
-                        if (m) {
-                            q[u] = __ffs((int)m) - 1;
-                            m &= m - 1;
+                        if (mk) {
+                            q[u] = __ffs((int)mk) - 1;
+                            mk &= mk - 1;
                             ++cntq;
                         }
                     }
@@ -713,6 +709,26 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
                         }
                 }
             }
+        };
+        // lists of at most 32 segments: one half-wave per node, no barrier
+        for (int t = hw; t < m; t += HW_PER_BLOCK) {
+            const int j = s_list[t];
+            const int first = seg_base[j], nsg = seg_base[j + 1] - first;
+            if (nsg > 32) continue;
+            float das = 0.f;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            sum_slots(first, nsg, 0, 32, acc, das);
+            const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
+            src_finish(j, l, acc, das, f, v, d_xw, ps, pd);
+        }
+        // longer lists: the whole block per node
+        for (int t = 0; t < m; ++t) {
+            const int j = s_list[t];
+            const int first = seg_base[j], nsg = seg_base[j + 1] - first;
+            if (nsg <= 32) continue;
+            float das = 0.f;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            sum_slots(first, nsg, hw * 32, HW_PER_BLOCK * 32, acc, das);
             reinterpret_cast<float4*>(&s_acc[hw][0])[l] = acc;
             if ((l & 7) == 0) s_das[hw][h] = das;
             __syncthreads();
