@@ -302,18 +302,116 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
     x_out[2 * v + 1] = static_cast<float>(invs);
 }
 
+// The same scores with the candidate rows staged in LDS.  The candidate set of slot r+1 is the set of
+// slot r plus at most the node processed at r, so T consecutive slots only ever touch the rows of
+// cand[r0] and of order[r0 .. r0+T-2]: K+T-1 rows per block instead of K*T gathered rows from L2.
+// A candidate that was processed inside the block's range (rank >= r0, r0 = the block's first scored
+// slot) sits at row K + rank - r0, any other one is found in the ascending id list of slot r0.  Same per-pair arithmetic (one fmaf chain
+// over the 128 channels in order), hence bit-identical logits.
+constexpr int SCORE_T = 64;        // slots per block
+constexpr int SCORE_THREADS = 1024; // sixteen waves share one tile: the per-pair chains are latency-bound
+constexpr int SCORE_LD = H + 4;    // padded row: lanes read different rows at the same column
+
+__global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, const int* __restrict__ order,
+                                                     const int* __restrict__ rank, const int* __restrict__ cnt,
+                                                     const int* __restrict__ cand, const float* __restrict__ A,
+                                                     const float* __restrict__ B, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tile = reinterpret_cast<float*>(smem);                     // [K + SCORE_T][SCORE_LD]
+    int* ids = reinterpret_cast<int*>(tile + (size_t)(K + SCORE_T) * SCORE_LD);   // [K] ascending ids of slot r0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = tid & 31, hw = tid >> 5;
+    // base slot: the first slot of the block that is scored at all (a slot that is not a target has
+    // cnt = 0 and no candidate list)
+    __shared__ int s_base;
+    if (tid < 64) {
+        const int rr = blockIdx.x * SCORE_T + tid;
+        const unsigned long long m = __ballot(rr < n && cnt[rr] > 0);
+        if (tid == 0) s_base = m ? blockIdx.x * SCORE_T + (__ffsll((long long)m) - 1) : -1;
+    }
+    __syncthreads();
+    const int r0 = s_base;
+    if (r0 < 0) return;
+    const int r_end = min(n, (int)(blockIdx.x + 1) * SCORE_T);
+    const int c0 = cnt[r0];
+    const size_t row00 = (size_t)r0 * K;
+    for (int i = tid; i < c0; i += SCORE_THREADS) ids[i] = cand[row00 + i];
+    // rows: [0, c0) = candidates of slot r0, [K, K + T - 1) = nodes processed at r0 .. r0 + T - 2
+    for (int row = hw; row < K + SCORE_T - 1; row += SCORE_THREADS / 32) {
+        int node = -1;
+        if (row < c0) node = cand[row00 + row];
+        else if (row >= K && r0 + row - K < r_end) node = order[r0 + row - K];
+        if (node >= 0)
+            *reinterpret_cast<float4*>(tile + (size_t)row * SCORE_LD + 4 * l) =
+                reinterpret_cast<const float4*>(A + (size_t)node * H)[l];
+    }
+    __syncthreads();
+    const float4* W = reinterpret_cast<const float4*>(w2);
+    const float bias = b2[0];
+    for (int r = r0 + wave; r < r_end; r += SCORE_THREADS / 64) {
+        const int c = cnt[r];
+        if (c <= 0) continue;
+        const int v = __builtin_amdgcn_readfirstlane(order[r]);
+        const float4* Bv = reinterpret_cast<const float4*>(B + (size_t)v * H);
+        const size_t row0 = (size_t)r * K;
+        for (int base = 0; base < c; base += 64) {
+            const int i = base + lane;
+            const bool active = i < c;
+            const int ci = cand[row0 + (active ? i : 0)];
+            const int rk = rank[ci];
+            int row;
+            if (rk >= r0) {
+                row = K + rk - r0;
+            } else {  // first position of the slot-r0 list holding ci
+                int lo = 0, hi = c0;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ids[mid] < ci) lo = mid + 1; else hi = mid;
+                }
+                row = lo;
+            }
+            const float4* Ar = reinterpret_cast<const float4*>(tile + (size_t)row * SCORE_LD);
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < H / 4; ++j) {
+                float4 a = Ar[j], b = Bv[j], w = W[j];
+                acc = fmaf(fmaxf(a.x + b.x, 0.f), w.x, acc);
+                acc = fmaf(fmaxf(a.y + b.y, 0.f), w.y, acc);
+                acc = fmaf(fmaxf(a.z + b.z, 0.f), w.z, acc);
+                acc = fmaf(fmaxf(a.w + b.w, 0.f), w.w, acc);
+            }
+            if (active) logits[row0 + i] = acc + bias;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace aig
 
 using namespace aig;
 
-extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* cnt, const int32_t* cand,
-                             const float* projA, const float* projB, const float* w2, const float* b2,
-                             float* logits, void* stream) {
+extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt,
+                             const int32_t* cand, const float* projA, const float* projB, const float* w2,
+                             const float* b2, float* logits, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1, "aig_gen_score: bad sizes n=%lld K=%lld", (long long)n, (long long)K);
     if (n == 0) return AIG_OK;
-    AIG_REQUIRE(order && cnt && cand && projA && projB && w2 && b2 && logits, "aig_gen_score: null pointer");
+    AIG_REQUIRE(order && rank && cnt && cand && projA && projB && w2 && b2 && logits, "aig_gen_score: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (K <= 128) {
+        const size_t lds = (size_t)(K + SCORE_T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
+        static size_t lds_allowed = 0;   // raising the dynamic LDS limit is idempotent
+        if (lds > lds_allowed) {
+            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_tiled),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_allowed = lds;
+        }
+        const int64_t tb = (n + SCORE_T - 1) / SCORE_T;
+        hipLaunchKernelGGL(k_score_tiled, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, order, rank, cnt, cand,
+                           projA, projB, w2, b2, logits);
+        AIG_LAUNCH_CHECK();
+        return AIG_OK;
+    }
     int64_t blocks = (n * 64 + 255) / 256;
     hipLaunchKernelGGL(k_score, dim3((unsigned)blocks), dim3(256), 0, s, (int)n, (int)K, order, cnt, cand, projA, projB,
                        w2, b2, logits);

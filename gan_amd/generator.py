@@ -150,7 +150,7 @@ class AIGGenerator(nn.Module):
         logits = torch.empty((max(n, 1), K), **f32)
         if return_debug:
             logits.fill_(float("nan"))
-        _abi.check(_abi.timed("aig_gen_score", lib.aig_gen_score, n, K, _abi.ptr(plan.order), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
+        _abi.check(_abi.timed("aig_gen_score", lib.aig_gen_score, n, K, _abi.ptr(plan.order), _abi.ptr(plan.rank), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
                                      _abi.ptr(proj[0]), _abi.ptr(proj[1]), _abi.ptr(self.edge_scorer[2].weight),
                                      _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), "aig_gen_score")
         sel = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)

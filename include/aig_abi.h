@@ -95,7 +95,7 @@ int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_w
 
 /* Candidate scores - models/generator.py:84-99 (_score_candidates + edge_scorer):
  *   logits[r*K + i] = w2 . relu(projA[cand[r*K+i]] + projB[order[r]]) + b2,   i < cnt[r] */
-int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* cnt, const int32_t* cand,
+int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt, const int32_t* cand,
                   const float* projA, const float* projB, const float* w2, const float* b2,
                   float* logits, void* stream);
 
