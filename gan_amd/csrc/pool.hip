@@ -92,22 +92,44 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* 
         atomicMax(t + 2, pack_max(mx.z, mi.z));
         atomicMax(t + 3, pack_max(mx.w, mi.w));
     };
-    for (int p = p0; p < p1; ++p) {
-        const int i = perm[p];
-        const int lev = node_level[i];
-        const float wi = w[i];
-        const float4 v = reinterpret_cast<const float4*>(h + (size_t)i * H)[l];
-        sum.x += wi * v.x; sum.y += wi * v.y; sum.z += wi * v.z; sum.w += wi * v.w;
-        if (lev != cur) {
-            if (cur >= 0) flush();
-            cur = lev;
-            mx = v;
-            mi = make_int4(i, i, i, i);
-        } else {  // rows of a level arrive by ascending node id: strict > keeps the first maximum
-            if (v.x > mx.x) { mx.x = v.x; mi.x = i; }
-            if (v.y > mx.y) { mx.y = v.y; mi.y = i; }
-            if (v.z > mx.z) { mx.z = v.z; mi.z = i; }
-            if (v.w > mx.w) { mx.w = v.w; mi.w = i; }
+    // lane q fetches the index, level and weight of row q of the item (one coalesced load, two
+    // gathers); the rows themselves then come four at a time
+    const int pq = p0 + l;
+    const bool onq = pq < p1;
+    const int iq = onq ? perm[pq] : 0;
+    const int levq = onq ? node_level[iq] : -1;
+    const float wq = onq ? w[iq] : 0.f;
+    const int nrows = p1 - p0;
+    for (int k0 = 0; k0 < nrows; k0 += 4) {
+        int ii[4], lv[4];
+        float ww[4];
+        float4 vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u, nrows - 1);
+            ii[u] = __shfl(iq, k, 32);
+            lv[u] = __shfl(levq, k, 32);
+            ww[u] = __shfl(wq, k, 32);
+            vv[u] = reinterpret_cast<const float4*>(h + (size_t)ii[u] * H)[l];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u >= nrows) break;
+            const int i = ii[u], lev = lv[u];
+            const float wi = ww[u];
+            const float4 v = vv[u];
+            sum.x += wi * v.x; sum.y += wi * v.y; sum.z += wi * v.z; sum.w += wi * v.w;
+            if (lev != cur) {
+                if (cur >= 0) flush();
+                cur = lev;
+                mx = v;
+                mi = make_int4(i, i, i, i);
+            } else {  // rows of a level arrive by ascending node id: strict > keeps the first maximum
+                if (v.x > mx.x) { mx.x = v.x; mi.x = i; }
+                if (v.y > mx.y) { mx.y = v.y; mi.y = i; }
+                if (v.z > mx.z) { mx.z = v.z; mi.z = i; }
+                if (v.w > mx.w) { mx.w = v.w; mi.w = i; }
+            }
         }
     }
     if (cur >= 0) flush();
