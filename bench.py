@@ -121,7 +121,7 @@ def main():
     rank, local_rank, world = parallel.init_distributed()
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))   # (modulo: rehearsals on fewer GPUs)
     torch.cuda.set_device(dev)
     torch.manual_seed(123)
 

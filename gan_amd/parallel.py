@@ -27,7 +27,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm; AIG_DIST_BACKEND=gloo lets several ranks rehearse on one GPU
+            backend = os.environ.get("AIG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

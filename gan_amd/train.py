@@ -155,7 +155,8 @@ class CapturedCriticTerms:
                        if real_for_D.edge_index.numel() > 0 else None,
                        D.level_plan(real_for_D.node_depth, n, device), D.level_plan(real_pad.node_depth, n, device))
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture: a communicator's watchdog thread may query events while we record
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.d_real, self.gp, self.grad_norm, self.grads = compute()
         self.params = [p for p, g in zip(params, self.grads) if g is not None]
         self.grads = [g for g in self.grads if g is not None]
