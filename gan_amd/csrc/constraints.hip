@@ -92,6 +92,7 @@ __global__ void k_segment_ptr(int n, int E, const K* __restrict__ skey, K scale,
 //   MODE 0: breadth-first levels; depth[] preset to 0 on the sources and -1 elsewhere.
 //   MODE 1: Kahn peel; state[] = indegree, every node released in the round after its last
 //           predecessor, so depth = longest-path level; *popped counts released nodes.
+//           (state[] is scratch: it is counted down in place or left as it was.)
 // Every wave leaves through the same `break` (the frontier size is read between two barriers),
 // and the loop ends after at most n rounds because a node enters a queue at most once.
 constexpr int HEAVY_DEG = 256;   // adjacency lists longer than this are expanded by the whole block
@@ -190,7 +191,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs)
 // holds a few hundred nodes, so a level-synchronous walk is a chain of dependent memory accesses
 // and nothing else.  Here
 //   - the frontier queues live in LDS (entries beyond TRAV_QCAP spill to the global queues),
-//   - MODE 0 keeps its visited set as a bitmap in LDS (test-and-set there; depth[] is only stored),
+//   - MODE 0 keeps its visited set as a bitmap in LDS (test-and-set there; depth[] is only stored);
+//     MODE 1 keeps the in-degree counters in LDS as bytes while n <= TRAV_KAHN_LDS_MAX_N and no
+//     in-degree exceeds 255 (global atomics otherwise),
 //   - the adjacency header of a node and its first two neighbours come in one 16-byte record,
 //   - two barriers per level (three rotating counters): frontier nodes take the two neighbours
 //     that came with their record, longer lists are set aside and walked by a wave or the block,
@@ -198,10 +201,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs)
 // Used while the bitmap fits (n <= TRAV_LDS_MAX_N); larger graphs take k_traverse.
 constexpr int TRAV_QCAP = 2048;
 constexpr int TRAV_LDS_MAX_N = 1 << 20;
+constexpr int TRAV_KAHN_LDS_MAX_N = 1 << 17;  // Kahn: one byte of LDS per node for the in-degree counters
 constexpr int TRAV_BIG_CAP = 960;   // adjacency lists set aside per level for a wave each
 constexpr int TRAV_HEAVY_CAP = 32;  // ... and for the whole block (beyond either: walked in place)
 
-// {first, one past last, neighbour 0, neighbour 1} of every node's adjacency list
+// {first, one past last, neighbour 0, neighbour 1} of every node's adjacency list.  (A longer
+// record with more neighbours inline was measured slower: the records of a 100k-node graph then
+// span 6.4 MB instead of 1.6 MB, and the per-level dependent load pays for it.)
 __global__ void k_node_rec(int n, const int* __restrict__ ptr, const int* __restrict__ adj, int4* __restrict__ rec) {
     for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
         const int b = ptr[u], e = ptr[u + 1];
@@ -210,7 +216,8 @@ __global__ void k_node_rec(int n, const int* __restrict__ ptr, const int* __rest
 }
 
 struct TravLds {
-    unsigned* bits;  // MODE 0 only
+    unsigned* bits;  // MODE 0: visited bitmap; MODE 1: in-degree counters, one byte per node (see lds_cnt)
+    bool lds_cnt;    // MODE 1: the counters live in LDS (every in-degree <= 255 and n small enough)
     unsigned* dummy; // 64 scratch words
     int* lq;         // two LDS queues of TRAV_QCAP entries, back to back
     int* gq0;        // their global spill areas
@@ -225,8 +232,10 @@ __device__ __forceinline__ void q_put(const TravLds& t, int which, int idx, int 
     else if (which) t.gq1[idx - TRAV_QCAP] = v;
     else t.gq0[idx - TRAV_QCAP] = v;
 }
-__device__ __forceinline__ int q_get(const TravLds& t, int which, int idx) {
-    if (idx < TRAV_QCAP) return t.lq[which * TRAV_QCAP + idx];
+// Readers walk the LDS part and the spilled part of a queue in two loops of their own (a single
+// loop with a branch per entry is merged back into one flat load by the compiler).
+__device__ __forceinline__ int q_get_lds(const TravLds& t, int which, int idx) { return t.lq[which * TRAV_QCAP + idx]; }
+__device__ __forceinline__ int q_get_spill(const TravLds& t, int which, int idx) {
     return which ? t.gq1[idx - TRAV_QCAP] : t.gq0[idx - TRAV_QCAP];
 }
 
@@ -239,6 +248,9 @@ __device__ __forceinline__ void visit_lds(int v, const TravLds& t, int nx, int n
         const unsigned m = 1u << (v & 31);
         if (t.bits[v >> 5] & m) return;  // peek: a popular node is claimed once and then only read
         if (atomicOr(&t.bits[v >> 5], m) & m) return;
+    } else if (t.lds_cnt) {
+        const int sh = 8 * (v & 3);
+        if (((atomicSub(&t.bits[v >> 2], 1u << sh) >> sh) & 255u) != 1u) return;
     } else {
         if (atomicSub(&state[v], 1) != 1) return;
     }
@@ -264,6 +276,15 @@ __device__ __forceinline__ void visit2_lds(int self, int v0, bool on0, int v1, b
         const unsigned o0 = atomicOr(q0, a0), o1 = atomicOr(q1, a1);
         c0 = (a0 & ~o0) != 0u;
         c1 = (a1 & ~o1) != 0u;
+    } else if (t.lds_cnt) {
+        // byte counters in LDS: the decrement of byte b of a word is a subtraction of 1 << 8b (a
+        // counter never goes below zero, so no borrow reaches its neighbour)
+        unsigned* const dummy = t.dummy + (threadIdx.x & 63);
+        const int s0 = 8 * (v0 & 3), s1 = 8 * (v1 & 3);
+        const unsigned o0 = atomicSub(on0 ? &t.bits[v0 >> 2] : dummy, on0 ? 1u << s0 : 0u);
+        const unsigned o1 = atomicSub(on1 ? &t.bits[v1 >> 2] : dummy, on1 ? 1u << s1 : 0u);
+        c0 = on0 && ((o0 >> s0) & 255u) == 1u;
+        c1 = on1 && ((o1 >> s1) & 255u) == 1u;
     } else {
         // both counter updates in flight together; an absent neighbour subtracts 0 from the
         // expanding node's own (already released) counter, a distinct address per lane
@@ -272,9 +293,14 @@ __device__ __forceinline__ void visit2_lds(int self, int v0, bool on0, int v1, b
         c0 = on0 && o0 == 1;
         c1 = on1 && o1 == 1;
     }
-    const int k = (int)c0 + (int)c1;
-    if (k) {
-        const int base = atomicAdd(&t.cnt[ncnt], k);
+    // queue slots for the whole wave with one counter update (a per-lane update with differing
+    // amounts is turned by the compiler into a loop over the active lanes)
+    const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1);
+    if (b0 | b1) {
+        const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+        int base = 0;
+        if ((__ballot(1) & below) == 0ull) base = atomicAdd(&t.cnt[ncnt], __popcll(b0) + __popcll(b1));
+        base = __builtin_amdgcn_readfirstlane(base) + __popcll(b0 & below) + __popcll(b1 & below);
         if (c0) q_put(t, nx, base, v0);
         if (c1) q_put(t, nx, base + (int)c0, v1);
     }
@@ -295,17 +321,38 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
     __shared__ int2 s_big[TRAV_BIG_CAP], s_heavy[TRAV_HEAVY_CAP];
     __shared__ unsigned s_dummy[64];
     const int tid = threadIdx.x;
-    const int nwords = MODE == 0 ? (n + 31) >> 5 : 0;
+    __shared__ int s_wide;
+    const int nwords = MODE == 0 ? (n + 31) >> 5 : (n <= TRAV_KAHN_LDS_MAX_N ? (n + 3) >> 2 : 0);
     TravLds t;
     t.bits = reinterpret_cast<unsigned*>(smem);
+    t.lds_cnt = false;
     t.dummy = s_dummy;
     t.lq = smem + nwords;
     t.gq0 = jb.q0;
     t.gq1 = jb.q1;
     t.cnt = s_cnt;
-    if (tid == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; s_total = 0; s_nbig[0] = s_nbig[1] = 0; s_nheavy[0] = s_nheavy[1] = 0; }
-    for (int w = tid; w < nwords; w += TRAV_THREADS) t.bits[w] = 0u;
+    if (tid == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; s_total = 0; s_nbig[0] = s_nbig[1] = 0; s_nheavy[0] = s_nheavy[1] = 0; s_wide = 0; }
+    if (MODE == 0) {
+        for (int w = tid; w < nwords; w += TRAV_THREADS) t.bits[w] = 0u;
+    } else {
+        // Kahn: the in-degree counters go to LDS, four to a word, unless one of them needs more than a byte
+        __syncthreads();
+        bool wide = false;
+        for (int w = tid; w < nwords; w += TRAV_THREADS) {
+            unsigned word = 0u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = 4 * w + b;
+                const int d = i < n ? state[i] : 0;
+                wide |= d > 255 || d < 0;
+                word |= ((unsigned)d & 255u) << (8 * b);
+            }
+            t.bits[w] = word;
+        }
+        if (wide) s_wide = 1;
+    }
     __syncthreads();
+    if (MODE == 1) t.lds_cnt = nwords > 0 && s_wide == 0;
     for (int i = tid; i < n; i += TRAV_THREADS) {
         bool start;
         if (MODE == 0) start = depth[i] == 0;
@@ -332,11 +379,12 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
         if (tid == 0) { s_cnt[(level + 2) % 3] = 0; s_total += c; s_nbig[nx] = 0; s_nheavy[nx] = 0; }
         // phase A: one thread per frontier node takes the two neighbours that came with the record;
         // a longer list is set aside so that a wave (or, when very long, the block) walks it
+        const int c_lds = min(c, TRAV_QCAP);
         if (writer) {
-            for (int idx = lane; idx < c; idx += 64) depth[q_get(t, cur, idx)] = level;
+            for (int idx = lane; idx < c_lds; idx += 64) depth[q_get_lds(t, cur, idx)] = level;
+            for (int idx = TRAV_QCAP + lane; idx < c; idx += 64) depth[q_get_spill(t, cur, idx)] = level;
         } else {
-            for (int idx = tid; idx < c; idx += EXPANDERS) {
-                const int u = q_get(t, cur, idx);
+            auto expand = [&](int u) {
                 const int4 r = rec[u];
                 const int deg = r.y - r.x;
                 visit2_lds<MODE>(u, r.z, deg > 0, r.w, deg > 1, t, nx, ncnt, state);
@@ -349,7 +397,9 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
                         for (int k = r.x + 2; k < r.y; ++k) visit_lds<MODE>(adj[k], t, nx, ncnt, state);
                     }
                 }
-            }
+            };
+            for (int idx = tid; idx < c_lds; idx += EXPANDERS) expand(q_get_lds(t, cur, idx));
+            for (int idx = TRAV_QCAP + tid; idx < c; idx += EXPANDERS) expand(q_get_spill(t, cur, idx));
         }
         __syncthreads();
         // phase B
@@ -387,7 +437,8 @@ int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* re
     const int g = (N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096;
     hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[0].ptr, jobs.j[0].adj, rec0);
     if (njobs > 1) hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[1].ptr, jobs.j[1].adj, rec1);
-    const size_t lds = (MODE == 0 ? (size_t)((N + 31) >> 5) * 4 : 0) + (size_t)2 * TRAV_QCAP * 4;
+    const size_t lds = (MODE == 0 ? (size_t)((N + 31) >> 5) * 4 : (N <= TRAV_KAHN_LDS_MAX_N ? (size_t)((N + 3) >> 2) * 4 : 0)) +
+                       (size_t)2 * TRAV_QCAP * 4;
     hipLaunchKernelGGL(k_traverse_lds<MODE>, dim3(njobs), dim3(TRAV_THREADS), lds, s, N, jobs, rec0, rec1);
     AIG_LAUNCH_CHECK();
     return AIG_OK;

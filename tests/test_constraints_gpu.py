@@ -85,7 +85,7 @@ def assert_same_graph(a: Data, b: Data):
 
 
 @pytest.mark.parametrize("n,e,depth_mode", [(300, 900, "long"), (5000, 30000, "float"), (20000, 50000, None),
-                                            (777, 40000, "long")])
+                                            (777, 40000, "long"), (300, 70000, None)])
 def test_constraints_match_checker_on_random_graphs(n, e, depth_mode):
     g = junk_graph(n, e, seed=n + e, depth_mode=depth_mode)
     pen = aig_constraint_penalties(to_dev(g))
@@ -123,6 +123,25 @@ def test_constraints_on_full_size_aig(orientation):
     fixed_ref = ocpu.enforce_aig_constraints(g.clone())
     assert_same_graph(enforce_aig_constraints(to_dev(g)), fixed_ref)
     assert_same_graph(resync_attrs(to_dev(g)), ocpu.resync_attrs(g.clone()))
+
+
+@pytest.mark.parametrize("fanin", [255, 256, 700])
+def test_kahn_depth_with_wide_fanin(fanin):
+    """An acyclic graph with one in-degree around / beyond what a byte counter holds: the Kahn sweep
+    (resync depths, cycle check of the validator) must not depend on where its counters live."""
+    n = fanin + 40
+    src = list(range(fanin)) + [fanin + i for i in range(39)] + [3, 5]
+    dst = [fanin] * fanin + [fanin + i + 1 for i in range(39)] + [fanin + 20, fanin + 20]
+    x = np.zeros((n, 2), np.float32)
+    x[fanin:, 0] = 2
+    x[-1, 0] = 1
+    rng = np.random.default_rng(fanin)
+    g = Data(x=torch.from_numpy(x), edge_index=torch.tensor([src, dst], dtype=torch.long),
+             edge_attr=torch.from_numpy(rng.integers(0, 2, len(src)).astype(np.int64)).view(-1, 1))
+    rs, ref = resync_attrs(to_dev(g)), ocpu.resync_attrs(g.clone())
+    assert int(ref.node_depth.max()) == 40
+    assert_same_graph(rs, ref)
+    assert validate_strict_aig(to_dev(g)) == ocpu.validate_strict_aig(g.clone())
 
 
 def test_empty_and_cpu_inputs():
