@@ -750,11 +750,25 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
     block_partial_2h(ps, pd, partial);
 }
 
-// out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree
-__global__ __launch_bounds__(256) void k_reduce_cols(int nb, int width, const float* __restrict__ partial,
-                                                     float* __restrict__ out) {
+// out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree.
+// One launch serves up to four such sums (the parameter gradients of one backward pass): block x
+// belongs to the first job whose column count it falls into.
+struct ColSum {
+    const float* partial;  // [nb][width], the job's first column at partial[0]
+    float* out;
+    int nb, width, cols;
+};
+struct ColSums {
+    ColSum j[4];
+};
+__global__ __launch_bounds__(256) void k_reduce_cols(ColSums jobs) {
     __shared__ float red[256];
-    const int c = blockIdx.x, t = threadIdx.x;
+    int c = blockIdx.x, which = 0;
+    while (which < 3 && c >= jobs.j[which].cols) c -= jobs.j[which++].cols;
+    const float* __restrict__ partial = jobs.j[which].partial;
+    float* __restrict__ out = jobs.j[which].out;
+    const int nb = jobs.j[which].nb, width = jobs.j[which].width;
+    const int t = threadIdx.x;
     float s = 0.f;
     for (int b = t; b < nb; b += 256) s += partial[(size_t)b * width + c];
     red[t] = s;
@@ -773,7 +787,7 @@ int grid_blocks(int64_t n) {
     static const int cap = [] {
         const char* e = getenv("AIG_GAT_GRID_CAP");
         int c = e ? atoi(e) : 0;
-        return c >= 8 ? c / 8 * 8 : 2048;
+        return c >= 8 && c <= 2048 ? c / 8 * 8 : 2048;  // the partial-sum areas hold 2048 blocks
     }();
     int64_t g = (n + 63) / 64;
     g = (g + 7) / 8 * 8;
@@ -890,7 +904,8 @@ extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const f
 extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {
     size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1), nseg = N + M / SEG + 1;
     return align_up(N * H * 4) /*g_pre*/ + align_up(M * HEADS * 4) + 2 * align_up(N * HEADS * 4) +
-           align_up(nseg * H * 4) + align_up(nseg * HEADS * 4) + align_up(nseg * 4) + align_up((size_t)4097 * 2 * H * 4) + 256;
+           align_up(nseg * H * 4) + align_up(nseg * HEADS * 4) + align_up(nseg * 4) + align_up((size_t)4097 * 2 * H * 4) +
+           align_up((size_t)2048 * (H + HEADS) * 4) + 256;
 }
 
 extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
@@ -926,14 +941,12 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     float* part_acc = c.take<float>(nseg_max * H);
     float* part_das = c.take<float>(nseg_max * HEADS);
     int* part_flag = c.take<int>(nseg_max);
-    float* partial = c.take<float>((size_t)4097 * 2 * H);
+    float* partial = c.take<float>((size_t)4097 * 2 * H);       // source-side kernels: [gs + g][2H]
+    float* partial_dst = c.take<float>((size_t)2048 * (H + HEADS));  // target-side kernel: [g][H + HEADS]
     const int g = grid_blocks(n);
     hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
-                       csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial);
+                       csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial_dst);
     AIG_LAUNCH_CHECK();
-    // bias gradient = first H columns, edge-coefficient gradient = last HEADS columns
-    hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, g, H + HEADS, partial, d_bias);
-    hipLaunchKernelGGL(k_reduce_cols, dim3(HEADS), dim3(256), 0, s, g, H + HEADS, partial + H, d_ce);
     const int gs = grid_blocks((int64_t)nseg_max);
     hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
                        reinterpret_cast<const int4*>(seg_desc), csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e,
@@ -941,8 +954,14 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     hipLaunchKernelGGL(k_gat_bwd_src_heavy, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
                        alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, part_flag, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, gs + g, 2 * H, partial, d_att_src);
-    hipLaunchKernelGGL(k_reduce_cols, dim3(H), dim3(256), 0, s, gs + g, 2 * H, partial + H, d_att_dst);
+    // bias gradient = first H columns of the target-side partials, edge-coefficient gradient = their
+    // last HEADS columns; the attention vectors' gradients = the two halves of the source-side ones
+    ColSums sums{};
+    sums.j[0] = ColSum{partial_dst, d_bias, g, H + HEADS, H};
+    sums.j[1] = ColSum{partial_dst + H, d_ce, g, H + HEADS, HEADS};
+    sums.j[2] = ColSum{partial, d_att_src, gs + g, 2 * H, H};
+    sums.j[3] = ColSum{partial + H, d_att_dst, gs + g, 2 * H, H};
+    hipLaunchKernelGGL(k_reduce_cols, dim3(3 * H + HEADS), dim3(256), 0, s, sums);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
