@@ -12,10 +12,12 @@ What differs, on purpose:
   does not change between iterations), which lets the critic reuse one CSR per edge list;
 * with ``WORLD_SIZE > 1`` (torchrun) the shuffled minibatches are dealt to the ranks and the
   critic gradient is averaged over ranks after every ``loss_D.backward()`` (gan_amd/parallel.py);
-* the real-side critic term and the gradient penalty of a minibatch are recorded as a HIP graph
-  and replayed (``CapturedCriticTerms``; ``--no-graph-capture`` keeps the eager path);
+* the real-side critic term and the gradient penalty of a minibatch are recorded as HIP graphs
+  and replayed (``CapturedCriticTerms``; ``--no-graph-capture`` keeps the eager path); the critic's
+  fakes are generated and repaired on a second stream underneath the first replay of the
+  real-side term (``--no-overlap`` keeps one stream);
 * extension flags: ``--seed``, ``--unpad-templates`` (the reference's templates stay padded,
-  see gan_amd/dataset.py), ``--no-progress``, ``--no-graph-capture``, ``--autograd-gp``;
+  see gan_amd/dataset.py), ``--no-progress``, ``--no-graph-capture``, ``--autograd-gp``, ``--no-overlap``;
 * the gradient penalty and its parameter gradient come from a closed form
   (``AIGDiscriminator.gradient_penalty_closed_form``) unless ``--autograd-gp`` is given.
 """
@@ -109,8 +111,9 @@ def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool 
 
 
 class CapturedCriticTerms:
-    """``-mean(D(real)) + gp_lambda * GP`` and its gradient w.r.t. the critic's parameters, recorded
-    once as a HIP graph and replayed every critic iteration.
+    """``-mean(D(real))`` and ``gp_lambda * GP`` with their gradients w.r.t. the critic's parameters,
+    recorded once as two HIP graphs and replayed every critic iteration (two graphs, because the
+    real-side term does not depend on the fakes and can run while they are still being generated).
 
     Both terms only see tensors of fixed shape and address (the real graph of a sample, the padded
     node features of the fake, alpha, the parameters), and together they are about half of the
@@ -128,25 +131,24 @@ class CapturedCriticTerms:
         fake_pad = Data(x=self.x_fake)
         self._inputs = (real_pad, fake_pad, real_for_D)
 
-        def compute():
+        def compute_real():
             d_real = torch.mean(D(real_for_D))
+            return d_real.detach(), torch.autograd.grad(-d_real, params, allow_unused=True)
+
+        def compute_gp():
             if closed_form_gp:
-                grads = list(torch.autograd.grad(-d_real, params, allow_unused=True))
                 gp, gn, gp_grads = D.gradient_penalty_closed_form(real_pad.x, fake_pad.x, self.alpha, real_pad.node_depth)
-                for k, p in enumerate(params):
-                    if p in gp_grads:
-                        grads[k] = gp_lambda * gp_grads[p] if grads[k] is None else grads[k] + gp_lambda * gp_grads[p]
-                return d_real.detach(), gp, gn, grads
+                return gp, gn, [gp_lambda * gp_grads[p] if p in gp_grads else None for p in params]
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha)
-            grads = torch.autograd.grad(gp_lambda * gp - d_real, params, allow_unused=True)
-            return d_real.detach(), gp.detach(), gn, grads
+            return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
         cur = torch.cuda.current_stream(device)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):      # builds the cached CSR / level plans, sizes the allocator
             for _ in range(2):
-                compute()
+                compute_real()
+                compute_gp()
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
         # the recorded kernels hold raw addresses of the cached plans: keep the plan objects alive
@@ -154,20 +156,31 @@ class CapturedCriticTerms:
         self._plans = (D.graph_csr(real_for_D.edge_index, real_for_D.edge_attr, n)
                        if real_for_D.edge_index.numel() > 0 else None,
                        D.level_plan(real_for_D.node_depth, n, device), D.level_plan(real_pad.node_depth, n, device))
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph_real, self.graph_gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread-local capture: a communicator's watchdog thread may query events while we record
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.d_real, self.gp, self.grad_norm, self.grads = compute()
-        self.params = [p for p, g in zip(params, self.grads) if g is not None]
-        self.grads = [g for g in self.grads if g is not None]
+        with torch.cuda.graph(self.graph_real, capture_error_mode="thread_local"):
+            self.d_real, grads_real = compute_real()
+        with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
+            self.gp, self.grad_norm, grads_gp = compute_gp()
+        self._adds = []   # (parameters, recorded gradients) per graph
+        for grads in (grads_real, grads_gp):
+            self._adds.append(([p for p, g in zip(params, grads) if g is not None], [g for g in grads if g is not None]))
 
-    def replay(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
+    def replay_real(self) -> None:
+        self.graph_real.replay()
+
+    def replay_gp(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
         self.x_fake.copy_(x_fake)
         self.alpha.copy_(alpha.reshape(1, 1))
-        self.graph.replay()
+        self.graph_gp.replay()
+
+    def replay(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
+        self.replay_real()
+        self.replay_gp(x_fake, alpha)
 
     def add_gradients(self) -> None:
-        torch._foreach_add_([p.grad for p in self.params], self.grads)
+        for ps, gs in self._adds:
+            torch._foreach_add_([p.grad for p in ps], gs)
 
 
 class Trainer:
@@ -198,6 +211,16 @@ class Trainer:
         # the structural penalties only need the raw graphs and their latency-bound traversals keep
         # one CU busy: they run on a second stream underneath the critic pass of the generator step
         self.side_stream = torch.cuda.Stream(device=device)
+        # ... and so do the critic's fakes (generator pass and repair), underneath the recorded
+        # real-side term of the first critic iteration
+        self.overlap_fakes = not bool(getattr(args, "no_overlap", False)) and os.environ.get("AIG_NO_OVERLAP") != "1"
+        self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream)] of the last step
+
+    def _mark(self, label: str) -> None:
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((label, ev))
 
     # templates are the same tensors every epoch: keep them (and their generator plan) per sample
     def templates_of(self, real_padded: Batch) -> List[Data]:
@@ -251,25 +274,38 @@ class Trainer:
         # A rank whose step raises still enters every gradient all-reduce of the step (with a
         # "not valid" flag), then re-raises: the other ranks never wait on a missing partner.
         failed: Optional[BaseException] = None
+        main_stream = torch.cuda.current_stream(dev)
+        self._mark("start")
+        real_replayed = False
         try:
-            zs_once = [self.draw_z() for _ in templates]
-            raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
-            corr_fakes_once = [enforce_aig_constraints(r) for r in raw_fakes_once]
-            fake_padded = self._pad_batch(corr_fakes_once)
             terms = self._captured_terms(real_padded)
             real_for_D = terms._inputs[2] if terms is not None else sanitize_for_D(real_padded)
-            fake_for_D = sanitize_for_D(fake_padded)
+            fakes_stream = self.side_stream if (terms is not None and self.overlap_fakes) else main_stream
+            fakes_stream.wait_stream(main_stream)
+            if fakes_stream is not main_stream:
+                terms.replay_real()       # the first iteration's real-side term: one launch, then the
+                real_replayed = True      # host goes on to enqueue the fakes next to it
+            with torch.cuda.stream(fakes_stream):
+                zs_once = [self.draw_z() for _ in templates]
+                raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
+                corr_fakes_once = [enforce_aig_constraints(r) for r in raw_fakes_once]
+                fake_padded = self._pad_batch(corr_fakes_once)
+                fake_for_D = sanitize_for_D(fake_padded)
+            main_stream.wait_stream(fakes_stream)
+            self._mark("fakes ready")
             self.edges_last_step = int(real_for_D.edge_index.size(1) + fake_for_D.edge_index.size(1))
         except Exception as e:
             if self.world == 1:
                 raise
             failed = e
-        for _ in range(a.n_critic):
+        for it in range(a.n_critic):
             if failed is None:
                 try:
                     self.opt_D.zero_grad()
                     if terms is not None:
-                        terms.replay(fake_padded.x, self.draw_alpha())
+                        if not (it == 0 and real_replayed):
+                            terms.replay_real()
+                        terms.replay_gp(fake_padded.x, self.draw_alpha())
                         D_fake_mean = torch.mean(D(fake_for_D))
                         D_fake_mean.backward()
                         terms.add_gradients()
@@ -304,10 +340,10 @@ class Trainer:
             raise failed
 
         # ---- generator (train.py:275-299); its output carries no gradient, so backward only touches D
+        self._mark("critic done")
         self.opt_G.zero_grad()
         zs = [self.draw_z() for _ in templates]
         raw_gen = [G(t, z) for t, z in zip(templates, zs)]
-        main_stream = torch.cuda.current_stream(dev)
         self.side_stream.wait_stream(main_stream)
         with torch.cuda.stream(self.side_stream):
             pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
@@ -323,6 +359,7 @@ class Trainer:
         loss_G.backward()
         self.opt_G.step()
         self.last.update(loss_G=loss_G.detach(), pen=loss_pen.detach())
+        self._mark("generator done")
 
         if save_dir is not None and (self.global_step % a.save_every) == 0:
             self._save_samples(raw_gen, epoch, save_dir)
@@ -432,6 +469,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-progress", action="store_true")
     p.add_argument("--autograd-gp", dest="closed_form_gp", action="store_false",
                    help="compute the gradient penalty by double backward (autograd) instead of its closed form")
+    p.add_argument("--no-overlap", dest="no_overlap", action="store_true",
+                   help="generate the critic's fakes on the main stream instead of underneath the real-side term")
     p.add_argument("--no-graph-capture", dest="graph_capture", action="store_false",
                    help="evaluate the real-side critic term and the gradient penalty eagerly instead of replaying a HIP graph")
     return p
