@@ -42,8 +42,19 @@ from .generator import AIGGenerator
 METRIC_FIELDS = ["step", "epoch", "D_real", "D_fake", "gap", "grad_norm", "loss_D", "loss_G", "gp", "pen"]
 
 
+# the four figures of train.py:79-102: file name -> (title, y label, series); a series drawn on a
+# second y axis is marked with "right"
+PLOTS = {
+    "losses.png": ("Losses", "loss", [("loss_D", "loss_D", "left"), ("loss_G", "loss_G", "left")]),
+    "scores.png": ("Discriminator scores", "score", [("D_real", "D_real", "left"), ("D_fake", "D_fake", "left")]),
+    "gap_grad.png": ("Gap & Grad-norm", None, [("gap", "gap (D_real - D_fake)", "left"), ("grad_norm", "grad_norm", "right")]),
+    "gp_pen.png": ("GP & Structure penalty", "value", [("gp", "gp", "left"), ("pen", "pen", "left")]),
+}
+
+
 class MetricsLogger:
-    """Rows of train.py:29-41 written as ``metrics.csv`` (train.py:43-50)."""
+    """Rows of train.py:29-41 written as ``metrics.csv`` (train.py:43-50) and drawn as the four PNG
+    figures of train.py:52-102 (skipped with a note when matplotlib is not installed)."""
 
     def __init__(self, out_dir: str):
         self.out_dir = out_dir
@@ -62,6 +73,40 @@ class MetricsLogger:
             w = csv.DictWriter(f, fieldnames=METRIC_FIELDS)
             w.writeheader()
             w.writerows(self.rows)
+
+    def plot_all(self) -> List[str]:
+        """Writes the figures next to ``metrics.csv``; returns the paths written."""
+        if not self.rows:
+            return []
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except ImportError:
+            print("[WARN] matplotlib is not installed: metrics.csv written, figures skipped")
+            return []
+        steps = [r["step"] for r in self.rows]
+        written = []
+        for fname, (title, ylabel, series) in PLOTS.items():
+            fig, left = plt.subplots()
+            right = left.twinx() if any(side == "right" for _, _, side in series) else None
+            lines = []
+            for key, label, side in series:
+                ax = right if side == "right" else left
+                lines += ax.plot(steps, [r[key] for r in self.rows], label=label, linestyle="--" if side == "right" else "-")
+                if right is not None:
+                    ax.set_ylabel(label)
+            left.set_xlabel("step")
+            if ylabel is not None:
+                left.set_ylabel(ylabel)
+            left.set_title(title)
+            left.legend(lines, [ln.get_label() for ln in lines], loc="best")
+            fig.tight_layout()
+            path = os.path.join(self.out_dir, fname)
+            fig.savefig(path)
+            plt.close(fig)
+            written.append(path)
+        return written
 
 
 def valid_edge_mask(d: Data) -> torch.Tensor:
@@ -437,6 +482,7 @@ def train(args) -> None:
             torch.save(trainer.G.state_dict(), os.path.join(args.out_dir, f"generator_epoch{epoch}.pt"))
             torch.save(trainer.D.state_dict(), os.path.join(args.out_dir, f"discriminator_epoch{epoch}.pt"))
             logger.flush_csv()
+            logger.plot_all()
             print(f"[INFO] saved checkpoints & metrics epoch {epoch}")
     if rank == 0:
         print("[INFO] training finished")
