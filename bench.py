@@ -10,7 +10,8 @@ penalties.  Every rank holds its own minibatch (weak scaling); for N > 1 the cri
 all-reduced over RCCL after each critic backward.  Rank 0 prints ONE JSON line:
 
   value            train edges/s = (real + fake non-sentinel edges of all ranks' minibatches) / step time
-  sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job
+  sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job, with
+                   several independent samples in flight (bulk sampling); ..._one_at_a_time is the plain loop
   roofline         the dominant kernel (fused GAT aggregate, aig_gat_fwd): algorithmic bytes of its
                    launches inside the timed region / their duration from stream events
   cpu_baseline     the CPU checker's training step on a bounded sample, timed on this host (rank 0, N=1)
@@ -109,6 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="synth100k", choices=["synth100k", "iscas85", "synth1m"])
     ap.add_argument("--sample-iters", type=int, default=10)
+    ap.add_argument("--sample-in-flight", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -116,6 +118,7 @@ def main():
     from gan_amd.constraints import enforce_aig_constraints, resync_attrs
     from gan_amd.data import Batch, Data
     from gan_amd.dataset import pad_data
+    from gan_amd.sample import sample_many
     from gan_amd.train import Trainer, build_parser
 
     rank, local_rank, world = parallel.init_distributed()
@@ -182,22 +185,33 @@ def main():
     templates = trainer.templates_of(batch)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
 
-    def sample_once():
-        for t in templates:
-            z = torch.randn(128, device=dev, generator=gen)
-            resync_attrs(enforce_aig_constraints(trainer.G(t, z)))
-    sample_once()
-    barrier()
-    s0 = time.perf_counter()
-    for _ in range(a.sample_iters):
-        sample_once()
-    barrier()
-    s_el = time.perf_counter() - s0
-    s_stat = torch.tensor([s_el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(s_stat, op=dist.ReduceOp.MAX)
+    draw_z = lambda: torch.randn(128, device=dev, generator=gen)   # noqa: E731
     nodes_per_iter = sum(int(t.x.size(0)) for t in templates)
-    sample_nodes_per_sec = nodes_per_iter * a.sample_iters * world / float(s_stat.item())
+
+    def sample_rate(run):
+        run(1)
+        barrier()
+        s0 = time.perf_counter()
+        run(a.sample_iters)
+        barrier()
+        s_stat = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(s_stat, op=dist.ReduceOp.MAX)
+        return nodes_per_iter * a.sample_iters * world / float(s_stat.item())
+
+    def one_at_a_time(iters):
+        for _ in range(iters):
+            for t in templates:
+                resync_attrs(enforce_aig_constraints(trainer.G(t, draw_z())))
+
+    sample_streams = [torch.cuda.Stream(device=dev) for _ in range(a.sample_in_flight)]
+
+    def in_flight(iters):   # bulk sampling as gan_amd.sample does it: several independent samples in the air
+        for _ in sample_many(trainer.G, ((t, draw_z) for _ in range(iters) for t in templates), streams=sample_streams):
+            pass
+
+    sample_nodes_per_sec_single = sample_rate(one_at_a_time)
+    sample_nodes_per_sec = sample_rate(in_flight)
 
     if rank == 0:
         ms_fwd, launches = tl.get("aig_gat_fwd", (0.0, 0))
@@ -228,6 +242,9 @@ def main():
                        "edges_per_step_per_gpu": trainer.edges_last_step,
                        "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
             "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
+            "sample_nodes_per_sec_one_at_a_time": round(sample_nodes_per_sec_single, 1),
+            "sample_note": f"G.forward + enforce + resync per sample; bulk rate with {a.sample_in_flight} independent "
+                           "samples in flight on as many streams, and the rate of strictly one sample after another",
             "roofline": roof,
             "roofline_mfma": mfma,
             "timeline_ms_per_step": {k: round(v[0] / inst_steps, 3) for k, v in sorted(tl_all.items())},

@@ -69,7 +69,21 @@ def _depth_arg(data: Data, n: int, dev):
 def enforce_aig_constraints(data: Data, strict: bool = False, check_all_on_path: bool = True) -> Data:
     """Repair ``data`` into AIG shape; mutates and returns it.  ``strict`` has no effect in the
     reference either once back edges are pruned (constraints.py:630-638 re-applies the same filter)."""
+    return enforce_finish(enforce_begin(data, strict, check_all_on_path))
+
+
+class EnforceHandle:
+    """A repair whose kernels are enqueued but whose edge count has not been read back yet."""
+    __slots__ = ("data", "out_ei", "out_ea", "node_depth", "x_out", "count_host", "ready")
+
+
+def enforce_begin(data: Data, strict: bool = False, check_all_on_path: bool = True) -> EnforceHandle:
+    """First half of ``enforce_aig_constraints``: enqueues the repair on the current stream and starts
+    the copy of the repaired edge count to the host.  A caller that keeps several graphs in flight
+    (bulk sampling) enqueues other work before it calls ``enforce_finish``."""
     lib = _abi.lib()
+    h = EnforceHandle()
+    h.data, h.ready = data, None
     x = data.x
     _need_gpu(x, "enforce_aig_constraints")
     dev = x.device
@@ -80,7 +94,7 @@ def enforce_aig_constraints(data: Data, strict: bool = False, check_all_on_path:
         data.edge_attr = torch.zeros((0, 1), dtype=torch.long, device=dev)
         data.node_depth = torch.full((n,), -1, dtype=torch.long, device=dev)
         data.x[:, 1] = 0
-        return data
+        return h
     x_in = _x32(x)
     inv = _inv64(data, E)
     kind, depth = _depth_arg(data, n, dev)
@@ -94,11 +108,27 @@ def enforce_aig_constraints(data: Data, strict: bool = False, check_all_on_path:
     _abi.check(lib.aig_enforce(n, E, _abi.ptr(x_in), _abi.ptr(ei), _abi.ptr(inv), kind, _abi.ptr(depth),
                                _abi.ptr(out_ei), cap, _abi.ptr(out_ea), _abi.ptr(out_cnt), _abi.ptr(node_depth),
                                _abi.ptr(x_out), _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_enforce")
-    m = int(out_cnt.item())  # one host read: the repaired edge count sizes the returned tensors
-    data.edge_index = out_ei[:, :m].contiguous()
-    data.edge_attr = out_ea[:m].reshape(-1, 1).contiguous()
-    data.node_depth = node_depth
-    data.x = x_out if x.dtype == torch.float32 else x_out.to(x.dtype)
+    h.out_ei, h.out_ea, h.node_depth, h.x_out = out_ei, out_ea, node_depth, x_out
+    h.count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    h.count_host.copy_(out_cnt, non_blocking=True)
+    h.ready = torch.cuda.Event()
+    h.ready.record()
+    return h
+
+
+def enforce_finish(h: EnforceHandle) -> Data:
+    """Second half: waits for the edge count (the one host read of the repair - it sizes the returned
+    tensors) and installs the repaired attributes.  Call it under the stream ``enforce_begin`` ran on."""
+    data = h.data
+    if h.ready is None:
+        return data
+    h.ready.synchronize()
+    m = int(h.count_host[0])
+    x = data.x
+    data.edge_index = h.out_ei[:, :m].contiguous()
+    data.edge_attr = h.out_ea[:m].reshape(-1, 1).contiguous()
+    data.node_depth = h.node_depth
+    data.x = h.x_out if x.dtype == torch.float32 else h.x_out.to(x.dtype)
     return data
 
 

@@ -5,17 +5,20 @@ build the generator and load its weights, draw ``z`` on the device, one forward 
 gradients, ``enforce_aig_constraints``, ``resync_attrs``, save.  Extensions: ``--num-samples`` for
 bulk sampling (sample i draws z from a device generator seeded ``seed + i``, so sample 0 is the
 reference's draw and the set of samples does not depend on how many ranks produce it), and
-under torchrun the samples are dealt to the ranks with no collective at all.
+under torchrun the samples are dealt to the ranks with no collective at all.  Bulk sampling keeps
+``--in-flight`` samples in the air on as many streams (``sample_many``).
 """
 from __future__ import annotations
 
 import argparse
 import os
+from collections import deque
+from typing import Callable, Iterable, Iterator, List, Optional, Tuple
 
 import torch
 
 from . import parallel
-from .constraints import enforce_aig_constraints, resync_attrs
+from .constraints import enforce_aig_constraints, enforce_begin, enforce_finish, resync_attrs
 from .data import Data
 from .dataset import load_pt_dataset
 from .generator import AIGGenerator
@@ -39,6 +42,46 @@ def sample_one(G: AIGGenerator, tpl: Data, z: torch.Tensor) -> Data:
     return resync_attrs(enforce_aig_constraints(raw))
 
 
+def sample_many(G: AIGGenerator, jobs: Iterable[Tuple[Data, Callable[[], torch.Tensor]]], in_flight: int = 4,
+                streams: Optional[List[torch.cuda.Stream]] = None) -> Iterator[Data]:
+    """``sample_one`` over many ``(template, draw_z)`` jobs with ``in_flight`` samples in the air.
+
+    The repair and the resync of one sample each hold a level-by-level graph walk that keeps a single
+    CU busy for about a millisecond, and the repair ends in a host read (its edge count).  Samples are
+    independent, so sample i is enqueued on stream ``i % in_flight`` and only finished (count read,
+    resync enqueued) once ``in_flight - 1`` younger samples have been enqueued behind it: the walks of
+    a few samples and the dense kernels of another run side by side.  ``draw_z`` is called under the
+    sample's stream.  Results come back in job order, the same tensors ``sample_one`` returns, and
+    the caller's current stream waits for each before it is handed out."""
+    if in_flight < 1:
+        raise ValueError("in_flight must be at least 1")
+    cur = torch.cuda.current_stream()
+    if streams is None:
+        streams = [torch.cuda.Stream(device=cur.device) for _ in range(in_flight)]
+    for st in streams:
+        st.wait_stream(cur)
+    pending: deque = deque()
+
+    def finish():
+        st, handle = pending.popleft()
+        with torch.cuda.stream(st):
+            d = resync_attrs(enforce_finish(handle))
+        cur.wait_stream(st)
+        for v in d.to_dict().values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return d
+
+    for i, (tpl, draw_z) in enumerate(jobs):
+        st = streams[i % len(streams)]
+        with torch.cuda.stream(st), torch.no_grad():
+            pending.append((st, enforce_begin(G(tpl, draw_z()))))
+        if len(pending) >= len(streams):
+            yield finish()
+    while pending:
+        yield finish()
+
+
 def out_path(base: str, i: int, total: int) -> str:
     if total == 1:
         return base
@@ -57,6 +100,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--template-idx", type=int, default=0)
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--num-samples", type=int, default=1, help="extension: bulk sampling")
+    ap.add_argument("--in-flight", type=int, default=4, help="extension: samples kept in flight during bulk sampling")
     return ap
 
 
@@ -80,10 +124,12 @@ def main(argv=None) -> None:
     G.eval()
 
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
-    for i in parallel.shard_indices(args.num_samples, rank, world):
-        gen = torch.Generator(device=device).manual_seed(args.seed + i)
-        z = torch.randn(args.z_dim, device=device, generator=gen)
-        fixed = sample_one(G, tpl, z)
+    mine = parallel.shard_indices(args.num_samples, rank, world)
+
+    def z_of(i):   # per-sample seed: the output set does not depend on the number of ranks
+        return lambda: torch.randn(args.z_dim, device=device, generator=torch.Generator(device=device).manual_seed(args.seed + i))
+
+    for i, fixed in zip(mine, sample_many(G, ((tpl, z_of(i)) for i in mine), in_flight=args.in_flight)):
         if args.num_samples == 1:
             print("[INFO] FIX:", summarize(fixed))
         path = out_path(args.out, i, args.num_samples)
