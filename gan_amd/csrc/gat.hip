@@ -98,28 +98,29 @@ size_t sort_temp_bytes(int64_t E, int bits) {
     return bytes;
 }
 
-constexpr int SEG = 32;   // edges per by-source segment: long fan-out lists are cut into pieces of this size
+constexpr int SEG = 32;         // an out-edge list of at most this many edges is one half-wave's work in the backward pass
+constexpr int HUB_CHUNK = 256;  // a longer list (a "hub") is cut into chunks of this many edges, one block each
+constexpr int HUB_BLOCKS = 1024;        // blocks that gather hub chunks (multiple of 8)
+constexpr int HUB_FINISH_BLOCKS = 64;   // blocks that add up the chunk rows, a hub at a time
+// upper bounds for E edges: a hub has more than SEG edges, and its chunks number fan-out / HUB_CHUNK rounded up
+inline size_t hubs_max(int64_t E) { return (size_t)(E > 0 ? E : 0) / (SEG + 1) + 1; }
+inline size_t hub_chunks_max(int64_t E) { return (size_t)(E > 0 ? E : 0) / HUB_CHUNK + hubs_max(E); }
 
-// number of segments of node j's out-edge list (at least one, so every node owns a segment)
-__global__ void k_seg_count(int n, const int* __restrict__ col_ptr, int* __restrict__ nch) {
+// per node: is it a hub, and how many chunks does its list make
+__global__ void k_hub_count(int n, const int* __restrict__ col_ptr, int* __restrict__ flag, int* __restrict__ chunks) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += gridDim.x * blockDim.x) {
-        int d = j < n ? col_ptr[j + 1] - col_ptr[j] : 0;
-        nch[j] = j < n ? max(1, (d + SEG - 1) / SEG) : 0;
+        const int d = j < n ? col_ptr[j + 1] - col_ptr[j] : 0;
+        flag[j] = d > SEG;
+        chunks[j] = d > SEG ? (d + HUB_CHUNK - 1) / HUB_CHUNK : 0;
     }
 }
-
-// descriptor of every segment: {owner j, first position, one past the last position, segments of j}
-__global__ void k_seg_desc(int n, int nseg_cap, const int* __restrict__ seg_base, const int* __restrict__ col_ptr,
-                           int4* __restrict__ desc) {
-    const int nseg = min(seg_base[n], nseg_cap);
-    for (int sgm = blockIdx.x * blockDim.x + threadIdx.x; sgm < nseg; sgm += gridDim.x * blockDim.x) {
-        int lo = 0, hi = n;  // owner: the last node j with seg_base[j] <= sgm
-        while (lo + 1 < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (seg_base[mid] <= sgm) lo = mid; else hi = mid;
-        }
-        const int first = seg_base[lo], beg = col_ptr[lo] + (sgm - first) * SEG;
-        desc[sgm] = make_int4(lo, beg, min(col_ptr[lo + 1], beg + SEG), seg_base[lo + 1] - first);
+// tab[0] = {hubs, chunks of all hubs, 0, 0}; tab[1 + k] = {node, first position in the by-source list,
+// fan-out, first chunk} of the k-th hub in node order (rank / cbase: exclusive sums of flag / chunks)
+__global__ void k_hub_tab(int n, const int* __restrict__ col_ptr, const int* __restrict__ rank,
+                          const int* __restrict__ cbase, int4* __restrict__ tab) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= n; j += gridDim.x * blockDim.x) {
+        if (j == n) { tab[0] = make_int4(rank[n], cbase[n], 0, 0); continue; }
+        if (rank[j + 1] != rank[j]) tab[1 + rank[j]] = make_int4(j, col_ptr[j], col_ptr[j + 1] - col_ptr[j], cbase[j]);
     }
 }
 
@@ -138,13 +139,13 @@ __device__ __forceinline__ int logical_block(int b, int nb) { return (b & 7) * (
 struct NodeRange {
     int begin, end;
 };
-__device__ __forceinline__ NodeRange block_nodes(int n) {
-    int nb = gridDim.x;  // multiple of 8
-    int lb = logical_block(blockIdx.x, nb);
+__device__ __forceinline__ NodeRange block_nodes_of(int n, int block, int nb /* multiple of 8 */) {
+    int lb = logical_block(block, nb);
     int chunk = (n + nb - 1) / nb;
     int b = lb * chunk, e = min(n, b + chunk);
     return {b, e};
 }
+__device__ __forceinline__ NodeRange block_nodes(int n) { return block_nodes_of(n, blockIdx.x, gridDim.x); }
 
 // value of the lane selected by a DPP control word within the row of 16
 template <int CTRL>
@@ -509,11 +510,12 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
 
 // Source side.  d_xw[j] = sum_{e: src=j} alpha_e g_pre[dst_e] + alpha_loop g_pre[j]
 //                        + d_a_s[j] att_src + d_a_d[j] att_dst,   d_a_s[j] = sum d_raw over out-edges.
-// Fan-out is heavily skewed (a generated graph can hang thousands of gates on one source), so the
-// out-edge lists are cut into segments of SEG edges and a half-wave owns one SEGMENT, described by
-// seg_desc (owner, first and last position in the by-source list, segments of the owner): a node
-// with a single segment is finished on the spot, a longer list leaves one partial row per segment
-// and is finished by k_gat_bwd_src_heavy, which adds the partials in segment order (reproducible).
+// Fan-out is heavily skewed: a generated graph hangs most of its gates on two or three sources (tens of
+// thousands of out-edges each) while every other node has a handful.  So a half-wave owns one NODE when
+// its out-edge list has at most SEG edges, and the lists of the few "hubs" (listed in hub_tab) are cut
+// into chunks of HUB_CHUNK edges that whole blocks gather, one partial row per chunk;
+// k_gat_bwd_hub_finish adds the rows of a hub in chunk order and finishes the node.  Every sum has a
+// fixed shape, so results are reproducible whatever the fan-out.
 struct SrcFinish {
     float4 as4, ad4;
 };
@@ -545,7 +547,8 @@ __device__ __forceinline__ void src_finish(int j, int l, float4 acc, float das, 
     pd.x += v.dad * v.xj.x; pd.y += v.dad * v.xj.y; pd.z += v.dad * v.xj.z; pd.w += v.dad * v.xj.w;
 }
 
-__device__ __forceinline__ void block_partial_2h(float4 ps, float4 pd, float* __restrict__ partial) {
+// row `row` of partial[][2H] = the block's sums of ps | pd, half-waves added in fixed order
+__device__ __forceinline__ void block_partial_2h(float4 ps, float4 pd, float* __restrict__ partial, int row) {
     __shared__ float red[HW_PER_BLOCK][2 * H];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     reinterpret_cast<float4*>(&red[hw][0])[l] = ps;
@@ -553,201 +556,162 @@ __device__ __forceinline__ void block_partial_2h(float4 ps, float4 pd, float* __
     __syncthreads();
     float s = 0.f;
     for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
-    partial[(size_t)blockIdx.x * (2 * H) + threadIdx.x] = s;
+    partial[(size_t)row * (2 * H) + threadIdx.x] = s;
 }
 
 __device__ __forceinline__ float pick(float4 v, int h) { return h == 0 ? v.x : h == 1 ? v.y : h == 2 ? v.z : v.w; }
 
-__global__ __launch_bounds__(THREADS) void k_gat_bwd_src_seg(
-    int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
-    const float* __restrict__ att_dst, const int* __restrict__ seg_base, const int4* __restrict__ seg_desc,
-    const int* __restrict__ csc_pos, const int* __restrict__ csc_dst, const float* __restrict__ alpha_e,
-    const float* __restrict__ alpha_loop, const float* __restrict__ d_raw_e, const float* __restrict__ d_raw_loop,
-    const float* __restrict__ d_a_d, float* __restrict__ d_xw, float* __restrict__ part_acc /*[nseg][H]*/,
-    float* __restrict__ part_das /*[nseg][HEADS]*/, int* __restrict__ part_flag /*[nseg]*/,
-    float* __restrict__ partial /*[grid][2H]*/) {
-    __shared__ float s_alpha[HW_PER_BLOCK][32][HEADS];
-    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
-    SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
-    const float4* g4 = reinterpret_cast<const float4*>(g_pre);
-    const float4* alpha_e4 = reinterpret_cast<const float4*>(alpha_e);
-    const float4* d_raw_e4 = reinterpret_cast<const float4*>(d_raw_e);
-    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
-    const float4 zero4 = ps;
-    const int nseg = seg_base[n];
-    NodeRange r = block_nodes(nseg);   // a contiguous range of segments per block, XCD-grouped
-    // A half-wave that meets several segments of one long list in a row adds them up and leaves ONE
-    // partial row (in the slot of the first of them, part_flag = 1; the other slots get flag 0),
-    // so a list of thousands of segments leaves a few hundred rows for k_gat_bwd_src_heavy.
-    int run_owner = -1, run_slot = 0;
-    float4 run_acc = zero4, run_das = zero4;
-    auto flush = [&]() {
-        if (run_owner < 0) return;
-        reinterpret_cast<float4*>(part_acc + (size_t)run_slot * H)[l] = run_acc;
-        if (l == 0) {
-            reinterpret_cast<float4*>(part_das)[run_slot] = run_das;
-            part_flag[run_slot] = 1;
-        }
-        run_owner = -1;
-    };
-    for (int sgm = r.begin + hw; sgm < r.end; sgm += HW_PER_BLOCK) {
-        const int4 d = seg_desc[sgm];
-        const int j = d.x, beg = d.y, cnt = d.z - d.y, nsg = d.w;
-        const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
-        // lane k: edge k of a 32-edge piece of the segment (position in the by-target order, target
-        // id); a segment with no edge belongs to a node without out-edges and reads nothing
-        float4 acc = zero4, dr = zero4;
-        for (int c0 = 0; c0 < cnt; c0 += 32) {
-            const bool on = c0 + l < cnt;
-            const int q = on ? beg + c0 + l : beg;
-            const int pv = csc_pos[q], dv = csc_dst[q];
-            const int p = on ? pv : 0;
-            const int dst = on ? dv : j;
-            const float4 alv = alpha_e4[p], drv = d_raw_e4[p];
-            const float4 al = on ? alv : zero4;
-            if (on) { dr.x += drv.x; dr.y += drv.y; dr.z += drv.z; dr.w += drv.w; }
-            *reinterpret_cast<float4*>(&s_alpha[hw][l][0]) = al;
-            __builtin_amdgcn_wave_barrier();
-            const int lim = min(32, cnt - c0);
-            for (int k0 = 0; k0 < lim; k0 += 4) {
-                const int t0 = __shfl(dst, k0, 32), t1 = __shfl(dst, k0 + 1, 32), t2 = __shfl(dst, k0 + 2, 32),
-                          t3 = __shfl(dst, k0 + 3, 32);
-                const float4 r0 = g4[(size_t)t0 * 32 + l], r1 = g4[(size_t)t1 * 32 + l], r2 = g4[(size_t)t2 * 32 + l],
-                             r3 = g4[(size_t)t3 * 32 + l];
-                axpy4(acc, s_alpha[hw][k0][h], r0);
-                axpy4(acc, s_alpha[hw][k0 + 1][h], r1);
-                axpy4(acc, s_alpha[hw][k0 + 2][h], r2);
-                axpy4(acc, s_alpha[hw][k0 + 3][h], r3);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        const float4 das4 = halfwave_reduce(dr, cnt > 4, SumOp());
-        if (nsg == 1) {
-            src_finish(j, l, acc, pick(das4, h), f, v, d_xw, ps, pd);
-        } else if (j == run_owner) {
-            run_acc.x += acc.x; run_acc.y += acc.y; run_acc.z += acc.z; run_acc.w += acc.w;
-            run_das.x += das4.x; run_das.y += das4.y; run_das.z += das4.z; run_das.w += das4.w;
-            if (l == 0) part_flag[sgm] = 0;
-        } else {
-            flush();
-            run_owner = j;
-            run_slot = sgm;
-            run_acc = acc;
-            run_das = das4;
-        }
+struct SrcEdges {
+    const int* __restrict__ csc_pos;
+    const int* __restrict__ csc_dst;
+    const float4* __restrict__ alpha_e4;
+    const float4* __restrict__ d_raw_e4;
+    const float4* __restrict__ g4;
+};
+// One half-wave, cnt (1..32) edges at positions q0.. of the by-source list: lane k takes edge k (its
+// position in the by-target order and its target), alpha goes through LDS, target rows come four at a
+// time.  acc += sum alpha_e g_pre[dst_e] (this lane's four columns), dr += d_raw of this lane's edge.
+__device__ __forceinline__ void src_edges32(const SrcEdges& a, int q0, int cnt, int l, int h, float (*s_al)[HEADS],
+                                            float4& acc, float4& dr) {
+    const bool on = l < cnt;
+    const int q = on ? q0 + l : q0;
+    const int p = a.csc_pos[q], dv = a.csc_dst[q];
+    const int dst = dv;   // lanes past the list read the first edge again: its target, with alpha 0
+    const float4 alv = a.alpha_e4[p], drv = a.d_raw_e4[p];
+    const float4 al = on ? alv : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) { dr.x += drv.x; dr.y += drv.y; dr.z += drv.z; dr.w += drv.w; }
+    *reinterpret_cast<float4*>(&s_al[l][0]) = al;
+    __builtin_amdgcn_wave_barrier();
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        const int t0 = __shfl(dst, k0, 32), t1 = __shfl(dst, k0 + 1, 32), t2 = __shfl(dst, k0 + 2, 32),
+                  t3 = __shfl(dst, k0 + 3, 32);
+        const float4 r0 = a.g4[(size_t)t0 * 32 + l], r1 = a.g4[(size_t)t1 * 32 + l], r2 = a.g4[(size_t)t2 * 32 + l],
+                     r3 = a.g4[(size_t)t3 * 32 + l];
+        axpy4(acc, s_al[k0][h], r0);
+        axpy4(acc, s_al[k0 + 1][h], r1);
+        axpy4(acc, s_al[k0 + 2][h], r2);
+        axpy4(acc, s_al[k0 + 3][h], r3);
     }
-    flush();
-    block_partial_2h(ps, pd, partial);
+    __builtin_amdgcn_wave_barrier();
 }
 
-// Nodes whose out-edge list spans several segments: the whole block adds one node's partial rows
-// (half-wave hw takes segments hw, hw+8, ... four loads in flight), the eight sums are combined in
-// half-wave order and half-wave 0 finishes the node - same result whatever the fan-out.
-__global__ __launch_bounds__(THREADS) void k_gat_bwd_src_heavy(
-    int n, const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
-    const float* __restrict__ att_dst, const int* __restrict__ seg_base, const float* __restrict__ alpha_loop,
-    const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, const float* __restrict__ part_acc,
-    const float* __restrict__ part_das, const int* __restrict__ part_flag, float* __restrict__ d_xw,
-    float* __restrict__ partial /*[grid][2H]*/) {
-    __shared__ int s_list[THREADS];
-    __shared__ int s_wcnt[THREADS / 64];
+// Blocks 0..hub_blocks-1 gather the chunks of the hubs (they are dispatched first, their work is the
+// longest), the other blocks walk the nodes, one half-wave per node, XCD-grouped.
+__global__ __launch_bounds__(THREADS) void k_gat_bwd_src(
+    int n, int hub_blocks, const float* __restrict__ g_pre, const float* __restrict__ xw,
+    const float* __restrict__ att_src, const float* __restrict__ att_dst, const int4* __restrict__ hub_tab,
+    const int* __restrict__ col_ptr, const int* __restrict__ csc_pos, const int* __restrict__ csc_dst,
+    const float* __restrict__ alpha_e, const float* __restrict__ alpha_loop, const float* __restrict__ d_raw_e,
+    const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, float* __restrict__ d_xw,
+    float* __restrict__ part_acc /*[chunks][H]*/, float* __restrict__ part_das /*[chunks][HEADS]*/,
+    float* __restrict__ partial /*[node blocks][2H]*/) {
+    __shared__ float s_alpha[HW_PER_BLOCK][32][HEADS];
     __shared__ float s_acc[HW_PER_BLOCK][H];
     __shared__ float s_das[HW_PER_BLOCK][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const SrcEdges ed{csc_pos, csc_dst, reinterpret_cast<const float4*>(alpha_e),
+                      reinterpret_cast<const float4*>(d_raw_e), reinterpret_cast<const float4*>(g_pre)};
+    if ((int)blockIdx.x < hub_blocks) {
+        const int4 hdr = hub_tab[0];
+        const int n_hub = hdr.x, total = hdr.y;
+        for (int c = blockIdx.x; c < total; c += hub_blocks) {
+            int lo = 0, hi = n_hub;  // the hub owning chunk c: the last one whose first chunk is <= c
+            while (lo + 1 < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (hub_tab[1 + mid].w <= c) lo = mid; else hi = mid;
+            }
+            const int4 t = hub_tab[1 + lo];
+            const int e0 = t.y + (c - t.w) * HUB_CHUNK, e1 = min(t.y + t.z, e0 + HUB_CHUNK);
+            const int q0 = e0 + hw * 32, cnt = max(0, min(32, e1 - q0));
+            float4 acc = zero4, dr = zero4;
+            if (cnt > 0) src_edges32(ed, q0, cnt, l, h, s_alpha[hw], acc, dr);
+            const float4 das4 = halfwave_reduce(dr, true, SumOp());
+            reinterpret_cast<float4*>(&s_acc[hw][0])[l] = acc;
+            if (l == 0) *reinterpret_cast<float4*>(&s_das[hw][0]) = das4;
+            __syncthreads();
+            if (threadIdx.x < H + HEADS) {
+                const bool row = threadIdx.x < H;
+                const int col = row ? threadIdx.x : threadIdx.x - H;
+                float sum = 0.f;
+                for (int k = 0; k < HW_PER_BLOCK; ++k) sum += row ? s_acc[k][col] : s_das[k][col];
+                if (row) part_acc[(size_t)c * H + col] = sum;
+                else part_das[(size_t)c * HEADS + col] = sum;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int b = blockIdx.x - hub_blocks;
+    SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
+    float4 ps = zero4, pd = zero4;
+    NodeRange r = block_nodes_of(n, b, gridDim.x - hub_blocks);
+    for (int j = r.begin + hw; j < r.end; j += HW_PER_BLOCK) {
+        const int beg = col_ptr[j], cnt = col_ptr[j + 1] - beg;
+        if (cnt > SEG) continue;  // a hub
+        const SrcNode v = src_node_load(j, l, h, ed.g4, xw, alpha_loop, d_raw_loop, d_a_d);
+        float4 acc = zero4, dr = zero4;
+        if (cnt > 0) src_edges32(ed, beg, cnt, l, h, s_alpha[hw], acc, dr);
+        const float4 das4 = halfwave_reduce(dr, cnt > 4, SumOp());
+        src_finish(j, l, acc, pick(das4, h), f, v, d_xw, ps, pd);
+    }
+    block_partial_2h(ps, pd, partial, b);
+}
+
+// One block per hub at a time: half-wave hw adds the chunk rows hw, hw+8, ... of the hub (four loads in
+// flight), the eight sums are combined in half-wave order and half-wave 0 finishes the node.
+__global__ __launch_bounds__(THREADS) void k_gat_bwd_hub_finish(
+    const float* __restrict__ g_pre, const float* __restrict__ xw, const float* __restrict__ att_src,
+    const float* __restrict__ att_dst, const int4* __restrict__ hub_tab, const float* __restrict__ alpha_loop,
+    const float* __restrict__ d_raw_loop, const float* __restrict__ d_a_d, const float* __restrict__ part_acc,
+    const float* __restrict__ part_das, float* __restrict__ d_xw, float* __restrict__ partial /*[grid][2H]*/) {
+    __shared__ float s_acc[HW_PER_BLOCK][H];
+    __shared__ float s_das[HW_PER_BLOCK][HEADS];
+    const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
     SrcFinish f{reinterpret_cast<const float4*>(att_src)[l], reinterpret_cast<const float4*>(att_dst)[l]};
     const float4* g4 = reinterpret_cast<const float4*>(g_pre);
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pd = ps;
-    NodeRange r = block_nodes(n);
-    for (int base = r.begin; base < r.end; base += THREADS) {
-        // heavy nodes among the next THREADS nodes of the block's range, listed in node order
-        const int c = base + threadIdx.x;
-        const bool heavy = c < r.end && seg_base[c + 1] - seg_base[c] > 1;
-        const unsigned long long bal = __ballot(heavy);
-        if (lane == 0) s_wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = 0, m = 0;
+    const int4 hdr = hub_tab[0];
+    const int n_hub = hdr.x, total = hdr.y;
+    for (int k = blockIdx.x; k < n_hub; k += gridDim.x) {
+        const int4 t = hub_tab[1 + k];
+        const int c0 = t.w, c1 = k + 1 < n_hub ? hub_tab[2 + k].w : total;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float das = 0.f;
+        for (int c = c0 + hw; c < c1; c += 4 * HW_PER_BLOCK) {
+            float4 a[4];
+            float dd[4];
 #pragma unroll
-        for (int k = 0; k < THREADS / 64; ++k) {
-            off += k < wv ? s_wcnt[k] : 0;
-            m += s_wcnt[k];
-        }
-        if (heavy) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c;
-        __syncthreads();
-        // rows of node j in slots k_begin, k_begin + 32, ... (step k_step) of its list, added in slot
-        // order; lane q of the half-wave looks at the flag of one slot, rows exist only where it is set
-        auto sum_slots = [&](int first, int nsg, int k_begin, int k_step, float4& acc, float& das) {
-            for (int k0 = k_begin; k0 < nsg; k0 += k_step) {
-                const int slot = k0 + l;
-                const bool has = slot < nsg && part_flag[first + slot] != 0;
-                unsigned mk = (unsigned)(__ballot(has) >> (threadIdx.x & 32));   // this half-wave's 32 flags
-                while (mk) {
-                    int q[4];   // up to four rows in flight
-                    int cntq = 0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        q[u] = -1;
-                        if (mk) {
-                            q[u] = __ffs((int)mk) - 1;
-                            mk &= mk - 1;
-                            ++cntq;
-                        }
-                    }
-                    float4 a[4];
-                    float dd[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const size_t sl = (size_t)(first + k0 + (q[u] >= 0 ? q[u] : q[0]));
-                        a[u] = reinterpret_cast<const float4*>(part_acc + sl * H)[l];
-                        dd[u] = part_das[sl * HEADS + h];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u < cntq) {
-                            acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w;
-                            das += dd[u];
-                        }
-                }
+            for (int u = 0; u < 4; ++u) {
+                const size_t row = (size_t)min(c + u * HW_PER_BLOCK, c1 - 1);
+                a[u] = reinterpret_cast<const float4*>(part_acc + row * H)[l];
+                dd[u] = part_das[row * HEADS + h];
             }
-        };
-        // lists of at most 32 segments: one half-wave per node, no barrier
-        for (int t = hw; t < m; t += HW_PER_BLOCK) {
-            const int j = s_list[t];
-            const int first = seg_base[j], nsg = seg_base[j + 1] - first;
-            if (nsg > 32) continue;
-            float das = 0.f;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            sum_slots(first, nsg, 0, 32, acc, das);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c + u * HW_PER_BLOCK < c1) {
+                    acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w;
+                    das += dd[u];
+                }
+        }
+        reinterpret_cast<float4*>(&s_acc[hw][0])[l] = acc;
+        if ((l & 7) == 0) s_das[hw][h] = das;
+        __syncthreads();
+        if (hw == 0) {
+            const int j = t.x;
             const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
-            src_finish(j, l, acc, das, f, v, d_xw, ps, pd);
-        }
-        // longer lists: the whole block per node
-        for (int t = 0; t < m; ++t) {
-            const int j = s_list[t];
-            const int first = seg_base[j], nsg = seg_base[j + 1] - first;
-            if (nsg <= 32) continue;
-            float das = 0.f;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            sum_slots(first, nsg, hw * 32, HW_PER_BLOCK * 32, acc, das);
-            reinterpret_cast<float4*>(&s_acc[hw][0])[l] = acc;
-            if ((l & 7) == 0) s_das[hw][h] = das;
-            __syncthreads();
-            if (hw == 0) {
-                const SrcNode v = src_node_load(j, l, h, g4, xw, alpha_loop, d_raw_loop, d_a_d);
-                float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-                float dt = 0.f;
-                for (int q = 0; q < HW_PER_BLOCK; ++q) {
-                    const float4 a = reinterpret_cast<const float4*>(&s_acc[q][0])[l];
-                    tot.x += a.x; tot.y += a.y; tot.z += a.z; tot.w += a.w;
-                    dt += s_das[q][h];
-                }
-                src_finish(j, l, tot, dt, f, v, d_xw, ps, pd);
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            float dt = 0.f;
+            for (int q = 0; q < HW_PER_BLOCK; ++q) {
+                const float4 a = reinterpret_cast<const float4*>(&s_acc[q][0])[l];
+                tot.x += a.x; tot.y += a.y; tot.z += a.z; tot.w += a.w;
+                dt += s_das[q][h];
             }
-            __syncthreads();
+            src_finish(j, l, tot, dt, f, v, d_xw, ps, pd);
         }
         __syncthreads();
     }
-    block_partial_2h(ps, pd, partial);
+    block_partial_2h(ps, pd, partial, blockIdx.x);
 }
 
 // out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree.
@@ -802,40 +766,25 @@ int grid_blocks(int64_t n) {
 using namespace aig;
 
 extern "C" size_t aig_gat_csr_ws_bytes(int64_t n, int64_t E) {
-    if (E <= 0) return align_up((size_t)(n + 1) * 4) + align_up(scan_temp_bytes(n + 1)) + 256;
+    if (E <= 0) return 256;
     size_t t = sort_temp_bytes(E, key_bits(n)), t2 = scan_temp_bytes(n + 1);
-    return 4 * align_up((size_t)E * 4) + align_up((size_t)(n + 1) * 4) + align_up(t > t2 ? t : t2) + 256;
+    return 4 * align_up((size_t)E * 4) + 4 * align_up((size_t)(n + 1) * 4) + align_up(t > t2 ? t : t2) + 256;
 }
 
 extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_attr,
                            int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
-                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* seg_base,
-                           int32_t* seg_desc, void* ws, size_t ws_bytes, void* stream) {
+                           int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* hub_tab, void* ws,
+                           size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0 && E < INT_MAX, "aig_gat_csr: bad sizes n=%lld E=%lld", (long long)n,
                 (long long)E);
-    AIG_REQUIRE(row_ptr && col_ptr && seg_base && seg_desc && (n == 0 || loop_ea), "aig_gat_csr: null output");
-    const int nseg_cap = (int)(n + E / SEG + 1);
-    int4* desc = reinterpret_cast<int4*>(seg_desc);
+    AIG_REQUIRE(row_ptr && col_ptr && hub_tab && (n == 0 || loop_ea), "aig_gat_csr: null output");
+    int4* tab = reinterpret_cast<int4*>(hub_tab);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (E == 0) {
         AIG_HIP_CHECK(hipMemsetAsync(row_ptr, 0, (size_t)(n + 1) * 4, s));
         AIG_HIP_CHECK(hipMemsetAsync(col_ptr, 0, (size_t)(n + 1) * 4, s));
         if (n) AIG_HIP_CHECK(hipMemsetAsync(loop_ea, 0, (size_t)n * 4, s));
-        // one empty segment per node
-        hipLaunchKernelGGL(k_seg_count, dim3(grid_for(n + 1, 256, 4096)), dim3(256), 0, s, (int)n, col_ptr, seg_base);
-        AIG_LAUNCH_CHECK();
-        if (n) {
-            Carver c0(ws);
-            AIG_REQUIRE(ws && ws_bytes >= aig_gat_csr_ws_bytes(n, 0), "aig_gat_csr: workspace too small");
-            int* nch0 = c0.take<int>(n + 1);
-            size_t tb0 = scan_temp_bytes(n + 1);
-            void* temp0 = c0.take<char>(tb0);
-            AIG_HIP_CHECK(hipMemcpyAsync(nch0, seg_base, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, s));
-            AIG_HIP_CHECK(rocprim::exclusive_scan(temp0, tb0, nch0, seg_base, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
-            hipLaunchKernelGGL(k_seg_desc, dim3(grid_for(nseg_cap, 256, 4096)), dim3(256), 0, s, (int)n, nseg_cap,
-                               seg_base, col_ptr, desc);
-            AIG_LAUNCH_CHECK();
-        }
+        AIG_HIP_CHECK(hipMemsetAsync(tab, 0, sizeof(int4), s));   // no hubs
         return AIG_OK;
     }
     AIG_REQUIRE(edge_index && csr_src && csr_ea && csr_eid && csc_pos && csc_dst && ws, "aig_gat_csr: null pointer");
@@ -847,7 +796,10 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     unsigned* skey = c.take<unsigned>(E);
     int* ids = c.take<int>(E);
     int* seid = c.take<int>(E);
-    int* nch = c.take<int>(n + 1);
+    int* flag = c.take<int>(n + 1);
+    int* chunks = c.take<int>(n + 1);
+    int* rank = c.take<int>(n + 1);
+    int* cbase = c.take<int>(n + 1);
     size_t tb = sort_temp_bytes(E, bits), tb2 = scan_temp_bytes(n + 1);
     if (tb2 > tb) tb = tb2;
     void* temp = c.take<char>(tb);
@@ -867,11 +819,11 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     hipLaunchKernelGGL(k_csr_ptr, dim3(gn), dim3(256), 0, s, (int)n, (int)E, ssrc, col_ptr);
     hipLaunchKernelGGL(k_csc_fill, dim3(g), dim3(256), 0, s, (int)E, row_ptr + n, skey, csc_pos, csc_dst);
     hipLaunchKernelGGL(k_loop_attr, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, (int)n, row_ptr, csr_ea, loop_ea);
-    hipLaunchKernelGGL(k_seg_count, dim3(gn), dim3(256), 0, s, (int)n, col_ptr, nch);
+    hipLaunchKernelGGL(k_hub_count, dim3(gn), dim3(256), 0, s, (int)n, col_ptr, flag, chunks);
     AIG_LAUNCH_CHECK();
-    AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, nch, seg_base, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
-    hipLaunchKernelGGL(k_seg_desc, dim3(grid_for(nseg_cap, 256, 4096)), dim3(256), 0, s, (int)n, nseg_cap, seg_base,
-                       col_ptr, desc);
+    AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, flag, rank, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
+    AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, chunks, cbase, 0, (size_t)(n + 1), rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(k_hub_tab, dim3(gn), dim3(256), 0, s, (int)n, col_ptr, rank, cbase, tab);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -902,9 +854,9 @@ extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const f
 }
 
 extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {
-    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1), nseg = N + M / SEG + 1;
+    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1), chunks = hub_chunks_max(E);
     return align_up(N * H * 4) /*g_pre*/ + align_up(M * HEADS * 4) + 2 * align_up(N * HEADS * 4) +
-           align_up(nseg * H * 4) + align_up(nseg * HEADS * 4) + align_up(nseg * 4) + align_up((size_t)4097 * 2 * H * 4) +
+           align_up(chunks * H * 4) + align_up(chunks * HEADS * 4) + align_up((size_t)4097 * 2 * H * 4) +
            align_up((size_t)2048 * (H + HEADS) * 4) + 256;
 }
 
@@ -912,7 +864,7 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
                            const float* att_src, const float* att_dst, const float* ce, const float* a_s,
                            const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
                            const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
-                           const int32_t* csc_dst, const int32_t* seg_base, const int32_t* seg_desc,
+                           const int32_t* csc_dst, const int32_t* hub_tab,
                            const float* alpha_e,
                            const float* alpha_loop, float* d_xw,
                            float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, void* ws,
@@ -928,7 +880,7 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
         return AIG_OK;
     }
     AIG_REQUIRE(g_out && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
-                    seg_base && seg_desc && alpha_loop && d_xw && ws,
+                    hub_tab && alpha_loop && d_xw && ws,
                 "aig_gat_bwd: null pointer");
     if (ws_bytes < aig_gat_bwd_ws_bytes(n, E))
         return fail(AIG_EWORKSPACE, "aig_gat_bwd: workspace %zu < %zu", ws_bytes, aig_gat_bwd_ws_bytes(n, E));
@@ -937,30 +889,31 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     float* d_raw_e = c.take<float>((size_t)(E > 0 ? E : 1) * HEADS);
     float* d_raw_loop = c.take<float>((size_t)n * HEADS);
     float* d_a_d = c.take<float>((size_t)n * HEADS);
-    const size_t nseg_max = (size_t)n + (size_t)(E > 0 ? E : 1) / SEG + 1;
-    float* part_acc = c.take<float>(nseg_max * H);
-    float* part_das = c.take<float>(nseg_max * HEADS);
-    int* part_flag = c.take<int>(nseg_max);
+    float* part_acc = c.take<float>(hub_chunks_max(E) * H);
+    float* part_das = c.take<float>(hub_chunks_max(E) * HEADS);
     float* partial = c.take<float>((size_t)4097 * 2 * H);       // source-side kernels: [gs + g][2H]
     float* partial_dst = c.take<float>((size_t)2048 * (H + HEADS));  // target-side kernel: [g][H + HEADS]
     const int g = grid_blocks(n);
     hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
                        csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial_dst);
     AIG_LAUNCH_CHECK();
-    const int gs = grid_blocks((int64_t)nseg_max);
-    hipLaunchKernelGGL(k_gat_bwd_src_seg, dim3(gs), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
-                       reinterpret_cast<const int4*>(seg_desc), csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e,
-                       d_raw_loop, d_a_d, d_xw, part_acc, part_das, part_flag, partial);
-    hipLaunchKernelGGL(k_gat_bwd_src_heavy, dim3(g), dim3(THREADS), 0, s, (int)n, g_pre, xw, att_src, att_dst, seg_base,
-                       alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, part_flag, d_xw, partial + (size_t)gs * 2 * H);
+    // blocks of the by-source kernel: HUB_BLOCKS for the hubs' chunks (they leave at once when the graph
+    // has none), then gs over the nodes; the finishing kernel takes a hub per block
+    const int gs = grid_blocks(n);
+    const int4* tab = reinterpret_cast<const int4*>(hub_tab);
+    hipLaunchKernelGGL(k_gat_bwd_src, dim3(HUB_BLOCKS + gs), dim3(THREADS), 0, s, (int)n, HUB_BLOCKS, g_pre, xw, att_src,
+                       att_dst, tab, col_ptr, csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw,
+                       part_acc, part_das, partial);
+    hipLaunchKernelGGL(k_gat_bwd_hub_finish, dim3(HUB_FINISH_BLOCKS), dim3(THREADS), 0, s, g_pre, xw, att_src, att_dst, tab,
+                       alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();
     // bias gradient = first H columns of the target-side partials, edge-coefficient gradient = their
     // last HEADS columns; the attention vectors' gradients = the two halves of the source-side ones
     ColSums sums{};
     sums.j[0] = ColSum{partial_dst, d_bias, g, H + HEADS, H};
     sums.j[1] = ColSum{partial_dst + H, d_ce, g, H + HEADS, HEADS};
-    sums.j[2] = ColSum{partial, d_att_src, gs + g, 2 * H, H};
-    sums.j[3] = ColSum{partial + H, d_att_dst, gs + g, 2 * H, H};
+    sums.j[2] = ColSum{partial, d_att_src, gs + HUB_FINISH_BLOCKS, 2 * H, H};
+    sums.j[3] = ColSum{partial + H, d_att_dst, gs + HUB_FINISH_BLOCKS, 2 * H, H};
     hipLaunchKernelGGL(k_reduce_cols, dim3(3 * H + HEADS), dim3(256), 0, s, sums);
     AIG_LAUNCH_CHECK();
     return AIG_OK;

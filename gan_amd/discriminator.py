@@ -52,8 +52,7 @@ class GraphCSR:
         self.csr_eid = torch.empty(max(E, 1), **i32)
         self.csc_pos = torch.empty(max(E, 1), **i32)
         self.csc_dst = torch.empty(max(E, 1), **i32)
-        self.seg_base = torch.empty(n + 1, **i32)
-        self.seg_desc = torch.empty((n + E // 32 + 1, 4), **i32)
+        self.hub_tab = torch.empty((E // 33 + 2, 4), **i32)   # nodes with more than 32 out-edges, see aig_abi.h
         self.csr_ea = torch.empty(max(E, 1), **f32)
         self.loop_ea = torch.empty(max(n, 1), **f32)
         ei = edge_index.contiguous()
@@ -62,8 +61,8 @@ class GraphCSR:
         _abi.check(lib.aig_gat_csr(n, E, _abi.ptr(ei) if E else None, _abi.ptr(ea) if E else None,
                                    _abi.ptr(self.row_ptr), _abi.ptr(self.csr_src), _abi.ptr(self.csr_ea),
                                    _abi.ptr(self.csr_eid), _abi.ptr(self.loop_ea), _abi.ptr(self.col_ptr),
-                                   _abi.ptr(self.csc_pos), _abi.ptr(self.csc_dst), _abi.ptr(self.seg_base),
-                                   _abi.ptr(self.seg_desc), _abi.ptr(ws), ws.numel(),
+                                   _abi.ptr(self.csc_pos), _abi.ptr(self.csc_dst), _abi.ptr(self.hub_tab),
+                                   _abi.ptr(ws), ws.numel(),
                                    _abi.stream()), "aig_gat_csr")
 
 
@@ -135,7 +134,7 @@ class _GATAggregate(torch.autograd.Function):
                                    _abi.ptr(att_dst), _abi.ptr(ce), _abi.ptr(a_s), _abi.ptr(a_d),
                                    _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea),
                                    _abi.ptr(csr.loop_ea), _abi.ptr(csr.col_ptr), _abi.ptr(csr.csc_pos),
-                                   _abi.ptr(csr.csc_dst), _abi.ptr(csr.seg_base), _abi.ptr(csr.seg_desc), _abi.ptr(alpha_e),
+                                   _abi.ptr(csr.csc_dst), _abi.ptr(csr.hub_tab), _abi.ptr(alpha_e),
                                    _abi.ptr(alpha_loop),
                                    _abi.ptr(d_xw), _abi.ptr(d_as), _abi.ptr(d_ad), _abi.ptr(d_ce), _abi.ptr(d_bias),
                                    _abi.ptr(ws), ws.numel(), _abi.stream(), meta=(n, csr.E)), "aig_gat_bwd")

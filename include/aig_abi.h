@@ -129,14 +129,14 @@ int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, const int32_t*
  *       (row_ptr[n] = number of kept edges); csr_eid = position in the caller's edge list
  *   loop_ea[n]: attribute of the implicit self loop = mean attribute of the entering edges, 0 if none
  *   col_ptr[n+1], csc_pos/csc_dst [E]: edges leaving node u; csc_pos indexes the by-target arrays
- *   seg_base[n+1]: the out-edge list of node u is cut into pieces of 32 edges, numbered seg_base[u]..seg_base[u+1]
- *       (at least one per node) - the unit of work of the backward pass, whatever the fan-out skew
- *   seg_desc[4*(n + E/32 + 1)]: per piece {owning node, first position, one past the last position in the
- *       by-source list, number of pieces of the owner} */
+ *   hub_tab[4*(E/33 + 2)]: the nodes with more than 32 out-edges ("hubs"; a generated graph hangs most gates on
+ *       two or three of them), whose lists the backward pass cuts into chunks of 256 edges:
+ *       entry 0 = {hubs, chunks of all hubs, 0, 0}, entry 1+k = {node, first position in the by-source list,
+ *       fan-out, first chunk} of the k-th hub in node order */
 size_t aig_gat_csr_ws_bytes(int64_t n, int64_t E);
 int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* edge_attr,
                 int32_t* row_ptr, int32_t* csr_src, float* csr_ea, int32_t* csr_eid, float* loop_ea,
-                int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* seg_base, int32_t* seg_desc,
+                int32_t* col_ptr, int32_t* csc_pos, int32_t* csc_dst, int32_t* hub_tab,
                 void* ws, size_t ws_bytes, void* stream);
 
 /* Attention logits' node terms after the dense projection xw = x W^T ([n,128], 4 heads x 32 channels):
@@ -160,8 +160,8 @@ size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E);
 int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
                 const float* att_src, const float* att_dst, const float* ce, const float* a_s, const float* a_d,
                 const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea, const float* loop_ea,
-                const int32_t* col_ptr, const int32_t* csc_pos, const int32_t* csc_dst, const int32_t* seg_base,
-                const int32_t* seg_desc, const float* alpha_e, const float* alpha_loop,
+                const int32_t* col_ptr, const int32_t* csc_pos, const int32_t* csc_dst, const int32_t* hub_tab,
+                const float* alpha_e, const float* alpha_loop,
                 float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
                 void* ws, size_t ws_bytes, void* stream);
 

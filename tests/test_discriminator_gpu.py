@@ -63,7 +63,41 @@ def graphs():
     g["star_skew"] = Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.stack([src, dst])),
                           edge_attr=torch.from_numpy(rng.integers(0, 2, src.size).astype(np.float32)).view(-1, 1),
                           node_depth=torch.from_numpy(rng.integers(0, 12, n)))
+    # several sources whose fan-out sits on either side of the backward pass's piece sizes (32 / 256 edges)
+    n = 1500
+    rng = np.random.default_rng(6)
+    src, dst = [rng.integers(0, n, 800)], [rng.integers(0, n, 800)]
+    for hub, fan in HUBS:
+        src.append(np.full(fan, hub, np.int64))
+        dst.append(rng.choice(np.setdiff1d(np.arange(n), [hub]), fan, replace=False))
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    x = np.stack([rng.choice([0, 1, 2], n), rng.integers(0, 3, n)], 1).astype(np.float32)
+    g["multi_hub"] = Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.stack([src, dst])),
+                          edge_attr=torch.from_numpy(rng.integers(0, 2, src.size).astype(np.float32)).view(-1, 1),
+                          node_depth=torch.from_numpy(rng.integers(0, 9, n)))
     return g
+
+
+HUBS = [(3, 32), (4, 33), (10, 256), (11, 257), (700, 600), (1499, 513)]
+
+
+def test_hub_table():
+    d = graphs()["multi_hub"]
+    n = d.x.size(0)
+    csr = GraphCSR(d.edge_index.to(DEV), d.edge_attr.to(DEV), n)
+    torch.cuda.synchronize()
+    keep = d.edge_index[0] != d.edge_index[1]
+    fan = torch.bincount(d.edge_index[0][keep], minlength=n)
+    hubs = [(j, int(fan[j])) for j in range(n) if fan[j] > 32]
+    assert {j for j, _ in hubs} >= {4, 10, 11, 700, 1499} and 3 not in {j for j, _ in hubs}
+    tab = csr.hub_tab.cpu().tolist()
+    col_ptr = csr.col_ptr.cpu().tolist()
+    chunks = [(f + 255) // 256 for _, f in hubs]
+    assert tab[0] == [len(hubs), sum(chunks), 0, 0]
+    first = 0
+    for k, (j, f) in enumerate(hubs):
+        assert tab[1 + k] == [j, col_ptr[j], f, first]
+        first += chunks[k]
 
 
 @pytest.mark.parametrize("name", list(graphs().keys()))
