@@ -99,7 +99,26 @@ class Data:
 
 
 class Batch(Data):
-    """Several graphs stacked into one disjoint graph (train.py:245,281)."""
+    """Several graphs stacked into one disjoint graph (train.py:245,281).
+
+    ``batch`` (graph id per node) and ``ptr`` (node offsets) are built on first use: nothing on the
+    training path reads them, and building them on a GPU costs two blocking host-to-device copies
+    per minibatch."""
+
+    def __getattr__(self, name: str):   # reached only when the attribute is not set yet
+        if name in ("batch", "ptr") and "_node_counts" in self.__dict__:
+            counts, dev = self.__dict__["_node_counts"], self.x.device
+            self.__dict__["batch"] = torch.repeat_interleave(
+                torch.arange(len(counts), device=dev), torch.tensor(counts, device=dev), output_size=sum(counts))
+            self.__dict__["ptr"] = torch.tensor(self.__dict__["_offsets"], dtype=torch.long, device=dev)
+            return self.__dict__[name]
+        raise AttributeError(f"{self.__class__.__name__!r} object has no attribute {name!r}")
+
+    def keys(self) -> List[str]:
+        ks = super().keys()
+        if "_node_counts" in self.__dict__:
+            ks += [k for k in ("batch", "ptr") if k not in ks]
+        return ks
 
     @classmethod
     def from_data_list(cls, data_list: Sequence[Data]) -> "Batch":
@@ -131,10 +150,7 @@ class Batch(Data):
                 for v in vals:
                     cuts.append(cuts[-1] + int(v.size(0)))
             slices[key] = cuts
-        dev = data_list[0].x.device
-        out.batch = torch.repeat_interleave(
-            torch.arange(len(data_list), device=dev), torch.tensor(node_counts, device=dev))
-        out.ptr = torch.tensor(offsets, dtype=torch.long, device=dev)
+        out._node_counts, out._offsets = node_counts, offsets
         out._slices = slices
         out._num_graphs = len(data_list)
         return out
@@ -145,7 +161,7 @@ class Batch(Data):
 
     def to_data_list(self) -> List[Data]:
         outs: List[Data] = []
-        ptr = self.ptr.tolist()
+        ptr = self._offsets
         for g in range(self._num_graphs):
             d = Data()
             for key, cuts in self._slices.items():

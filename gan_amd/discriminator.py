@@ -73,12 +73,16 @@ class LevelPlan:
         lib = _abi.lib()
         L = 0
         depth = None
+        nvalid = None
         if node_depth is not None and n > 0:
             nd = node_depth.to(device)
-            top = int(nd.max().item())  # host read, once per depth vector (the plan is cached)
+            # the one host read per depth vector (the plan is cached): deepest level and nodes with a level
+            top, nvalid = (int(v) for v in torch.stack([nd.max().long(), (nd >= 0).sum()]).tolist())
             if top >= 0:                # otherwise no valid level: pool over all nodes (discriminator.py:68-72)
                 L = top
                 depth = nd.to(torch.int64).contiguous()
+            else:
+                nvalid = None
         self.n, self.L = int(n), int(L)
         i32 = dict(dtype=torch.int32, device=device)
         self.perm = torch.empty(max(n, 1), **i32)
@@ -89,7 +93,8 @@ class LevelPlan:
         _abi.check(lib.aig_level_plan(n, L, _abi.ptr(depth), _abi.ptr(self.perm), _abi.ptr(self.lvl_ptr),
                                       _abi.ptr(self.node_level), _abi.ptr(self.w), _abi.ptr(ws), ws.numel(),
                                       _abi.stream()), "aig_level_plan")
-        self.nvalid = int(self.lvl_ptr[L + 1].item()) if n > 0 else 0
+        # lvl_ptr[L + 1] = nodes in levels 0..L; without a depth vector every node sits in level 0
+        self.nvalid = (nvalid if nvalid is not None else n) if n > 0 else 0
 
 
 class _GATAggregate(torch.autograd.Function):

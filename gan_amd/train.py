@@ -8,8 +8,10 @@ penalty, then the generator step evaluates ``-D(raw) + lambda_cons * penalties``
 
 What differs, on purpose:
 * every model / constraint call runs on the GPU kernels of this package (no CPU path);
-* ``sanitize_for_D`` of the real and fake batch is hoisted out of the critic loop (its result
-  does not change between iterations), which lets the critic reuse one CSR per edge list;
+* ``sanitize_for_D`` of the real batch is hoisted out of the critic loop (its result does not change
+  between iterations), which lets the critic reuse one CSR per edge list; the fake batches go to the
+  critic with their ``-1`` padding columns, which the CSR builder drops itself (a boolean-mask copy
+  would make the host wait for the GPU), and the columns ``sanitize_for_D`` would keep are only counted;
 * with ``WORLD_SIZE > 1`` (torchrun) the shuffled minibatches are dealt to the ranks and the
   critic gradient is averaged over ranks after every ``loss_D.backward()`` (gan_amd/parallel.py);
 * the real-side critic term and the gradient penalty of a minibatch are recorded as HIP graphs
@@ -26,6 +28,7 @@ from __future__ import annotations
 import argparse
 import csv
 import os
+import time
 import traceback
 from collections import OrderedDict
 from typing import Dict, List, Optional
@@ -249,7 +252,8 @@ class Trainer:
         self.global_step = 0
         self._templates: Dict[int, Data] = {}
         self.last: Dict[str, torch.Tensor] = {}
-        self.edges_last_step = 0
+        self._edges_last = None   # device scalar: edge columns of the last step's critic inputs
+        self._raw_depth: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
         # random draws of the loop (train.py:143,241,276); tests substitute recorded values
         self.draw_z = lambda: torch.randn(args.z_dim, device=device)
         self.draw_alpha = lambda: torch.rand(1, 1, device=device)
@@ -259,13 +263,13 @@ class Trainer:
         # ... and so do the critic's fakes (generator pass and repair), underneath the recorded
         # real-side term of the first critic iteration
         self.overlap_fakes = not bool(getattr(args, "no_overlap", False)) and os.environ.get("AIG_NO_OVERLAP") != "1"
-        self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream)] of the last step
+        self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
 
     def _mark(self, label: str) -> None:
         if self.marks is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            self.marks.append((label, ev))
+            self.marks.append((label, ev, time.perf_counter()))
 
     # templates are the same tensors every epoch: keep them (and their generator plan) per sample
     def templates_of(self, real_padded: Batch) -> List[Data]:
@@ -307,6 +311,11 @@ class Trainer:
             self._captured.popitem(last=False)
         return terms
 
+    @property
+    def edges_last_step(self) -> int:
+        """Edge columns the critic saw in the last step: real + fake, ``-1`` padding excluded (one host read)."""
+        return 0 if self._edges_last is None else int(self._edges_last.item())
+
     def _pad_batch(self, graphs: List[Data]) -> Batch:
         return Batch.from_data_list([pad_data(g, self.max_nodes, self.max_edges) for g in graphs]).to(self.device)
 
@@ -335,10 +344,11 @@ class Trainer:
                 raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
                 corr_fakes_once = [enforce_aig_constraints(r) for r in raw_fakes_once]
                 fake_padded = self._pad_batch(corr_fakes_once)
-                fake_for_D = sanitize_for_D(fake_padded)
+                fake_for_D = fake_padded
+                edges_fake = valid_edge_mask(fake_padded).sum()
             main_stream.wait_stream(fakes_stream)
             self._mark("fakes ready")
-            self.edges_last_step = int(real_for_D.edge_index.size(1) + fake_for_D.edge_index.size(1))
+            self._edges_last = edges_fake + int(real_for_D.edge_index.size(1))
         except Exception as e:
             if self.world == 1:
                 raise
@@ -393,7 +403,19 @@ class Trainer:
         with torch.cuda.stream(self.side_stream):
             pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
             loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
-        raw_batch_for_D = sanitize_for_D(self._pad_batch(raw_gen))
+        raw_batch_for_D = self._pad_batch(raw_gen)
+        ids = getattr(real_padded, "sample_ids", None)
+        if ids is not None:
+            # the generator hands the template's depths through unchanged, so the padded depth vector of
+            # a minibatch is the same every time: keeping the first one lets the critic reuse its level plan
+            key = tuple(int(i) for i in ids)
+            kept = self._raw_depth.get(key)
+            if kept is None or kept.shape != raw_batch_for_D.node_depth.shape:
+                self._raw_depth[key] = raw_batch_for_D.node_depth
+                if len(self._raw_depth) > 16:
+                    self._raw_depth.popitem(last=False)
+            else:
+                raw_batch_for_D.node_depth = kept
         loss_G_adv = -torch.mean(D(raw_batch_for_D))
         main_stream.wait_stream(self.side_stream)
         loss_pen.record_stream(main_stream)

@@ -61,3 +61,16 @@ def test_loader_shards_batches_across_ranks():
     r1 = [b.sample_ids for b in GraphLoader(items, batch_size=2, seed=5, rank=1, world_size=2)]
     assert len(r0) == len(r1) == 2                      # 5 batches -> 4 usable, 2 per rank
     assert r0 == full[0:4:2] and r1 == full[1:4:2]
+
+
+def test_batch_vector_and_offsets_are_built_on_first_use():
+    from gan_amd.data import Batch, Data
+    parts = [Data(x=torch.zeros(k, 2), edge_index=torch.zeros(2, 1, dtype=torch.long)) for k in (3, 1, 4)]
+    b = Batch.from_data_list(parts)
+    assert "batch" not in b.__dict__ and "ptr" not in b.__dict__
+    assert {"batch", "ptr"} <= set(b.keys()) and hasattr(b, "batch")
+    assert b.ptr.tolist() == [0, 3, 4, 8]
+    assert b.batch.tolist() == [0, 0, 0, 1, 2, 2, 2, 2]
+    assert [int(d.x.size(0)) for d in b.to_data_list()] == [3, 1, 4]
+    with __import__("pytest").raises(AttributeError):
+        b.no_such_attribute

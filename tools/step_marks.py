@@ -23,7 +23,8 @@ for extra in ([], ["--no-overlap"]):
         tr.step(real)
         torch.cuda.synchronize()
         m = tr.marks
-        for (la, ea), (lb, eb) in zip(m, m[1:]):
+        for (la, ea, ha), (lb, eb, hb) in zip(m, m[1:]):
             acc[lb] = acc.get(lb, 0.0) + ea.elapsed_time(eb)
+            acc[lb + " (host)"] = acc.get(lb + " (host)", 0.0) + (hb - ha) * 1e3
     wall = (time.perf_counter() - t0) / reps * 1e3
     print(extra or "overlap", {k: round(v / reps, 2) for k, v in acc.items()}, "wall/step incl. sync", round(wall, 2))
