@@ -36,7 +36,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import parallel
-from .constraints import aig_constraint_penalties, enforce_aig_constraints, validate_strict_aig
+from .constraints import (aig_constraint_penalties, enforce_aig_constraints, enforce_begin, enforce_finish,
+                          validate_strict_aig)
 from .data import Batch, Data, GraphLoader
 from .dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
 from .discriminator import AIGDiscriminator
@@ -342,7 +343,9 @@ class Trainer:
             with torch.cuda.stream(fakes_stream):
                 zs_once = [self.draw_z() for _ in templates]
                 raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
-                corr_fakes_once = [enforce_aig_constraints(r) for r in raw_fakes_once]
+                # every repair is enqueued before the first edge count is awaited: one wait per minibatch
+                repairs = [enforce_begin(r) for r in raw_fakes_once]
+                corr_fakes_once = [enforce_finish(h) for h in repairs]
                 fake_padded = self._pad_batch(corr_fakes_once)
                 fake_for_D = fake_padded
                 edges_fake = valid_edge_mask(fake_padded).sum()
