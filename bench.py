@@ -210,7 +210,14 @@ def main():
         for _ in sample_many(trainer.G, ((t, draw_z) for _ in range(iters) for t in templates), streams=sample_streams):
             pass
 
+    # the matrix-core roofline is read here, where nothing else shares the GPU with the projection
+    # kernel (inside a training step the generator pass runs next to the replayed critic term)
+    _abi.timeline.reset()
+    _abi.timeline.only = {"aig_gen_node_proj"}
+    _abi.timeline.enabled = True
     sample_nodes_per_sec_single = sample_rate(one_at_a_time)
+    _abi.timeline.enabled = False
+    tl_proj = _abi.timeline.totals_ms()
     sample_nodes_per_sec = sample_rate(in_flight)
 
     if rank == 0:
@@ -226,7 +233,7 @@ def main():
         # the dense contraction of the path: node projections of the generator (7 products of
         # [n,128]x[128,128] per sample) on the f32 matrix cores, flops executed / event time
         mfma = None
-        ms_proj, n_proj = tl_all.get("aig_gen_node_proj", (0.0, 0))
+        ms_proj, n_proj = tl_proj.get("aig_gen_node_proj", (0.0, 0))
         if n_proj:
             flops = 7 * 2.0 * 128 * 128 * nodes_per_iter * (n_proj / max(len(templates), 1))   # one launch per template
             tf = flops / (ms_proj * 1e-3) / 1e12
@@ -248,7 +255,8 @@ def main():
             "roofline": roof,
             "roofline_mfma": mfma,
             "timeline_ms_per_step": {k: round(v[0] / inst_steps, 3) for k, v in sorted(tl_all.items())},
-            "timeline_note": f"GPU ms per step by entry point, from {inst_steps} extra instrumented steps outside the timed region",
+            "timeline_note": f"GPU ms per step by entry point, from {inst_steps} extra instrumented steps outside the timed region "
+                             "(event brackets on the launching stream; entry points that run next to another stream's work include that contention)",
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
