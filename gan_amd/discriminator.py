@@ -324,6 +324,39 @@ class GATLayer(nn.Module):
         return _GATAggregate.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), ce, self.bias, csr)
 
 
+class _CriticHead(torch.autograd.Function):
+    """``out(mlp(r))`` for one pooled row (discriminator.py:98-100): one launch forward, one backward.
+    Differentiable once; the gradient penalty's second-order path uses the torch modules or the closed form."""
+
+    @staticmethod
+    def forward(ctx, r, w1, b1, w2, b2, w3, b3):
+        lib = _abi.lib()
+        tensors = [t.contiguous() for t in (r, w1, b1, w2, b2, w3, b3)]
+        r_, w1_, b1_, w2_, b2_, w3_, b3_ = tensors
+        score = torch.empty(1, dtype=torch.float32, device=r.device)
+        act = torch.empty(192, dtype=torch.float32, device=r.device)
+        _abi.check(lib.aig_head_fwd(_abi.ptr(r_), _abi.ptr(w1_), _abi.ptr(b1_), _abi.ptr(w2_), _abi.ptr(b2_),
+                                    _abi.ptr(w3_), _abi.ptr(b3_), _abi.ptr(score), _abi.ptr(act), _abi.stream()),
+                   "aig_head_fwd")
+        ctx.save_for_backward(r_, w1_, w2_, w3_, act)
+        return score
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_score):
+        lib = _abi.lib()
+        r, w1, w2, w3, act = ctx.saved_tensors
+        f32 = dict(dtype=torch.float32, device=r.device)
+        d_r = torch.empty((1, 256), **f32)
+        d_w1, d_b1 = torch.empty((128, 256), **f32), torch.empty(128, **f32)
+        d_w2, d_b2 = torch.empty((64, 128), **f32), torch.empty(64, **f32)
+        d_w3, d_b3 = torch.empty((1, 64), **f32), torch.empty(1, **f32)
+        _abi.check(lib.aig_head_bwd(_abi.ptr(g_score.contiguous()), _abi.ptr(r), _abi.ptr(w1), _abi.ptr(w2), _abi.ptr(w3),
+                                    _abi.ptr(act), _abi.ptr(d_r), _abi.ptr(d_w1), _abi.ptr(d_b1), _abi.ptr(d_w2),
+                                    _abi.ptr(d_b2), _abi.ptr(d_w3), _abi.ptr(d_b3), _abi.stream()), "aig_head_bwd")
+        return d_r, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3
+
+
 class _Cache(OrderedDict):
     def __init__(self, cap: int = 16):
         super().__init__()
@@ -376,8 +409,8 @@ class AIGDiscriminator(nn.Module):
         """``gradient_penalty(use_edges=False)`` of train.py:133-152 and its gradient w.r.t. the critic's
         parameters without autograd on the node tensors: on an empty edge list each attention layer
         is ``elu(x W^T + b)``, which makes the penalty a closed form (four [n,128]x[128,128]
-        products, three node-dimension weight gradients, a few row-wise passes).  Only the small
-        head is differentiated by autograd.  Returns ``(gp, grad_norm, grads)`` with ``grads`` a dict
+        products, three node-dimension weight gradients, a few row-wise passes; the head's input
+        gradient and its second-order share come from the head kernels).  Returns ``(gp, grad_norm, grads)`` with ``grads`` a dict
         parameter -> gradient of ``gp`` (parameters the edge-free pass never touches are absent)."""
         lib = _abi.lib()
         dev = x_real.device
@@ -402,13 +435,17 @@ class AIGDiscriminator(nn.Module):
         _abi.check(lib.aig_level_pool_fwd(n, plan.nvalid, plan.L, _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
                                           _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(r), _abi.ptr(argmax),
                                           _abi.ptr(ws), ws.numel(), st), "aig_level_pool_fwd")
-        # head: s = out(mlp(r)); g_r = ds/dr stays attached to the head's weights
-        head = [p for p in list(self.mlp.parameters()) + list(self.out.parameters())]
-        with torch.enable_grad():
-            r = r.requires_grad_(True)
-            s = self.out(self.mlp(r)).sum()
-            (g_r,) = torch.autograd.grad(s, [r], create_graph=True)
-        g_r_c = g_r.detach().contiguous()
+        # head: s = out(mlp(r)), g_r = ds/dr (the backward kernel of the head with ds = 1)
+        hw1, hb1 = self.mlp[0].weight.detach().contiguous(), self.mlp[0].bias.detach().contiguous()
+        hw2, hb2 = self.mlp[2].weight.detach().contiguous(), self.mlp[2].bias.detach().contiguous()
+        hw3, hb3 = self.out.weight.detach().contiguous(), self.out.bias.detach().contiguous()
+        score, act = torch.empty(1, **f32), torch.empty(192, **f32)
+        _abi.check(lib.aig_head_fwd(_abi.ptr(r), _abi.ptr(hw1), _abi.ptr(hb1), _abi.ptr(hw2), _abi.ptr(hb2),
+                                    _abi.ptr(hw3), _abi.ptr(hb3), _abi.ptr(score), _abi.ptr(act), st), "aig_head_fwd")
+        g_r_c = torch.empty((1, 2 * HIDDEN), **f32)
+        one = torch.ones(1, **f32)
+        _abi.check(lib.aig_head_bwd(_abi.ptr(one), _abi.ptr(r), _abi.ptr(hw1), _abi.ptr(hw2), _abi.ptr(hw3), _abi.ptr(act),
+                                    _abi.ptr(g_r_c), None, None, None, None, None, None, st), "aig_head_bwd")
         g_z2, g_h1, g_z1 = (torch.empty((n, HIDDEN), **f32) for _ in range(3))
         g_x, norm_sq = torch.empty((n, 2), **f32), torch.empty(1, **f32)
         ws = _abi.workspace(lib.aig_gp_input_grad_ws_bytes(n), dev)
@@ -429,14 +466,25 @@ class AIGDiscriminator(nn.Module):
                                          _abi.ptr(g_x), _abi.ptr(dW1), _abi.ptr(db1), _abi.ptr(dW2), _abi.ptr(db2),
                                          _abi.ptr(u_gr), _abi.ptr(ws), ws.numel(), st), "aig_gp_param_grad")
         grads = {self.gat1.lin.weight: dW1, self.gat1.bias: db1, self.gat2.lin.weight: dW2, self.gat2.bias: db2}
-        head_grads = torch.autograd.grad(g_r, head, grad_outputs=u_gr, allow_unused=True)
-        for p_, g_ in zip(head, head_grads):
-            if g_ is not None:
-                grads[p_] = g_
+        # the head's share: gradient of <g_r, u_gr> w.r.t. its weights (its biases only move the ReLU masks)
+        dhw1, dhw2, dhw3 = torch.empty((128, 256), **f32), torch.empty((64, 128), **f32), torch.empty((1, 64), **f32)
+        _abi.check(lib.aig_head_input_grad_wgrad(_abi.ptr(u_gr), _abi.ptr(hw1), _abi.ptr(hw2), _abi.ptr(hw3), _abi.ptr(act),
+                                                 _abi.ptr(dhw1), _abi.ptr(dhw2), _abi.ptr(dhw3), st),
+                   "aig_head_input_grad_wgrad")
+        grads[self.mlp[0].weight], grads[self.mlp[2].weight], grads[self.out.weight] = dhw1, dhw2, dhw3
         return gp.detach(), norm.detach(), grads
 
-    def forward(self, data: Data) -> torch.Tensor:
+    def _head_is_fused(self, r: torch.Tensor) -> bool:
+        return (tuple(r.shape) == (1, 2 * HIDDEN) and r.dtype == torch.float32 and self.hidden_dim == HIDDEN and
+                os.environ.get("AIG_NO_FUSED_HEAD") != "1")
+
+    def forward(self, data: Data, twice_differentiable: bool = False) -> torch.Tensor:
+        """The fused head kernel is differentiable once.  When the node features themselves require a
+        gradient - the autograd form of the gradient penalty differentiates the critic w.r.t. its input and
+        then once more (train.py:143-150) - or when ``twice_differentiable`` is set, the head runs as torch
+        modules, which can be differentiated again."""
         x = data.x.float()
+        twice_differentiable = twice_differentiable or x.requires_grad
         if x.device.type != "cuda":
             raise _abi.AigAbiError("AIGDiscriminator.forward needs the graph on a HIP device (no CPU path exists)")
         n = int(x.size(0))
@@ -449,5 +497,8 @@ class AIGDiscriminator(nn.Module):
         nd = data.node_depth if (hasattr(data, "node_depth") and data.node_depth is not None) else None
         plan = self.level_plan(nd, n, x.device)
         graph_repr = _LevelPool.apply(h, plan)           # [1, 2H]
+        if not twice_differentiable and self._head_is_fused(graph_repr):
+            return _CriticHead.apply(graph_repr, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
+                                     self.mlp[2].bias, self.out.weight, self.out.bias)
         g = self.mlp(graph_repr)
         return self.out(g).view(-1)

@@ -173,6 +173,23 @@ int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, cons
 int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,
                   float* y, void* stream);
 
+/* Critic head: score = out(mlp(r)) for the pooled graph vector r [256] - Linear(256,128), ReLU, Linear(128,64),
+ * ReLU, Linear(64,1) (models/discriminator.py:36-40,98-100) - in one launch, and its backward pass in one launch
+ * (torch runs three GEMV launches forward and a dozen small launches backward, ten times per training step).
+ *   w1 [128,256], b1 [128], w2 [64,128], b2 [64], w3 [64], b3 [1] as the Linear layers store them
+ *   act [192]: the activations of the two hidden layers, kept for the backward calls
+ * aig_head_bwd: d_score [1] on the device; any of the seven outputs may be NULL.  With d_score = 1 its d_r is the
+ * input gradient ds/dr the gradient penalty starts from (train.py:143-150 on the head).
+ * aig_head_input_grad_wgrad: gradient of <ds/dr, u> w.r.t. w1, w2, w3 (u [256]; the biases get none) - the head's
+ * share of the second-order term of the gradient penalty, which autograd obtains by differentiating twice. */
+int aig_head_fwd(const float* r, const float* w1, const float* b1, const float* w2, const float* b2,
+                 const float* w3, const float* b3, float* score, float* act, void* stream);
+int aig_head_bwd(const float* d_score, const float* r, const float* w1, const float* w2, const float* w3,
+                 const float* act, float* d_r, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3,
+                 float* d_b3, void* stream);
+int aig_head_input_grad_wgrad(const float* u, const float* w1, const float* w2, const float* w3, const float* act,
+                              float* d_w1, float* d_w2, float* d_w3, void* stream);
+
 /* Weight gradient of a dense projection xw = x W^T over the nodes (the reduction torch.nn.functional.linear's
  * backward performs for gat{1,2}.lin at discriminator.py:60-61): dW[j][f] = sum_n g[n][j] * x[n][f],
  * g [n,128], x [n,F], dW [128,F]; F in {1, 2, 4, 128}. */

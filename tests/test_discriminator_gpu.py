@@ -287,3 +287,47 @@ def test_closed_form_gradient_penalty_matches_autograd(case):
         assert p in grads
         err = float((grads[p] - r).abs().max()) / float(r.abs().max())
         assert err <= 1e-4, (tuple(p.shape), err)
+
+
+def test_fused_head_matches_torch_modules():
+    """One-launch head (forward, backward, input gradient, second-order weight gradient) against the
+    same three Linear layers run by torch."""
+    D, _ = make_critic(seed=9)
+    with torch.no_grad():
+        for q in list(D.mlp.parameters()) + list(D.out.parameters()):
+            q.add_(0.05 * torch.randn_like(q))
+    g = torch.Generator().manual_seed(3)
+    r = torch.randn(1, 256, generator=g).to(DEV)
+    params = [D.mlp[0].weight, D.mlp[0].bias, D.mlp[2].weight, D.mlp[2].bias, D.out.weight, D.out.bias]
+    from gan_amd.discriminator import _CriticHead
+    r1 = r.clone().requires_grad_(True)
+    s1 = _CriticHead.apply(r1, *params)
+    g1 = torch.autograd.grad(s1.sum() * 1.7, [r1] + params)
+    r2 = r.clone().requires_grad_(True)
+    s2 = D.out(D.mlp(r2)).view(-1)
+    g2 = torch.autograd.grad(s2.sum() * 1.7, [r2] + params, create_graph=False)
+    close(s1.detach().cpu().numpy(), s2.detach().cpu().numpy(), what="score")
+    for a, b, name in zip(g1, g2, ["r", "w1", "b1", "w2", "b2", "w3", "b3"]):
+        assert a.shape == b.shape, name
+        close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, what="head grad " + name)
+    # second order: gradient of <ds/dr, u> w.r.t. the weights
+    lib = _abi.lib()
+    u = torch.randn(1, 256, generator=g).to(DEV)
+    r3 = r.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(D.out(D.mlp(r3)).sum(), [r3], create_graph=True)
+    ref = torch.autograd.grad(gr, [D.mlp[0].weight, D.mlp[2].weight, D.out.weight], grad_outputs=u)
+    w1, b1, w2, b2, w3, b3 = (q.detach().contiguous() for q in params)
+    score, act = torch.empty(1, device=DEV), torch.empty(192, device=DEV)
+    _abi.check(lib.aig_head_fwd(_abi.ptr(r.contiguous()), _abi.ptr(w1), _abi.ptr(b1), _abi.ptr(w2), _abi.ptr(b2),
+                                _abi.ptr(w3), _abi.ptr(b3), _abi.ptr(score), _abi.ptr(act), _abi.stream()))
+    d1, d2, d3 = torch.empty(128, 256, device=DEV), torch.empty(64, 128, device=DEV), torch.empty(1, 64, device=DEV)
+    _abi.check(lib.aig_head_input_grad_wgrad(_abi.ptr(u.contiguous()), _abi.ptr(w1), _abi.ptr(w2), _abi.ptr(w3),
+                                             _abi.ptr(act), _abi.ptr(d1), _abi.ptr(d2), _abi.ptr(d3), _abi.stream()))
+    for a, b, name in zip((d1, d2, d3), ref, ("w1", "w2", "w3")):
+        close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, what="second-order " + name)
+    # a critic fed features that require a gradient keeps the twice-differentiable head
+    x = torch.zeros(5, 2, device=DEV).requires_grad_(True)
+    out = D(Data(x=x, edge_index=torch.zeros((2, 0), dtype=torch.long, device=DEV)))
+    (gx,) = torch.autograd.grad(out.sum(), [x], create_graph=True)
+    gx.pow(2).sum().backward()
+    assert D.mlp[0].weight.grad is not None
