@@ -43,10 +43,10 @@ SIGNATURES = {
     "aig_gen_emit": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "aig_gat_csr_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_csr": (INT, [I64, I64] + [P] * 11 + [P, SZ, P]),
-    "aig_gat_node_alpha": (INT, [I64, P, P, P, P, P, P]),
+    "aig_gat_node_alpha": (INT, [I64, P, P, P, P, P, P, P, P, P]),
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
-    "aig_gat_bwd": (INT, [I64, I64] + [P] * 23 + [P, SZ, P]),
+    "aig_gat_bwd": (INT, [I64, I64] + [P] * 27 + [P, SZ, P]),
     "aig_level_pool_bwd": (INT, [I64, I64, P, P, P, P, P, P]),
     "aig_level_pool_bwd_adj_ws_bytes": (SZ, [I64]),
     "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),

@@ -164,12 +164,22 @@ __device__ __forceinline__ float head_sum(float v) {  // sum over the 8 lanes of
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : NEG_SLOPE * x; }
 
-// a_s[i,h] = <xw[i,h,:], att_src[h,:]>, a_d likewise
+// a_s[i,h] = <xw[i,h,:], att_src[h,:]>, a_d likewise; block 0 also leaves the edge coefficients
+// ce[h] = <lin_edge.weight[h,:], att_edge[h,:]> (edge_dim = 1: the attention term of an edge is attr * ce[h])
 __global__ __launch_bounds__(THREADS) void k_gat_node_alpha(int n, const float* __restrict__ xw,
                                                             const float* __restrict__ att_src,
                                                             const float* __restrict__ att_dst,
-                                                            float* __restrict__ a_s, float* __restrict__ a_d) {
+                                                            const float* __restrict__ lin_edge_w,
+                                                            const float* __restrict__ att_edge,
+                                                            float* __restrict__ a_s, float* __restrict__ a_d,
+                                                            float* __restrict__ ce) {
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    if (blockIdx.x == 0 && threadIdx.x < HEADS && ce) {
+        float s = 0.f;
+        for (int c = 0; c < H / HEADS; ++c)
+            s += lin_edge_w[threadIdx.x * (H / HEADS) + c] * att_edge[threadIdx.x * (H / HEADS) + c];
+        ce[threadIdx.x] = s;
+    }
     const float4 as4 = reinterpret_cast<const float4*>(att_src)[l], ad4 = reinterpret_cast<const float4*>(att_dst)[l];
     NodeRange r = block_nodes(n);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
@@ -721,6 +731,12 @@ struct ColSum {
     const float* partial;  // [nb][width], the job's first column at partial[0]
     float* out;
     int nb, width, cols;
+    // optional: column c's sum times fac_a[c*fan + t] -> out_a[c*fan + t], likewise b (t < fan <= 256)
+    const float* fac_a;
+    float* out_a;
+    const float* fac_b;
+    float* out_b;
+    int fan;
 };
 struct ColSums {
     ColSum j[4];
@@ -742,6 +758,12 @@ __global__ __launch_bounds__(256) void k_reduce_cols(ColSums jobs) {
         __syncthreads();
     }
     if (t == 0) out[c] = red[0];
+    const ColSum& job = jobs.j[which];
+    if (job.fac_a && t < job.fan) {
+        const float total = red[0];
+        job.out_a[c * job.fan + t] = total * job.fac_a[c * job.fan + t];
+        job.out_b[c * job.fan + t] = total * job.fac_b[c * job.fan + t];
+    }
 }
 
 // Grid of the node-parallel kernels: a multiple of 8 (XCD grouping), at least 8 nodes per half-wave
@@ -829,13 +851,15 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
 }
 
 extern "C" int aig_gat_node_alpha(int64_t n, const float* xw, const float* att_src, const float* att_dst,
-                                  float* a_s, float* a_d, void* stream) {
+                                  const float* lin_edge_w, const float* att_edge, float* a_s, float* a_d, float* ce,
+                                  void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat_node_alpha: n=%lld out of range", (long long)n);
     if (n == 0) return AIG_OK;
     AIG_REQUIRE(xw && att_src && att_dst && a_s && a_d, "aig_gat_node_alpha: null pointer");
+    AIG_REQUIRE(!ce || (lin_edge_w && att_edge), "aig_gat_node_alpha: ce needs lin_edge_w and att_edge");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_gat_node_alpha, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, att_src, att_dst, a_s,
-                       a_d);
+    hipLaunchKernelGGL(k_gat_node_alpha, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, att_src, att_dst,
+                       lin_edge_w, att_edge, a_s, a_d, ce);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -866,17 +890,23 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
                            const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
                            const int32_t* csc_dst, const int32_t* hub_tab,
                            const float* alpha_e,
-                           const float* alpha_loop, float* d_xw,
-                           float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, void* ws,
-                           size_t ws_bytes, void* stream) {
+                           const float* alpha_loop, const float* lin_edge_w, const float* att_edge, float* d_xw,
+                           float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, float* d_lin_edge_w,
+                           float* d_att_edge, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && E >= 0, "aig_gat_bwd: bad sizes");
     AIG_REQUIRE(d_att_src && d_att_dst && d_ce && d_bias, "aig_gat_bwd: null output");
+    AIG_REQUIRE((d_lin_edge_w == nullptr) == (d_att_edge == nullptr) && (!d_lin_edge_w || (lin_edge_w && att_edge)),
+                "aig_gat_bwd: d_lin_edge_w and d_att_edge come together and need lin_edge_w and att_edge");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
         AIG_HIP_CHECK(hipMemsetAsync(d_att_src, 0, H * 4, s));
         AIG_HIP_CHECK(hipMemsetAsync(d_att_dst, 0, H * 4, s));
         AIG_HIP_CHECK(hipMemsetAsync(d_ce, 0, HEADS * 4, s));
         AIG_HIP_CHECK(hipMemsetAsync(d_bias, 0, H * 4, s));
+        if (d_lin_edge_w) {
+            AIG_HIP_CHECK(hipMemsetAsync(d_lin_edge_w, 0, H * 4, s));
+            AIG_HIP_CHECK(hipMemsetAsync(d_att_edge, 0, H * 4, s));
+        }
         return AIG_OK;
     }
     AIG_REQUIRE(g_out && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
@@ -911,7 +941,9 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     // last HEADS columns; the attention vectors' gradients = the two halves of the source-side ones
     ColSums sums{};
     sums.j[0] = ColSum{partial_dst, d_bias, g, H + HEADS, H};
-    sums.j[1] = ColSum{partial_dst + H, d_ce, g, H + HEADS, HEADS};
+    // d ce[h] also gives d lin_edge.weight[h,:] = d ce[h] * att_edge[h,:] and d att_edge[h,:] = d ce[h] * lin_edge.weight[h,:]
+    sums.j[1] = ColSum{partial_dst + H, d_ce, g, H + HEADS, HEADS, d_lin_edge_w ? att_edge : nullptr, d_lin_edge_w,
+                       lin_edge_w, d_att_edge, H / HEADS};
     sums.j[2] = ColSum{partial, d_att_src, gs + HUB_FINISH_BLOCKS, 2 * H, H};
     sums.j[3] = ColSum{partial + H, d_att_dst, gs + HUB_FINISH_BLOCKS, 2 * H, H};
     hipLaunchKernelGGL(k_reduce_cols, dim3(3 * H + HEADS), dim3(256), 0, s, sums);

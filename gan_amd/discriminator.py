@@ -101,25 +101,28 @@ class _GATAggregate(torch.autograd.Function):
     """softmax-attention aggregation + bias + ELU over a GraphCSR (first-order differentiable)."""
 
     @staticmethod
-    def forward(ctx, xw, att_src, att_dst, ce, bias, csr: GraphCSR):
+    def forward(ctx, xw, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR):
         lib = _abi.lib()
         n, dev = csr.n, xw.device
         xw = xw.contiguous()
-        att_src, att_dst, ce, bias = (t.detach().contiguous() for t in (att_src, att_dst, ce, bias))
+        att_src, att_dst, lin_edge_w, att_edge, bias = (t.detach().contiguous().view(-1)
+                                                        for t in (att_src, att_dst, lin_edge_w, att_edge, bias))
         f32 = dict(dtype=torch.float32, device=dev)
+        ce = torch.empty(4, **f32)
         a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
         out = torch.empty((n, HIDDEN), **f32)
         alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
         alpha_loop = torch.empty((max(n, 1), 4), **f32)
         st = _abi.stream()
         _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
-                              _abi.ptr(att_dst), _abi.ptr(a_s), _abi.ptr(a_d), st), "aig_gat_node_alpha")
+                              _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
+                              _abi.ptr(ce), st), "aig_gat_node_alpha")
         _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
                               _abi.ptr(ce), _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
                               _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
                               _abi.ptr(alpha_loop), st, meta=(n, csr.E)), "aig_gat_fwd")
         ctx.csr = csr
-        ctx.save_for_backward(xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop)
+        ctx.save_for_backward(xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop, lin_edge_w, att_edge)
         return out
 
     @staticmethod
@@ -127,23 +130,25 @@ class _GATAggregate(torch.autograd.Function):
     def backward(ctx, g_out):
         lib = _abi.lib()
         csr: GraphCSR = ctx.csr
-        xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop = ctx.saved_tensors
+        xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop, lin_edge_w, att_edge = ctx.saved_tensors
         n, dev = csr.n, xw.device
         g_out = g_out.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         d_xw = torch.empty((n, HIDDEN), **f32)
         d_as, d_ad, d_bias = torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32)
         d_ce = torch.empty(4, **f32)
+        d_lw, d_ae = torch.empty((HIDDEN, 1), **f32), torch.empty((1, 4, HIDDEN // 4), **f32)
         ws = _abi.workspace(lib.aig_gat_bwd_ws_bytes(n, csr.E), dev)
         _abi.check(_abi.timed("aig_gat_bwd", lib.aig_gat_bwd, n, csr.E, _abi.ptr(g_out), _abi.ptr(out), _abi.ptr(xw), _abi.ptr(att_src),
                                    _abi.ptr(att_dst), _abi.ptr(ce), _abi.ptr(a_s), _abi.ptr(a_d),
                                    _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea),
                                    _abi.ptr(csr.loop_ea), _abi.ptr(csr.col_ptr), _abi.ptr(csr.csc_pos),
                                    _abi.ptr(csr.csc_dst), _abi.ptr(csr.hub_tab), _abi.ptr(alpha_e),
-                                   _abi.ptr(alpha_loop),
+                                   _abi.ptr(alpha_loop), _abi.ptr(lin_edge_w), _abi.ptr(att_edge),
                                    _abi.ptr(d_xw), _abi.ptr(d_as), _abi.ptr(d_ad), _abi.ptr(d_ce), _abi.ptr(d_bias),
+                                   _abi.ptr(d_lw), _abi.ptr(d_ae),
                                    _abi.ptr(ws), ws.numel(), _abi.stream(), meta=(n, csr.E)), "aig_gat_bwd")
-        return d_xw, d_as, d_ad, d_ce, d_bias, None
+        return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None
 
 
 class _WGrad(torch.autograd.Function):
@@ -319,9 +324,10 @@ class GATLayer(nn.Module):
         if csr is None or csr.E == 0:
             # only self loops: alpha = 1/(1 + 1e-16) = 1 in fp32
             return F.elu(xw + self.bias)
-        ce = (self.lin_edge.weight.view(self.heads, self.out_per_head) *
-              self.att_edge.view(self.heads, self.out_per_head)).sum(-1)
-        return _GATAggregate.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), ce, self.bias, csr)
+        # edge_dim = 1: an edge's attention term is attr * ce[h], ce[h] = <lin_edge.weight[h,:], att_edge[h,:]>,
+        # formed (and differentiated) inside the kernels
+        return _GATAggregate.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), self.lin_edge.weight,
+                                   self.att_edge, self.bias, csr)
 
 
 class _CriticHead(torch.autograd.Function):

@@ -140,9 +140,12 @@ int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, const float* ed
                 void* ws, size_t ws_bytes, void* stream);
 
 /* Attention logits' node terms after the dense projection xw = x W^T ([n,128], 4 heads x 32 channels):
- *   a_s[i,h] = <xw[i,h,:], att_src[h,:]>,  a_d[i,h] = <xw[i,h,:], att_dst[h,:]>        ([n,4] each) */
+ *   a_s[i,h] = <xw[i,h,:], att_src[h,:]>,  a_d[i,h] = <xw[i,h,:], att_dst[h,:]>        ([n,4] each)
+ * and, when ce is not NULL, the edge coefficients ce[h] = <lin_edge.weight[h,:], att_edge[h,:]> ([4]; lin_edge_w and
+ * att_edge are [128] = 4 heads x 32) that aig_gat_fwd / aig_gat_bwd take. */
 int aig_gat_node_alpha(int64_t n, const float* xw, const float* att_src, const float* att_dst,
-                       float* a_s, float* a_d, void* stream);
+                       const float* lin_edge_w, const float* att_edge, float* a_s, float* a_d, float* ce,
+                       void* stream);
 
 /* Fused attention / softmax / aggregation / bias / ELU of one layer (one kernel):
  *   e = leaky_relu(a_s[src] + a_d[dst] + edge_attr * ce[h], 0.2)   ce[h] = <lin_edge.weight[h,:], att_edge[h,:]>
@@ -154,16 +157,18 @@ int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const float* a_d, 
                 const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* stream);
 
 /* Backward of the same layer: given g_out = dLoss/d out, returns d_xw [n,128], d_att_src [128],
- * d_att_dst [128], d_ce [4], d_bias [128].  (Gradients w.r.t. edge_attr are not produced: the only
- * caller that differentiates edge attributes in the reference is dead code, train.py:154-185.) */
+ * d_att_dst [128], d_ce [4], d_bias [128] and, when asked for (both or neither; they need lin_edge_w and att_edge),
+ * d_lin_edge_w [128] and d_att_edge [128], the gradients of the two parameters ce is made of.  (Gradients w.r.t.
+ * edge_attr are not produced: the only caller that differentiates edge attributes in the reference is dead code,
+ * train.py:154-185.) */
 size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E);
 int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
                 const float* att_src, const float* att_dst, const float* ce, const float* a_s, const float* a_d,
                 const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea, const float* loop_ea,
                 const int32_t* col_ptr, const int32_t* csc_pos, const int32_t* csc_dst, const int32_t* hub_tab,
-                const float* alpha_e, const float* alpha_loop,
+                const float* alpha_e, const float* alpha_loop, const float* lin_edge_w, const float* att_edge,
                 float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
-                void* ws, size_t ws_bytes, void* stream);
+                float* d_lin_edge_w, float* d_att_edge, void* ws, size_t ws_bytes, void* stream);
 
 /* Dense projection of the critic's second attention layer, y = act(x W^T + bias) with x [n,128],
  * y [n,128] on the f32 matrix cores - torch.nn.functional.linear inside GATConv.lin (discriminator.py:61) and
