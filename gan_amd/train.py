@@ -139,6 +139,13 @@ def sanitize_for_D(padded: Data) -> Data:
     return d
 
 
+def mean_score(D, data: Data) -> torch.Tensor:
+    """``torch.mean(D(data))`` (train.py:247-248,289): the critic returns one score per call, whose mean is
+    that score - taken as a view, not as a reduction launch with its own backward launch."""
+    s = D(data)
+    return s.reshape(()) if s.numel() == 1 else torch.mean(s)
+
+
 def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool = True,
                      alpha: Optional[torch.Tensor] = None):
     """Node-feature gradient penalty on an edge-free interpolate (train.py:141-152).
@@ -181,13 +188,15 @@ class CapturedCriticTerms:
         self._inputs = (real_pad, fake_pad, real_for_D)
 
         def compute_real():
-            d_real = torch.mean(D(real_for_D))
+            d_real = mean_score(D, real_for_D)
             return d_real.detach(), torch.autograd.grad(-d_real, params, allow_unused=True)
 
         def compute_gp():
             if closed_form_gp:
                 gp, gn, gp_grads = D.gradient_penalty_closed_form(real_pad.x, fake_pad.x, self.alpha, real_pad.node_depth)
-                return gp, gn, [gp_lambda * gp_grads[p] if p in gp_grads else None for p in params]
+                scaled = dict(zip([p for p in params if p in gp_grads],
+                                  torch._foreach_mul([gp_grads[p] for p in params if p in gp_grads], gp_lambda)))
+                return gp, gn, [scaled.get(p) for p in params]
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha)
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
@@ -364,15 +373,16 @@ class Trainer:
                         if not (it == 0 and real_replayed):
                             terms.replay_real()
                         terms.replay_gp(fake_padded.x, self.draw_alpha())
-                        D_fake_mean = torch.mean(D(fake_for_D))
+                        D_fake_mean = mean_score(D, fake_for_D)
                         D_fake_mean.backward()
                         terms.add_gradients()
-                        D_real_mean, gp_term, grad_norm = terms.d_real.clone(), terms.gp.clone(), terms.grad_norm.clone()
-                        gap = D_real_mean - D_fake_mean.detach()
-                        loss_D = (D_fake_mean.detach() - D_real_mean) + a.gp_lambda * gp_term
+                        if it == a.n_critic - 1:   # the logged scalars are those of the last iteration (train.py:263-272)
+                            D_real_mean, gp_term, grad_norm = terms.d_real.clone(), terms.gp.clone(), terms.grad_norm.clone()
+                            gap = D_real_mean - D_fake_mean.detach()
+                            loss_D = (D_fake_mean.detach() - D_real_mean) + a.gp_lambda * gp_term
                     else:
-                        D_real_mean = torch.mean(D(real_for_D))
-                        D_fake_mean = torch.mean(D(fake_for_D))
+                        D_real_mean = mean_score(D, real_for_D)
+                        D_fake_mean = mean_score(D, fake_for_D)
                         gap = D_real_mean - D_fake_mean
                         if self.closed_form_gp:
                             gp_term, grad_norm, gp_grads = D.gradient_penalty_closed_form(
@@ -386,8 +396,9 @@ class Trainer:
                                                                   alpha=self.draw_alpha())
                             loss_D = (D_fake_mean - D_real_mean) + a.gp_lambda * gp_term
                             loss_D.backward()
-                    self.last = dict(D_real=D_real_mean.detach(), D_fake=D_fake_mean.detach(), gap=gap.detach(),
-                                     gp=gp_term.detach(), grad_norm=grad_norm.detach(), loss_D=loss_D.detach())
+                    if it == a.n_critic - 1:
+                        self.last = dict(D_real=D_real_mean.detach(), D_fake=D_fake_mean.detach(), gap=gap.detach(),
+                                         gp=gp_term.detach(), grad_norm=grad_norm.detach(), loss_D=loss_D.detach())
                 except Exception as e:
                     if self.world == 1:
                         raise
@@ -419,7 +430,7 @@ class Trainer:
                     self._raw_depth.popitem(last=False)
             else:
                 raw_batch_for_D.node_depth = kept
-        loss_G_adv = -torch.mean(D(raw_batch_for_D))
+        loss_G_adv = -mean_score(D, raw_batch_for_D)
         main_stream.wait_stream(self.side_stream)
         loss_pen.record_stream(main_stream)
         if (self.global_step % a.save_every) == 0:
