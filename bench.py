@@ -103,6 +103,43 @@ def cpu_baseline(seconds_budget: float = 25.0):
                       f"{threads} torch threads, generator/constraint checker single-threaded C"}
 
 
+def side_workload(name: str, dev, steps: int, warmup: int):
+    """A short measurement of another BASELINE.json configuration on the same GPU (rank 0, N=1 only):
+    training step time, edges/s and bulk sampling rate, reported next to the main line."""
+    from gan_amd.data import Batch
+    from gan_amd.dataset import pad_data
+    from gan_amd.sample import sample_many
+    from gan_amd.train import Trainer, build_parser
+    graphs, desc = workload_graphs(name, 0)
+    mn = max(g.x.size(0) for g in graphs)
+    me = max(g.edge_index.size(1) for g in graphs)
+    targs = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000"])
+    tr = Trainer(targs, mn, me, dev)
+    tr.global_step = 1
+    batch = Batch.from_data_list([pad_data(g, mn, me) for g in graphs]).to(dev)
+    batch.sample_ids = list(range(len(graphs)))
+    for _ in range(warmup):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    templates = tr.templates_of(batch)
+    draw = lambda: torch.randn(128, device=dev)   # noqa: E731
+    list(sample_many(tr.G, ((t, draw) for t in templates)))
+    torch.cuda.synchronize()
+    s0 = time.perf_counter()
+    for _ in sample_many(tr.G, ((t, draw) for _ in range(steps) for t in templates)):
+        pass
+    torch.cuda.synchronize()
+    nodes = sum(int(t.x.size(0)) for t in templates) * steps
+    return {"workload": f"{name}: {desc}", "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+            "edges_per_sec": round(tr.edges_last_step / dt, 1),
+            "sample_nodes_per_sec": round(nodes / (time.perf_counter() - s0), 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +149,8 @@ def main():
     ap.add_argument("--sample-iters", type=int, default=10)
     ap.add_argument("--sample-in-flight", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="skip the short ISCAS85-sized measurement reported next to the main line at N=1")
     a = ap.parse_args()
 
     from gan_amd import _abi, parallel
@@ -258,6 +297,14 @@ def main():
             "timeline_note": f"GPU ms per step by entry point, from {inst_steps} extra instrumented steps outside the timed region "
                              "(event brackets on the launching stream; entry points that run next to another stream's work include that contention)",
         }
+        if world == 1 and not a.no_side_workloads and a.workload != "iscas85":
+            # BASELINE.json configs[1] (ISCAS85-sized graphs, one minibatch of all of them): bound by launches
+            # and Python, not by the GPU - reported for completeness, the roofline figures above are not its
+            del trainer, batch, templates
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_workloads"] = [side_workload("iscas85", dev, steps=10, warmup=5)]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -96,6 +96,22 @@ class AIGGenerator(nn.Module):
 
     # ------------------------------------------------------------------ plumbing
     def _weights(self) -> _abi.GenWeights:
+        """Pointer table of the 16 parameter tensors, rebuilt only when one of them moved (``.to()``,
+        ``load_state_dict`` on a new device): it is needed once per forward pass."""
+        params = (self.node_enc[0].weight, self.node_enc[0].bias, self.node_enc[2].weight, self.node_enc[2].bias,
+                  self.node_proj[0].weight, self.node_proj[0].bias, self.node_proj[2].weight, self.node_proj[2].bias,
+                  self.edge_scorer[0].weight, self.edge_scorer[0].bias, self.edge_scorer[2].weight,
+                  self.edge_scorer[2].bias, self.edge_attr_pred[0].weight, self.edge_attr_pred[0].bias,
+                  self.edge_attr_pred[2].weight, self.edge_attr_pred[2].bias)
+        key = tuple(t.data_ptr() for t in params)
+        cached = self.__dict__.get("_weights_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        w = self._weights_uncached()
+        self.__dict__["_weights_cache"] = (key, w)
+        return w
+
+    def _weights_uncached(self) -> _abi.GenWeights:
         def p(t):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise _abi.AigAbiError("generator parameters must be contiguous float32 tensors on a HIP device")
