@@ -331,3 +331,25 @@ def test_fused_head_matches_torch_modules():
     (gx,) = torch.autograd.grad(out.sum(), [x], create_graph=True)
     gx.pow(2).sum().backward()
     assert D.mlp[0].weight.grad is not None
+
+
+def test_hub_with_more_chunks_than_gathering_blocks():
+    """One source feeding 280k targets: 1094 chunks of 256 edges, more than the blocks that gather them,
+    so every block takes a second chunk; score and all parameter gradients against the CPU restatement."""
+    n = 280000
+    rng = np.random.default_rng(8)
+    src = np.concatenate([np.zeros(n - 1, np.int64), rng.integers(0, n, 3000)])
+    dst = np.concatenate([np.arange(1, n), rng.integers(0, n, 3000)])
+    x = torch.from_numpy(np.stack([rng.choice([0, 1, 2], n), rng.integers(0, 3, n)], 1).astype(np.float32))
+    ei = torch.from_numpy(np.stack([src, dst]))
+    ea = torch.from_numpy(rng.integers(0, 2, src.size).astype(np.float32)).view(-1, 1)
+    nd = torch.from_numpy(rng.integers(0, 12, n))
+    D, p = make_critic(seed=3)
+    out = D(Data(x=x.to(DEV), edge_index=ei.to(DEV), edge_attr=ea.to(DEV), node_depth=nd.to(DEV)))
+    ref = omodel.discriminator_forward(p, x, ei, ea, nd)
+    close(out.detach().cpu().numpy(), ref.detach().numpy(), what="score")
+    out.sum().backward()
+    ref.sum().backward()
+    for k, v in D.named_parameters():
+        # sums over 283k edges with heavy cancellation, in fp32 on both sides: a looser bound than elsewhere
+        close(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=5e-3, what="grad " + k)
