@@ -5,7 +5,9 @@ the ranks of one node and the only exchange is the critic's gradient: 59,137 fp3
 (236.5 KB), once per critic iteration.  Such a message is latency-bound on xGMI, so it goes
 out as ONE flat buffer (never per tensor), with a validity flag appended so that a rank whose
 step raised still takes part in the collective - the reference's catch-and-continue contract
-(train.py:349-352) would otherwise leave the other ranks waiting forever.  The generator has
+(train.py:349-352) would otherwise leave the other ranks waiting forever.  The flag is used on the
+device (the gradient becomes the mean over the ranks that had one), never read by the host: a host
+read per critic iteration would stop the host from enqueueing ahead of the GPU.  The generator has
 no gradient (see gan_amd/generator.py), hence no second collective.
 """
 from __future__ import annotations
@@ -54,8 +56,10 @@ def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0) -> No
 class FlatGradAllReduce:
     """Mean of the parameter gradients over ranks through one flat all-reduce.
 
-    ``reduce(ok)`` returns True when every rank reported a valid gradient; otherwise the
-    gradients are left zeroed and the caller skips its optimiser step - on every rank alike."""
+    ``reduce(ok)``: a rank whose step failed passes ``ok=False`` and contributes nothing; every rank
+    (that one included) ends up with the mean over the ranks that did report a gradient - zeros when
+    none did - so all ranks take the same optimiser step and their weights stay equal.  No host
+    synchronisation.  Returns True when the caller should step (always, with more than one rank)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -77,17 +81,12 @@ class FlatGradAllReduce:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         self.flat[self.numel] = 1.0 if ok else 0.0
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        all_ok = bool(self.flat[self.numel].item() >= self.world - 0.5)
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-        grads = [p.grad for p in self.params]
-        if all_ok:
-            self.flat[:self.numel].div_(self.world)
-            torch._foreach_copy_(grads, views)
-        else:
-            torch._foreach_zero_(grads)
-        return all_ok
+        self.flat[:self.numel].div_(self.flat[self.numel].clamp(min=1.0))   # valid ranks, counted on the device
+        torch._foreach_copy_([p.grad for p in self.params], views)
+        return True
 
     def _views(self) -> List[torch.Tensor]:
         if getattr(self, "_view_cache", None) is None:

@@ -52,10 +52,16 @@ def _worker(rank, world, port, tmp):
         assert torch.allclose(p.grad, mean, atol=1e-6), "all-reduced gradient is not the rank mean"
     assert any(not torch.equal(a, p.grad) for a, p in zip(local, net.parameters()))
 
-    # one rank reports a failed step: nobody may step, everybody returns (no hang)
+    # one rank reports a failed step: everybody returns (no hang) with the mean over the other ranks
     net.zero_grad()
     net(x).sum().backward()
-    assert red.reduce(ok=(rank != 1)) is False
+    assert red.reduce(ok=(rank != 1)) is True
+    for i, p in enumerate(net.parameters()):
+        assert torch.allclose(p.grad, want[0][i], atol=1e-6), "gradient is not the mean over the valid ranks"
+    # nobody has a gradient: zeros everywhere
+    net.zero_grad()
+    net(x).sum().backward()
+    assert red.reduce(ok=False) is True
     assert all(float(p.grad.abs().max()) == 0.0 for p in net.parameters())
 
     # minibatch sharding: same shuffle everywhere, disjoint batches, equal step counts
