@@ -48,6 +48,15 @@ def workload_graphs(name: str, rank: int):
     raise SystemExit(f"unknown workload {name}")
 
 
+def measured_peaks():
+    """Achievable peaks of an MI355X measured with tools/peaks.hip (committed as profiles/r01_peaks.json)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_peaks.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def pmc_traffic(workload: str):
     """HBM bytes per launch of k_gat_aggregate on this workload from the committed PMC passes
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see profiles/pmc_traffic.json); None when not collected."""
@@ -269,6 +278,13 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload),
                     "launches": launches, "avg_launch_us": round(ms_fwd * 1e3 / launches, 2),
                     "algorithmic_bytes_per_launch_avg": int(total_bytes / launches)}
+            peaks = measured_peaks()
+            if roof["traffic"] and peaks.get("hbm_read_GBs"):
+                # HBM-side view: bytes that actually crossed the memory interface (PMC) per second of kernel time,
+                # against the read bandwidth a plain streaming kernel reaches on this GPU (tools/peaks.hip)
+                hbm_side = roof["traffic"] / (ms_fwd * 1e-3 / launches) / 1e9
+                roof.update({"traffic_GBs": round(hbm_side, 1), "peak_measured": peaks["hbm_read_GBs"],
+                             "traffic_frac_of_measured": round(hbm_side / peaks["hbm_read_GBs"], 4)})
         # the dense contraction of the path: node projections of the generator (7 products of
         # [n,128]x[128,128] per sample) on the f32 matrix cores, flops executed / event time
         mfma = None
@@ -279,6 +295,9 @@ def main():
             mfma = {"kernel": "k_linear128 (entry point aig_gen_node_proj)", "bound": "mfma", "achieved": round(tf, 1),
                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                     "launches": n_proj, "avg_launch_us": round(ms_proj * 1e3 / n_proj, 2)}
+            if measured_peaks().get("mfma_f32_TFs"):
+                mfma.update({"peak_measured": measured_peaks()["mfma_f32_TFs"],
+                             "frac_of_measured": round(tf / measured_peaks()["mfma_f32_TFs"], 4)})
         out = {
             "metric": "train edges/sec (AIG nodes/sec sampled at k=64 in sample_nodes_per_sec)",
             "value": round(edges_total / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps,
