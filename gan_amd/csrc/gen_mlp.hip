@@ -24,9 +24,6 @@ struct Chunk {          // one 128-column slice of the output
     int ldw;
     int wt;             // 1: w is stored [in][out] (ldw = row length of that layout)
 };
-struct ChunkSet {
-    Chunk c[4];
-};
 
 // z-dependent bias vectors: out[v*128 + j] = b_v[j] + sum_k W_v[j][off_v + k] * z[k]
 __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w0, const float* __restrict__ b0,
@@ -34,6 +31,10 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
                         int off1, const float* __restrict__ w2, const float* __restrict__ b2, int ld2, int off2,
                         float* __restrict__ out) {
     int v = blockIdx.x, j = threadIdx.x;
+    if (v == 3) {  // a zero vector for layers without bias
+        out[v * H + j] = 0.f;
+        return;
+    }
     const float* w = v == 0 ? w0 : (v == 1 ? w1 : w2);
     const float* b = v == 0 ? b0 : (v == 1 ? b1 : b2);
     int ld = v == 0 ? ld0 : (v == 1 ? ld1 : ld2), off = v == 0 ? off0 : (v == 1 ? off1 : off2);
@@ -43,8 +44,8 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
     out[v * H + j] = acc + b[j];
 }
 
-// Y[:, chunk] = act(X W_chunk^T + bias_chunk) for a persistent grid of row tiles (ACT 0 none, 1 ReLU, 2 ELU).
-// FROM_X2: the input tile is relu(enc0(x)) computed on the fly from the [M,2] features.
+// Y = act(X W^T + bias) for a persistent grid of row tiles (ACT 0 none, 1 ReLU, 2 ELU): the single
+// 128x128 layer the critic calls (aig_linear128).
 //
 // LDS: the weight slice (padded rows) stays for the life of the block; input tiles of BM rows are
 // double-buffered.  A plain input tile goes global -> LDS by direct 16-byte loads (no register
@@ -57,14 +58,11 @@ __device__ __forceinline__ void load_to_lds16(const float* src, float* lds_dst) 
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int ACT, bool FROM_X2>
-__global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __restrict__ X,
-                                                       const float* __restrict__ enc_w,
-                                                       const float* __restrict__ enc_b, ChunkSet cs) {
+template <int ACT>
+__global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __restrict__ X, Chunk ck) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Wl = lds;                       // [128][LDS_LD]
     float* Xl = lds + H * LDS_LD;          // [2][BM][H], chunks permuted within a row
-    const Chunk ck = cs.c[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = (M + BM - 1) / BM;
 
@@ -104,44 +102,8 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
             load_to_lds16(X + static_cast<size_t>(gr) * H + 4 * c4, Xl + (buf * BM + pr) * H);
         }
     };
-    // FROM_X2: raw features of 8 rows per thread, encoded when they are written to LDS
-    float2 xs[BM / 8];
-    auto fetch_x2 = [&](int tile) {
-#pragma unroll
-        for (int q = 0; q < BM / 8; ++q) {
-            const int gr = min(tile * BM + q * 8 + (tid >> 5), M - 1);
-            xs[q] = *reinterpret_cast<const float2*>(X + static_cast<size_t>(gr) * 2);
-        }
-    };
-    auto stash_x2 = [&](int buf) {
-        const int c4 = tid & 31;
-        float w0[4], w1[4], bb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w0[u] = enc_w[2 * (c4 * 4 + u)];
-            w1[u] = enc_w[2 * (c4 * 4 + u) + 1];
-            bb[u] = enc_b[c4 * 4 + u];
-        }
-#pragma unroll
-        for (int q = 0; q < BM / 8; ++q) {
-            const int row = q * 8 + (tid >> 5);
-            float o[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaf(xs[q].y, w1[u], xs[q].x * w0[u]) + bb[u], 0.f);
-            *reinterpret_cast<float4*>(Xl + (buf * BM + row) * H + 4 * (c4 ^ (row & 15))) =
-                make_float4(o[0], o[1], o[2], o[3]);
-        }
-    };
-
     int tile = blockIdx.x;
-    if (tile < ntiles) {
-        if constexpr (FROM_X2) {
-            fetch_x2(tile);
-            stash_x2(0);
-        } else {
-            fetch(tile, 0);
-        }
-    }
+    if (tile < ntiles) fetch(tile, 0);
 
     const int frow = lane & 31, fh = lane >> 5;
     const float* Wfrag = Wl + (wave * 32 + frow) * LDS_LD + 4 * fh;
@@ -151,18 +113,13 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
         const int next = tile + gridDim.x;
-        if constexpr (FROM_X2) {
-            __syncthreads();
-            if (next < ntiles) fetch_x2(next);
-        } else {
-            // the tile's direct loads are older than the 32 output stores of the previous trip:
-            // wait until only those stores may be outstanding, then meet the other waves
-            // (first trip: nothing but the tile and the weight slice is in flight - wait for all)
-            if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (next < ntiles) fetch(next, buf ^ 1);
-        }
+        // the tile's direct loads are older than the 32 output stores of the previous trip:
+        // wait until only those stores may be outstanding, then meet the other waves
+        // (first trip: nothing but the tile and the weight slice is in flight - wait for all)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (next < ntiles) fetch(next, buf ^ 1);
 
         f32x16 acc0 = {0}, acc1 = {0};
         const float* Xf0 = Xl + (buf * BM + frow) * H;
@@ -214,27 +171,354 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
             ck.out[static_cast<size_t>(g0) * H + col] = y0;
             ck.out[static_cast<size_t>(g1) * H + col] = y1;
         }
-        if constexpr (FROM_X2) {
-            if (next < ntiles) stash_x2(buf ^ 1);
-        }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node pipeline of the generator with the weights in registers.
+//
+// Every wave only ever needs its own 32 output columns of a 128x128 layer: lane (col, fh) keeps
+// W[col][8g + 4fh .. + 3], g = 0..15, in 64 registers per layer for the life of the block (one wave per
+// SIMD: 512 registers per lane), which leaves LDS to tiles: a tile of BM rows is read as matrix-core
+// fragments from one LDS buffer and the layer's output is written to another (same chunk permutation
+// as k_linear128's input tiles), either as the next layer's input or as a staging copy of an output
+// that the NEXT layer's product loop streams to memory, whole 512-byte rows at a time, one 16-byte
+// piece per thread every other group of products - so stores never come in a burst at the end of a
+// tile, when all 256 workgroups (which run in step) would otherwise issue theirs together.
+// The weights are the FIRST matrix-core operand and the tile the second, so a lane ends up with four
+// consecutive output columns (8j + 4fh .. + 3 of the wave's 32, j = 0..3) of tile rows frow and
+// frow + 32: 16-byte LDS writes.  The products of an output element and their order are those of
+// k_linear128, so both give the same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_F = BM * H;  // floats per LDS tile
+
+// rows of a staged tile -> global rows grow0 .. (rows past M: onto row M-1, whose values they repeat)
+struct Drain {
+    const float* stage;  // LDS tile (permuted chunks)
+    float* gout;         // [M][128]
+    int grow0, M;
+};
+
+__device__ __forceinline__ float4 drain_read(const Drain& d, int q, int tid) {
+    return *reinterpret_cast<const float4*>(d.stage + (q * 8 + (tid >> 5)) * H + 4 * (tid & 31));
+}
+__device__ __forceinline__ void drain_write(const Drain& d, int q, int tid, float4 v) {
+    const int row = q * 8 + (tid >> 5);
+    const int grow = min(d.grow0 + row, d.M - 1);
+    *reinterpret_cast<float4*>(d.gout + static_cast<size_t>(grow) * H + 4 * ((tid & 31) ^ (row & 15))) = v;
+}
+
+// One layer of a tile: out = act(tile W^T + bias) into the LDS tile tout.  NDRAIN of the 8 pieces per
+// thread of a staged tile, from piece Q0 on, go to memory on the way.  HALF: only tile rows 0..31.
+template <bool RELU, int NDRAIN, int Q0, bool HALF>
+__device__ __forceinline__ void tile_layer(const float* tin, const float4 (&wr)[H / 8], const float* bias, float* tout,
+                                           const Drain& dr, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, frow = lane & 31, fh = lane >> 5;
+    const int swz = frow & 15;
+    const float* Xf0 = tin + frow * H;
+    const float* Xf1 = Xf0 + 32 * H;
+    float4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + wave * 32 + 8 * j + 4 * fh);
+    f32x16 acc0 = {0}, acc1 = {0};
+    float4 a0 = *reinterpret_cast<const float4*>(Xf0 + 4 * (fh ^ swz));
+    float4 a1 = make_float4(0, 0, 0, 0);
+    if (!HALF) a1 = *reinterpret_cast<const float4*>(Xf1 + 4 * (fh ^ swz));
+    constexpr int NRD = HALF ? 1 : 2;  // fragment reads per group of products
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // the first group's reads: a slot of their own
+    constexpr int STEP = NDRAIN ? (H / 8) / NDRAIN : 1;  // a piece is read in group STEP*i, stored in the next
+    float4 piece = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < H / 8; ++g) {
+        float4 n0 = a0, n1 = a1;
+        if (g + 1 < H / 8) {
+            const int pc = 4 * ((2 * (g + 1) + fh) ^ swz);
+            n0 = *reinterpret_cast<const float4*>(Xf0 + pc);
+            if (!HALF) n1 = *reinterpret_cast<const float4*>(Xf1 + pc);
+        }
+        const bool rd = NDRAIN && g % STEP == 0, wrt = NDRAIN && g % STEP == 1;
+        if (wrt) drain_write(dr, Q0 + g / STEP, tid, piece);
+        if (rd) piece = drain_read(dr, Q0 + g / STEP, tid);
+        const float4 b = wr[g];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a0.x, acc0, 0, 0, 0);
+        if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a0.y, acc0, 0, 0, 0);
+        if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a0.z, acc0, 0, 0, 0);
+        if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a0.w, acc0, 0, 0, 0);
+        if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a1.w, acc1, 0, 0, 0);
+        a0 = n0; a1 = n1;
+        // issue order: the LDS reads for the next group (and a piece to drain), a drained piece's store,
+        // then this group's products
+        if (g + 1 < H / 8) {
+            if (rd) __builtin_amdgcn_sched_group_barrier(0x100, NRD + 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        } else if (rd) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (wrt) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, HALF ? 4 : 8, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // registers 4j..4j+3 of a 32x32 block: columns 8j + 4fh .. + 3, tile row frow
+        float4 y0 = make_float4(acc0[4 * j] + bv[j].x, acc0[4 * j + 1] + bv[j].y, acc0[4 * j + 2] + bv[j].z,
+                                acc0[4 * j + 3] + bv[j].w);
+        float4 y1 = make_float4(acc1[4 * j] + bv[j].x, acc1[4 * j + 1] + bv[j].y, acc1[4 * j + 2] + bv[j].z,
+                                acc1[4 * j + 3] + bv[j].w);
+        if (RELU) {
+            y0 = make_float4(fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f), fmaxf(y0.z, 0.f), fmaxf(y0.w, 0.f));
+            y1 = make_float4(fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f), fmaxf(y1.z, 0.f), fmaxf(y1.w, 0.f));
+        }
+        // rows frow and frow + 32 share frow & 15: one chunk position for both
+        const int pos = 4 * ((wave * 8 + 2 * j + fh) ^ swz);
+        *reinterpret_cast<float4*>(tout + frow * H + pos) = y0;
+        if (!HALF) *reinterpret_cast<float4*>(tout + (frow + 32) * H + pos) = y1;
+    }
+}
+
+// the two variants of a layer; `half` is uniform over the block
+#define TILE_LAYER(RELU, ND_FULL, ND_HALF, Q0, ...)                             \
+    do {                                                                        \
+        if (half) tile_layer<RELU, ND_HALF, Q0, true>(__VA_ARGS__);             \
+        else tile_layer<RELU, ND_FULL, Q0, false>(__VA_ARGS__);                 \
+    } while (0)
+
+// the first NQ of the 8 pieces per thread of a staged tile (4: tile rows 0..31), outside a product loop:
+// the last tile of a block
+template <int NQ>
+__device__ __forceinline__ void drain_all(const Drain& d, int tid) {
+    float4 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = drain_read(d, q, tid);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) drain_write(d, q, tid, v[q]);
+}
+
+// Rows are dealt to workgroups in contiguous runs of a multiple of 32 rows (the same for all, so that all
+// finish together); a run is worked through in tiles of BM = 64 rows, the last of which may be a half tile.
+__host__ __device__ inline int rows_per_block(int M, int blocks) {
+    const int units = (M + 31) / 32;
+    return 32 * ((units + blocks - 1) / blocks);
+}
+
+__device__ __forceinline__ void load_rows(float4 (&wr)[H / 8], const float* w, int ldw, int col, int fh) {
+#pragma unroll
+    for (int g = 0; g < H / 8; ++g)
+        wr[g] = *reinterpret_cast<const float4*>(w + static_cast<size_t>(col) * ldw + 8 * g + 4 * fh);
+}
+
+// node_enc + node_proj: h_cond = relu(W3 relu(W2' relu(W1 relu(enc0(x)) + b1) + zb) + b3), a tile at a time
+// without leaving the CU; only x (8 B per row) is read from memory and only h_cond (512 B per row) written.
+struct Mlp3 {
+    const float* x;        // [M][2]
+    const float* enc0_w;   // [128][2]
+    const float* enc0_b;   // [128]
+    const float* w[3];     // [128][ldw]
+    const float* b[3];     // [128]
+    int ldw[3];
+    float* out;            // [M][128]
+#ifdef MLP3_TIMING
+    long long* dbg;
+#endif
+};
+
+constexpr size_t MLP3_LDS = (3 * TILE_F + 2 * BM) * sizeof(float);
+
+__global__ __launch_bounds__(THREADS) void k_node_mlp3(int M, int rpb, Mlp3 p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // tiles t0, t1, staging tile, x of the next tile
+    float* const stage = lds + 2 * TILE_F;
+    float2* const xs = reinterpret_cast<float2*>(lds + 3 * TILE_F);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int col = wave * 32 + frow;
+    const int row_begin = blockIdx.x * rpb;
+    if (row_begin >= M) return;
+    const int row_end = min(M, row_begin + rpb);
+    const int nt = (row_end - row_begin + BM - 1) / BM;
+
+    float4 wr0[H / 8], wr1[H / 8], wr2[H / 8];
+    load_rows(wr0, p.w[0], p.ldw[0], col, fh);
+    load_rows(wr1, p.w[1], p.ldw[1], col, fh);
+    load_rows(wr2, p.w[2], p.ldw[2], col, fh);
+
+    // enc0 = Linear(2,128) + ReLU: thread (c4 = tid & 31) makes columns 4c4..4c4+3 of rows q*8 + tid/32
+    const int c4 = tid & 31;
+    float e0[4], e1[4], eb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        e0[u] = p.enc0_w[2 * (c4 * 4 + u)];
+        e1[u] = p.enc0_w[2 * (c4 * 4 + u) + 1];
+        eb[u] = p.enc0_b[c4 * 4 + u];
+    }
+    // x of a tile: every thread fetches row tid & 63 (four threads a row, the same value); rows past M
+    // repeat row M-1, and so do all values computed from them
+    auto fetch_x = [&](int row0) {
+        return *reinterpret_cast<const float2*>(p.x + static_cast<size_t>(min(row0 + (tid & 63), M - 1)) * 2);
+    };
+    auto encode = [&](float* t) {
+#pragma unroll
+        for (int q = 0; q < BM / 8; ++q) {
+            const int row = q * 8 + (tid >> 5);
+            const float2 xv = xs[row];
+            float o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaf(xv.y, e1[u], xv.x * e0[u]) + eb[u], 0.f);
+            *reinterpret_cast<float4*>(t + row * H + 4 * (c4 ^ (row & 15))) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+
+    xs[tid & 63] = fetch_x(row_begin);
+    __syncthreads();
+    encode(lds);
+    Drain dr{stage, p.out, 0, M};
+    bool half = false;
+    for (int it = 0; it < nt; ++it) {
+        float* ta = lds + (it & 1) * TILE_F;
+        float* tb = lds + ((it & 1) ^ 1) * TILE_F;
+        const int row0 = row_begin + it * BM;
+        half = row_end - row0 <= 32;
+        __syncthreads();  // the encoded tile is in ta, the last tile's output in the staging tile
+#ifdef MLP3_TIMING
+        long long tm[8]; long long rt0 = wall_clock64();
+#define TM(i) tm[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define TM(i)
+#endif
+        TM(0);
+        const float2 xn = fetch_x(row0 + BM);
+        if (it) TILE_LAYER(true, 4, 4, 0, ta, wr0, p.b[0], tb, dr, tid);
+        else TILE_LAYER(true, 0, 0, 0, ta, wr0, p.b[0], tb, dr, tid);
+        xs[tid & 63] = xn;
+        TM(1);
+        __syncthreads();
+        TM(2);
+        if (it) TILE_LAYER(true, 4, 4, 4, tb, wr1, p.b[1], ta, dr, tid);
+        else TILE_LAYER(true, 0, 0, 0, tb, wr1, p.b[1], ta, dr, tid);
+        TM(3);
+        __syncthreads();  // every thread has drained its pieces of the staging tile
+        TM(4);
+        TILE_LAYER(true, 0, 0, 0, ta, wr2, p.b[2], stage, dr, tid);
+        dr.grow0 = row0;
+        TM(5);
+        if (it + 1 < nt) encode(tb);  // tb was last read by the second layer: free since the barrier above
+#ifdef MLP3_TIMING
+        TM(6);
+        if (p.dbg && blockIdx.x == 0 && tid == 0) {
+            for (int i = 0; i < 7; ++i) p.dbg[it * 8 + i] = tm[i];
+            p.dbg[it * 8 + 7] = wall_clock64() - rt0;
+        }
+#endif
+    }
+    __syncthreads();
+    if (half) drain_all<4>(dr, tid);
+    else drain_all<8>(dr, tid);
+}
+
+// Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not
+// see (after the builtin it waits for ALL memory traffic before the next LDS read, which would put the
+// whole load latency in front of the products it is meant to hide behind).  The kernel waits itself:
+// counted wait + barrier at the top of a trip.  lds_byte_addr: wave-uniform LDS address of the 1 KB
+// the 64 lanes fill.
+__device__ __forceinline__ void load_to_lds16_uncounted(const float* src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :
+                 : "s"(lds_byte_addr), "v"(src)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_address(const float* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const float*)p;
+}
+
+// The first Linear of both edge MLPs on h_cond, split into source block / target block: four independent
+// 128-column outputs of the same input tile.  The tile is loaded once (direct to LDS, double-buffered,
+// a tile ahead), each output is staged in LDS and drained by the next output's product loop.
+struct Proj4 {
+    const float* x;      // [M][128]
+    const float* w[4];   // [128][ldw]
+    const float* b[4];   // [128] (never null: a zero vector where the layer has no bias)
+    int ldw[4];
+    float* out[4];       // [M][128] each
+};
+
+constexpr size_t PROJ4_LDS = 4 * TILE_F * sizeof(float);
+
+__global__ __launch_bounds__(THREADS) void k_node_proj4(int M, int rpb, Proj4 p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // input tiles x0, x1, staging tiles s0, s1
+    float* const s0 = lds + 2 * TILE_F;
+    float* const s1 = lds + 3 * TILE_F;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int col = wave * 32 + frow;
+    const int row_begin = blockIdx.x * rpb;
+    if (row_begin >= M) return;
+    const int row_end = min(M, row_begin + rpb);
+    const int nt = (row_end - row_begin + BM - 1) / BM;
+
+    // wave w, instruction q fills tile rows 2(4q+w) and 2(4q+w)+1 (chunk c of row r at position c ^ (r & 15));
+    // rows past M repeat row M-1
+    const unsigned lds0 = lds_address(lds);
+    auto fetch = [&](int row0, int buf) {
+#pragma unroll
+        for (int q = 0; q < BM / 8; ++q) {
+            const int pr = 2 * (4 * q + wave);
+            const int row = pr + (lane >> 5);
+            const int gr = min(row0 + row, M - 1);
+            const int c4 = (lane & 31) ^ (row & 15);
+            load_to_lds16_uncounted(p.x + static_cast<size_t>(gr) * H + 4 * c4,
+                                    __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * BM + pr) * H * sizeof(float))));
+        }
+    };
+    fetch(row_begin, 0);
+
+    float4 wr0[H / 8], wr1[H / 8], wr2[H / 8], wr3[H / 8];
+    load_rows(wr0, p.w[0], p.ldw[0], col, fh);
+    load_rows(wr1, p.w[1], p.ldw[1], col, fh);
+    load_rows(wr2, p.w[2], p.ldw[2], col, fh);
+    load_rows(wr3, p.w[3], p.ldw[3], col, fh);
+
+    int prev_row0 = 0;
+    bool half = false;
+    for (int it = 0; it < nt; ++it) {
+        const float* xa = lds + (it & 1) * TILE_F;
+        const int row0 = row_begin + it * BM;
+        half = row_end - row0 <= 32;
+        // This tile's direct loads were issued a trip ago, ahead of at least 28 stores and bias loads:
+        // "at most 16 outstanding" (completion is in issue order) means it has landed.
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __syncthreads();  // ... for every wave; nobody still reads the other input tile, s1 is complete
+        if (it + 1 < nt) fetch(row0 + BM, (it & 1) ^ 1);
+        // each output is staged while the one before it (the last tile's fourth, for the first) drains;
+        // a half tile's outputs have 4 pieces per thread, the last tile before it was a whole one
+        if (it) TILE_LAYER(false, 8, 8, 0, xa, wr0, p.b[0], s0, (Drain{s1, p.out[3], prev_row0, M}), tid);
+        else TILE_LAYER(false, 0, 0, 0, xa, wr0, p.b[0], s0, (Drain{s1, p.out[3], 0, M}), tid);
+        __syncthreads();  // s0 complete, s1 drained
+        TILE_LAYER(false, 8, 4, 0, xa, wr1, p.b[1], s1, (Drain{s0, p.out[0], row0, M}), tid);
+        __syncthreads();
+        TILE_LAYER(false, 8, 4, 0, xa, wr2, p.b[2], s0, (Drain{s1, p.out[1], row0, M}), tid);
+        __syncthreads();
+        TILE_LAYER(false, 8, 4, 0, xa, wr3, p.b[3], s1, (Drain{s0, p.out[2], row0, M}), tid);
+        prev_row0 = row0;
+    }
+    __syncthreads();
+    if (half) drain_all<4>(Drain{s1, p.out[3], prev_row0, M}, tid);
+    else drain_all<8>(Drain{s1, p.out[3], prev_row0, M}, tid);
 }
 
 constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * H) * sizeof(float);
 
-template <int ACT, bool FROM_X2>
-int launch_linear(hipStream_t s, int M, const float* X, const float* enc_w, const float* enc_b, const ChunkSet& cs,
-                  int nchunks) {
+template <int ACT>
+int launch_linear(hipStream_t s, int M, const float* X, const Chunk& ck) {
     static bool attr_set = false;  // raising the dynamic LDS limit is idempotent; racing threads set the same value
     if (!attr_set) {
-        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear128<ACT, FROM_X2>),
+        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear128<ACT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LINEAR_LDS));
         attr_set = true;
     }
     int ntiles = (M + BM - 1) / BM;
     int gx = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL((k_linear128<ACT, FROM_X2>), dim3(gx, nchunks), dim3(THREADS), LINEAR_LDS, s, M, X, enc_w,
-                       enc_b, cs);
+    hipLaunchKernelGGL((k_linear128<ACT>), dim3(gx), dim3(THREADS), LINEAR_LDS, s, M, X, ck);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -246,7 +530,7 @@ using namespace aig;
 
 extern "C" size_t aig_gen_node_proj_ws_bytes(int64_t n) {
     if (n <= 0) return 256;
-    return 2 * align_up(static_cast<size_t>(n) * H * 4) + align_up(3 * H * 4) + 256;
+    return align_up(static_cast<size_t>(n) * H * 4) + align_up(4 * H * 4) + 256;
 }
 
 extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_weights* w,
@@ -261,33 +545,59 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
         return fail(AIG_EWORKSPACE, "aig_gen_node_proj: workspace %zu < %zu", ws_bytes, aig_gen_node_proj_ws_bytes(n));
     hipStream_t s = static_cast<hipStream_t>(stream);
     Carver c(ws);
-    float* bufA = c.take<float>(static_cast<size_t>(n) * H);
-    float* bufB = c.take<float>(static_cast<size_t>(n) * H);
-    float* zb = c.take<float>(3 * H);  // [0] node_proj.0, [1] edge_scorer.0, [2] edge_attr_pred.0
+    float* bufA = c.take<float>(static_cast<size_t>(n) * H);  // h_cond when the caller does not want it
+    float* zb = c.take<float>(4 * H);  // [0] node_proj.0, [1] edge_scorer.0, [2] edge_attr_pred.0, [3] zeros
     const int M = static_cast<int>(n);
 
-    hipLaunchKernelGGL(k_zbias, dim3(3), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w, w->sc0_b, 3 * H,
+    hipLaunchKernelGGL(k_zbias, dim3(4), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w, w->sc0_b, 3 * H,
                        2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb);
     AIG_LAUNCH_CHECK();
 
-    ChunkSet cs{};
-    int rc;
-    // node_enc: Linear(2,128)+ReLU computed while staging, Linear(128,128)+ReLU on the matrix cores
-    cs.c[0] = Chunk{w->enc2_w, w->enc2_b, bufA, H, 0};
-    if ((rc = launch_linear<1, true>(s, M, x, w->enc0_w, w->enc0_b, cs, 1))) return rc;
-    // node_proj.0 on cat[h, z]: the z block is the bias vector zb[0]
-    cs.c[0] = Chunk{w->proj0_w, zb, bufB, 2 * H, 0};
-    if ((rc = launch_linear<1, false>(s, M, bufA, nullptr, nullptr, cs, 1))) return rc;
+    // node_enc (Linear(2,128)+ReLU while staging, Linear(128,128)+ReLU) and node_proj (on cat[h, z]: the z
+    // block of node_proj.0 is the bias vector zb[0]) in one pass over the rows
     float* hc = h_cond ? h_cond : bufA;
-    cs.c[0] = Chunk{w->proj2_w, w->proj2_b, hc, H, 0};
-    if ((rc = launch_linear<1, false>(s, M, bufB, nullptr, nullptr, cs, 1))) return rc;
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node_mlp3),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP3_LDS));
+            attr_set = true;
+        }
+        Mlp3 p{};
+        p.x = x;
+        p.enc0_w = w->enc0_w;
+        p.enc0_b = w->enc0_b;
+        p.w[0] = w->enc2_w;  p.b[0] = w->enc2_b;  p.ldw[0] = H;
+        p.w[1] = w->proj0_w; p.b[1] = zb;         p.ldw[1] = 2 * H;
+        p.w[2] = w->proj2_w; p.b[2] = w->proj2_b; p.ldw[2] = H;
+        p.out = hc;
+#ifdef MLP3_TIMING
+        p.dbg = reinterpret_cast<long long*>(bufA);  // timing builds are run with h_cond given
+#endif
+        const int rpb = rows_per_block(M, 256);
+        hipLaunchKernelGGL(k_node_mlp3, dim3((M + rpb - 1) / rpb), dim3(THREADS), MLP3_LDS, s, M, rpb, p);
+        AIG_LAUNCH_CHECK();
+    }
     // first Linear of both edge MLPs, split into source block / target block (+ z block and bias)
     const size_t plane = static_cast<size_t>(n) * H;
-    cs.c[0] = Chunk{w->sc0_w, nullptr, proj, 3 * H, 0};
-    cs.c[1] = Chunk{w->sc0_w + H, zb + H, proj + plane, 3 * H, 0};
-    cs.c[2] = Chunk{w->at0_w, nullptr, proj + 2 * plane, 3 * H, 0};
-    cs.c[3] = Chunk{w->at0_w + H, zb + 2 * H, proj + 3 * plane, 3 * H, 0};
-    if ((rc = launch_linear<0, false>(s, M, hc, nullptr, nullptr, cs, 4))) return rc;
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node_proj4),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PROJ4_LDS));
+            attr_set = true;
+        }
+        Proj4 q{};
+        q.x = hc;
+        q.w[0] = w->sc0_w;     q.b[0] = zb + 3 * H; q.out[0] = proj;
+        q.w[1] = w->sc0_w + H; q.b[1] = zb + H;     q.out[1] = proj + plane;
+        q.w[2] = w->at0_w;     q.b[2] = zb + 3 * H; q.out[2] = proj + 2 * plane;
+        q.w[3] = w->at0_w + H; q.b[3] = zb + 2 * H; q.out[3] = proj + 3 * plane;
+        for (int i = 0; i < 4; ++i) q.ldw[i] = 3 * H;
+        const int rpb = rows_per_block(M, 256);
+        hipLaunchKernelGGL(k_node_proj4, dim3((M + rpb - 1) / rpb), dim3(THREADS), PROJ4_LDS, s, M, rpb, q);
+        AIG_LAUNCH_CHECK();
+    }
     return AIG_OK;
 }
 
@@ -298,10 +608,9 @@ extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in
     AIG_REQUIRE(x && w && y, "aig_linear128: null pointer");
     AIG_REQUIRE(x != y, "aig_linear128: in-place operation is not supported");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ChunkSet cs{};
-    cs.c[0] = Chunk{w, bias, y, H, w_in_major ? 1 : 0};
+    const Chunk ck{w, bias, y, H, w_in_major ? 1 : 0};
     AIG_REQUIRE(act >= 0 && act <= 2, "aig_linear128: act=%d (0 none, 1 ReLU, 2 ELU)", act);
-    if (act == 1) return launch_linear<1, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
-    if (act == 2) return launch_linear<2, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
-    return launch_linear<0, false>(s, static_cast<int>(n), x, nullptr, nullptr, cs, 1);
+    if (act == 1) return launch_linear<1>(s, static_cast<int>(n), x, ck);
+    if (act == 2) return launch_linear<2>(s, static_cast<int>(n), x, ck);
+    return launch_linear<0>(s, static_cast<int>(n), x, ck);
 }

@@ -117,6 +117,32 @@ def test_generator_bit_exact_against_checker(case):
     assert np.array_equal(out.x.cpu().numpy(), ref["x"].numpy())
 
 
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 64, 65, 97, 4097, 8192 + 33, 256 * 96, 256 * 160 + 7])
+def test_node_projection_row_runs_bit_exact(n):
+    """The node pipeline deals rows to workgroups in runs of whole and half tiles and streams each
+    output to memory from the product loop of the next: every run shape (one half tile, whole + half,
+    several whole + half, a ragged last run) against the CPU checker, bit for bit."""
+    import ctypes as C
+    G = golden_generator(8)
+    lib = _abi.lib()
+    gen = torch.Generator().manual_seed(n)
+    x = torch.stack([torch.randint(0, 3, (n,), generator=gen).float(), torch.randint(0, 3, (n,), generator=gen).float()], 1)
+    z = torch.randn(128, generator=gen)
+    xd, zd = x.to(DEV).contiguous(), z.to(DEV)
+    proj = torch.full((4, n, 128), float("nan"), device=DEV)
+    hc = torch.full((n, 128), float("nan"), device=DEV)
+    guard = torch.full((4096,), 7.0, device=DEV)   # allocated right after: rows past n must not be written
+    ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), DEV)
+    w = G._weights()
+    _abi.check(lib.aig_gen_node_proj(n, _abi.ptr(xd), _abi.ptr(zd), C.byref(w), _abi.ptr(hc), _abi.ptr(proj), _abi.ptr(ws),
+                                     ws.numel(), _abi.stream()), "aig_gen_node_proj")
+    torch.cuda.synchronize()
+    ref_h, ref_p = ocpu.node_proj(cpu_state(), x.numpy(), z.numpy())
+    assert np.array_equal(hc.cpu().numpy().view(np.int32), ref_h.view(np.int32))
+    assert np.array_equal(proj.cpu().numpy().view(np.int32), ref_p.view(np.int32))
+    assert bool((guard == 7.0).all())
+
+
 def check_plan_against_checker(tpl_cpu: Data, K: int):
     x = tpl_cpu.x
     n = x.size(0)
