@@ -292,7 +292,7 @@ def main():
         if n_proj:
             flops = 7 * 2.0 * 128 * 128 * nodes_per_iter * (n_proj / max(len(templates), 1))   # one launch per template
             tf = flops / (ms_proj * 1e-3) / 1e12
-            mfma = {"kernel": "k_linear128 (entry point aig_gen_node_proj)", "bound": "mfma", "achieved": round(tf, 1),
+            mfma = {"kernel": "k_node_mlp3 + k_node_proj4 (entry point aig_gen_node_proj)", "bound": "mfma", "achieved": round(tf, 1),
                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                     "launches": n_proj, "avg_launch_us": round(ms_proj * 1e3 / n_proj, 2)}
             if measured_peaks().get("mfma_f32_TFs"):

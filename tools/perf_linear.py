@@ -1,4 +1,4 @@
-"""Timing aid: the generator's node projection chain (four k_linear128 launches) at 100k nodes."""
+"""Timing aid: the generator's node projection chain (k_node_mlp3 + k_node_proj4) at 100k nodes."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gan_amd import _abi
