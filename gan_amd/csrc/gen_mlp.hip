@@ -541,6 +541,12 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
     AIG_REQUIRE(w->enc0_w && w->enc0_b && w->enc2_w && w->enc2_b && w->proj0_w && w->proj0_b && w->proj2_w &&
                     w->proj2_b && w->sc0_w && w->sc0_b && w->at0_w && w->at0_b,
                 "aig_gen_node_proj: null weight pointer");
+    // the kernels read weights, biases and rows in 16-byte pieces (x in 8-byte pieces)
+    auto aligned = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+    AIG_REQUIRE(aligned(x, 8) && aligned(proj, 16) && aligned(h_cond, 16) && aligned(ws, 16) && aligned(w->enc2_w, 16) &&
+                    aligned(w->enc2_b, 16) && aligned(w->proj0_w, 16) && aligned(w->proj2_w, 16) &&
+                    aligned(w->proj2_b, 16) && aligned(w->sc0_w, 16) && aligned(w->at0_w, 16),
+                "aig_gen_node_proj: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned");
     if (ws_bytes < aig_gen_node_proj_ws_bytes(n))
         return fail(AIG_EWORKSPACE, "aig_gen_node_proj: workspace %zu < %zu", ws_bytes, aig_gen_node_proj_ws_bytes(n));
     hipStream_t s = static_cast<hipStream_t>(stream);

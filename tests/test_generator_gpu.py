@@ -143,6 +143,23 @@ def test_node_projection_row_runs_bit_exact(n):
     assert bool((guard == 7.0).all())
 
 
+def test_node_projection_rejects_misaligned_rows():
+    """The kernels read x in 8-byte and everything else in 16-byte pieces: a pointer that is not aligned
+    so is refused up front instead of faulting on the GPU."""
+    import ctypes as C
+    G = golden_generator(8)
+    lib = _abi.lib()
+    n = 100
+    x = torch.zeros(2 * n + 1, device=DEV)[1:].view(n, 2)   # 4 bytes past an aligned address
+    z = torch.zeros(128, device=DEV)
+    proj = torch.empty((4, n, 128), device=DEV)
+    ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), DEV)
+    w = G._weights()
+    with pytest.raises(_abi.AigAbiError):
+        _abi.check(lib.aig_gen_node_proj(n, _abi.ptr(x), _abi.ptr(z), C.byref(w), None, _abi.ptr(proj), _abi.ptr(ws),
+                                         ws.numel(), _abi.stream()), "aig_gen_node_proj")
+
+
 def check_plan_against_checker(tpl_cpu: Data, K: int):
     x = tpl_cpu.x
     n = x.size(0)
