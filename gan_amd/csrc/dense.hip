@@ -163,10 +163,47 @@ int wg_blocks(int64_t n, int per_block, int cap) {
     return (int)b;
 }
 
+// y[n][c] = x[n][0] w[c][0] + x[n][1] w[c][1]: the first attention layer's projection of the two node
+// features (models/discriminator.py:56, GATConv(2, 32, heads=4).lin).  Bound by the 512 bytes written per
+// node; a half-wave writes a row, a lane four columns.
+__global__ __launch_bounds__(256) void k_linear_in2(int n, const float* __restrict__ x, const float* __restrict__ w,
+                                                    float* __restrict__ y) {
+    const int l = threadIdx.x & 31;
+    float w0[4], w1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        w0[u] = w[2 * (4 * l + u)];
+        w1[u] = w[2 * (4 * l + u) + 1];
+    }
+    const int rows_per_pass = gridDim.x * (256 / 32);
+    for (int r = blockIdx.x * (256 / 32) + (threadIdx.x >> 5); r < n; r += rows_per_pass) {
+        const float2 xv = *reinterpret_cast<const float2*>(x + 2 * (size_t)r);
+        float4 o;
+        o.x = fmaf(xv.y, w1[0], xv.x * w0[0]);
+        o.y = fmaf(xv.y, w1[1], xv.x * w0[1]);
+        o.z = fmaf(xv.y, w1[2], xv.x * w0[2]);
+        o.w = fmaf(xv.y, w1[3], xv.x * w0[3]);
+        reinterpret_cast<float4*>(y + (size_t)r * H)[l] = o;
+    }
+}
+
 }  // namespace
 }  // namespace aig
 
 using namespace aig;
+
+extern "C" int aig_linear_in2(int64_t n, const float* x, const float* w, float* y, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_linear_in2: n=%lld out of range", (long long)n);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(x && w && y, "aig_linear_in2: null pointer");
+    AIG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                "aig_linear_in2: x must be 8-byte aligned, y 16-byte aligned");
+    const int64_t want = (n + 7) / 8;
+    const int blocks = (int)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_linear_in2, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), (int)n, x, w, y);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
 
 extern "C" size_t aig_wgrad_ws_bytes(int64_t n, int64_t F) {
     (void)n;

@@ -13,6 +13,7 @@ namespace {
 
 constexpr int HD_IN = 256, HD_H1 = 128, HD_H2 = 64;
 constexpr int HD_THREADS = 256;
+constexpr int HD_FWD_THREADS = 1024;  // forward pass: 16 waves, so that every weight row is in flight at once
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -20,13 +21,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// s_a1 / s_a2 <- activations of the two hidden layers for input s_r (all in LDS); wave per output row
+// s_a1 / s_a2 <- activations of the two hidden layers for input s_r (all in LDS); wave per output row,
+// four rows at a time, any number of waves
 __device__ __forceinline__ void head_hidden(const float* __restrict__ W1, const float* __restrict__ b1,
                                             const float* __restrict__ W2, const float* __restrict__ b2,
                                             const float* s_r, float* s_a1, float* s_a2) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, step = 4 * (blockDim.x >> 6);
     const float4 rv = reinterpret_cast<const float4*>(s_r)[lane];
-    for (int row = wave * 4; row < HD_H1; row += 16) {  // four rows per wave at a time
+    for (int row = wave * 4; row < HD_H1; row += step) {  // four rows per wave at a time
         float p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -41,7 +43,7 @@ __device__ __forceinline__ void head_hidden(const float* __restrict__ W1, const 
     }
     __syncthreads();
     const float2 av = reinterpret_cast<const float2*>(s_a1)[lane];
-    for (int row = wave * 4; row < HD_H2; row += 16) {
+    for (int row = wave * 4; row < HD_H2; row += step) {
         float p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -57,7 +59,7 @@ __device__ __forceinline__ void head_hidden(const float* __restrict__ W1, const 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(HD_THREADS) void k_head_fwd(const float* __restrict__ r, const float* __restrict__ W1,
+__global__ __launch_bounds__(HD_FWD_THREADS) void k_head_fwd(const float* __restrict__ r, const float* __restrict__ W1,
                                                          const float* __restrict__ b1, const float* __restrict__ W2,
                                                          const float* __restrict__ b2, const float* __restrict__ W3,
                                                          const float* __restrict__ b3, float* __restrict__ score,
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(HD_THREADS) void k_head_fwd(const float* __restrict
     __shared__ __attribute__((aligned(16))) float s_a1[HD_H1];
     __shared__ float s_a2[HD_H2];
     const int tid = threadIdx.x;
-    s_r[tid] = r[tid];
+    if (tid < HD_IN) s_r[tid] = r[tid];
     __syncthreads();
     head_hidden(W1, b1, W2, b2, s_r, s_a1, s_a2);
     if (tid < 64) {
@@ -190,7 +192,7 @@ using namespace aig;
 extern "C" int aig_head_fwd(const float* r, const float* w1, const float* b1, const float* w2, const float* b2,
                             const float* w3, const float* b3, float* score, float* act, void* stream) {
     AIG_REQUIRE(r && w1 && b1 && w2 && b2 && w3 && b3 && score && act, "aig_head_fwd: null pointer");
-    hipLaunchKernelGGL(k_head_fwd, dim3(1), dim3(HD_THREADS), 0, static_cast<hipStream_t>(stream), r, w1, b1, w2, b2,
+    hipLaunchKernelGGL(k_head_fwd, dim3(1), dim3(HD_FWD_THREADS), 0, static_cast<hipStream_t>(stream), r, w1, b1, w2, b2,
                        w3, b3, score, act);
     AIG_LAUNCH_CHECK();
     return AIG_OK;

@@ -181,7 +181,21 @@ def _linear128(x: torch.Tensor, w: torch.Tensor, in_major: bool) -> torch.Tensor
     return y
 
 
+def _linear_in2(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x w^T for the two node features, x [n,2], w [128,2] (the first attention layer's projection)."""
+    x, w = x.contiguous(), w.contiguous()
+    y = torch.empty((x.size(0), HIDDEN), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.timed("aig_linear_in2", _abi.lib().aig_linear_in2, int(x.size(0)), _abi.ptr(x), _abi.ptr(w),
+                          _abi.ptr(y), _abi.stream()), "aig_linear_in2")
+    return y
+
+
 _USE_LINEAR128 = os.environ.get("AIG_NO_LINEAR128", "") == ""
+
+
+def _is_in2(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (_USE_LINEAR128 and x.dim() == 2 and x.size(1) == 2 and tuple(w.shape) == (HIDDEN, 2)
+            and x.dtype == torch.float32 and x.is_cuda)
 
 
 def _is128(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -205,6 +219,8 @@ class _Project(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        if _is_in2(x, w):
+            return _linear_in2(x, w)
         return _linear128(x, w, False) if _is128(x, w) else x @ w.t()
 
     @staticmethod

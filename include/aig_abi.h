@@ -178,6 +178,10 @@ int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, cons
 int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,
                   float* y, void* stream);
 
+/* Projection of the critic's FIRST attention layer, y = x W^T with x [n,2] (node type, inverter count), w [128,2],
+ * y [n,128] - torch.nn.functional.linear inside GATConv(2, 32, heads=4).lin (models/discriminator.py:31,56). */
+int aig_linear_in2(int64_t n, const float* x, const float* w, float* y, void* stream);
+
 /* Critic head: score = out(mlp(r)) for the pooled graph vector r [256] - Linear(256,128), ReLU, Linear(128,64),
  * ReLU, Linear(64,1) (models/discriminator.py:36-40,98-100) - in one launch, and its backward pass in one launch
  * (torch runs three GEMV launches forward and a dozen small launches backward, ten times per training step).
