@@ -251,6 +251,20 @@ def test_linear128_matches_fp32_matmul(n, in_major):
         assert torch.equal(y2[64], y2[0])
 
 
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 4099, 100003])
+def test_linear_in2_matches_fp32_product(n):
+    """aig_linear_in2 (first attention layer's projection of the two node features) against the fp32 product,
+    to 1e-6 of the row scale (two terms: the only freedom is which of them is fused into the fmaf)."""
+    from gan_amd.discriminator import _linear_in2
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 4, (n, 2), generator=gen).float().to(DEV)
+    w = torch.randn(128, 2, generator=gen).to(DEV)
+    got = _linear_in2(x, w)
+    want = (x.double() @ w.double().t()).float()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-6 * (want.abs().max().item() + 1e-6)
+
+
 @pytest.mark.parametrize("case", ["levels", "no_depth", "negative_depths"])
 def test_closed_form_gradient_penalty_matches_autograd(case):
     """gradient_penalty_closed_form against the autograd path (itself checked against the CPU
