@@ -688,17 +688,18 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_hub_finish(
         const int c0 = t.w, c1 = k + 1 < n_hub ? hub_tab[2 + k].w : total;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float das = 0.f;
-        for (int c = c0 + hw; c < c1; c += 4 * HW_PER_BLOCK) {
-            float4 a[4];
-            float dd[4];
+        constexpr int INFL = 16;  // rows in flight per half-wave (added in row order whatever this is)
+        for (int c = c0 + hw; c < c1; c += INFL * HW_PER_BLOCK) {
+            float4 a[INFL];
+            float dd[INFL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < INFL; ++u) {
                 const size_t row = (size_t)min(c + u * HW_PER_BLOCK, c1 - 1);
                 a[u] = reinterpret_cast<const float4*>(part_acc + row * H)[l];
                 dd[u] = part_das[row * HEADS + h];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < INFL; ++u)
                 if (c + u * HW_PER_BLOCK < c1) {
                     acc.x += a[u].x; acc.y += a[u].y; acc.z += a[u].z; acc.w += a[u].w;
                     das += dd[u];
