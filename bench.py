@@ -163,7 +163,7 @@ def main():
     a = ap.parse_args()
 
     from gan_amd import _abi, parallel
-    from gan_amd.constraints import enforce_aig_constraints, resync_attrs
+    from gan_amd.constraints import enforce_aig_constraints, repair_and_resync, resync_attrs
     from gan_amd.data import Batch, Data
     from gan_amd.dataset import pad_data
     from gan_amd.sample import sample_many
@@ -250,7 +250,7 @@ def main():
     def one_at_a_time(iters):
         for _ in range(iters):
             for t in templates:
-                resync_attrs(enforce_aig_constraints(trainer.G(t, draw_z())))
+                repair_and_resync(trainer.G(t, draw_z()))
 
     sample_streams = [torch.cuda.Stream(device=dev) for _ in range(a.sample_in_flight)]
 

@@ -77,10 +77,15 @@ class EnforceHandle:
     __slots__ = ("data", "out_ei", "out_ea", "node_depth", "x_out", "count_host", "ready")
 
 
-def enforce_begin(data: Data, strict: bool = False, check_all_on_path: bool = True) -> EnforceHandle:
+def enforce_begin(data: Data, strict: bool = False, check_all_on_path: bool = True,
+                  want_depth: bool = True) -> EnforceHandle:
     """First half of ``enforce_aig_constraints``: enqueues the repair on the current stream and starts
     the copy of the repaired edge count to the host.  A caller that keeps several graphs in flight
-    (bulk sampling) enqueues other work before it calls ``enforce_finish``."""
+    (bulk sampling) enqueues other work before it calls ``enforce_finish``.
+
+    ``want_depth=False`` leaves out the breadth-first walk behind ``node_depth`` (the repaired graph then
+    carries ``node_depth = None``): for the sampling path, where ``resync_attrs`` follows and replaces
+    ``node_depth`` and ``x[:, 1]`` (AIGgan.py:105-110) - see ``repair_and_resync``."""
     lib = _abi.lib()
     h = EnforceHandle()
     h.data, h.ready = data, None
@@ -95,6 +100,7 @@ def enforce_begin(data: Data, strict: bool = False, check_all_on_path: bool = Tr
         data.node_depth = torch.full((n,), -1, dtype=torch.long, device=dev)
         data.x[:, 1] = 0
         return h
+    h.node_depth = None
     x_in = _x32(x)
     inv = _inv64(data, E)
     kind, depth = _depth_arg(data, n, dev)
@@ -102,7 +108,7 @@ def enforce_begin(data: Data, strict: bool = False, check_all_on_path: bool = Tr
     out_ei = torch.empty((2, cap), dtype=torch.int64, device=dev)
     out_ea = torch.empty((cap,), dtype=torch.int64, device=dev)
     out_cnt = torch.empty(1, dtype=torch.int32, device=dev)
-    node_depth = torch.empty(n, dtype=torch.int64, device=dev)
+    node_depth = torch.empty(n, dtype=torch.int64, device=dev) if want_depth else None
     x_out = torch.empty((n, 2), dtype=torch.float32, device=dev)
     ws = _abi.workspace(lib.aig_enforce_ws_bytes(n, E), dev)
     _abi.check(lib.aig_enforce(n, E, _abi.ptr(x_in), _abi.ptr(ei), _abi.ptr(inv), kind, _abi.ptr(depth),
@@ -133,6 +139,12 @@ def enforce_finish(h: EnforceHandle) -> Data:
 
 
 # ------------------------------------------------------------------------------------------ penalties
+def repair_and_resync(data: Data) -> Data:
+    """``resync_attrs(enforce_aig_constraints(data))`` (AIGgan.py:105-110) without the walk whose result
+    the resync overwrites: same tensors, one level-by-level traversal instead of two."""
+    return resync_attrs(enforce_finish(enforce_begin(data, want_depth=False)))
+
+
 def aig_constraint_penalties(data: Data, weights: Optional[Dict[str, float]] = None) -> Dict[str, torch.Tensor]:
     """Violation counts as 0-dim float32 device tensors (no host synchronisation)."""
     lib = _abi.lib()

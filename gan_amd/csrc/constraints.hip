@@ -742,7 +742,7 @@ extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* 
     AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_enforce: needs n > 0 and E > 0 (got %lld, %lld)",
                 (long long)n, (long long)E);
     AIG_REQUIRE((double)n * (double)n < 1.8e19, "aig_enforce: n too large for 64-bit pair keys");
-    AIG_REQUIRE(x && edge_index && out_edge_index && out_edge_attr && out_count && node_depth && x_out && ws,
+    AIG_REQUIRE(x && edge_index && out_edge_index && out_edge_attr && out_count && x_out && ws,
                 "aig_enforce: null pointer");
     AIG_REQUIRE(cap >= 2 * n, "aig_enforce: output capacity %lld < 2n", (long long)cap);
     AIG_REQUIRE(depth_kind >= 0 && depth_kind <= 2 && (depth_kind == 0 || depth), "aig_enforce: bad depth argument");
@@ -795,6 +795,7 @@ extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* 
                        reinterpret_cast<long long*>(out_edge_index), reinterpret_cast<long long*>(out_edge_attr),
                        out_count);
     AIG_LAUNCH_CHECK();
+    if (!node_depth) return AIG_OK;  // the caller recomputes the depths anyway (sampling: resync follows)
     // node_depth: breadth-first level from the PIs over the cleaned (pre-repair) edges
     rc = run_csr(s, N, M, 32, key_src, skey_src, ids, sid, ei + E, sptr, adj, temp, tb);
     if (rc) return rc;

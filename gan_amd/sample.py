@@ -18,7 +18,8 @@ from typing import Callable, Iterable, Iterator, List, Optional, Tuple
 import torch
 
 from . import parallel
-from .constraints import enforce_aig_constraints, enforce_begin, enforce_finish, resync_attrs
+from .constraints import (enforce_aig_constraints, enforce_begin, enforce_finish, repair_and_resync,
+                          resync_attrs)
 from .data import Data
 from .dataset import load_pt_dataset
 from .generator import AIGGenerator
@@ -39,7 +40,7 @@ def sample_one(G: AIGGenerator, tpl: Data, z: torch.Tensor) -> Data:
     """AIGgan.py:104-111: forward, repair, resync."""
     with torch.no_grad():
         raw = G(tpl, z)
-    return resync_attrs(enforce_aig_constraints(raw))
+    return repair_and_resync(raw)   # = resync_attrs(enforce_aig_constraints(raw)), one graph walk fewer
 
 
 def sample_many(G: AIGGenerator, jobs: Iterable[Tuple[Data, Callable[[], torch.Tensor]]], in_flight: int = 4,
@@ -75,7 +76,7 @@ def sample_many(G: AIGGenerator, jobs: Iterable[Tuple[Data, Callable[[], torch.T
     for i, (tpl, draw_z) in enumerate(jobs):
         st = streams[i % len(streams)]
         with torch.cuda.stream(st), torch.no_grad():
-            pending.append((st, enforce_begin(G(tpl, draw_z()))))
+            pending.append((st, enforce_begin(G(tpl, draw_z()), want_depth=False)))   # the resync replaces it
         if len(pending) >= len(streams):
             yield finish()
     while pending:

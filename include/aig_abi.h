@@ -277,7 +277,8 @@ int aig_gp_param_grad(int64_t n, int64_t L, const float* coef, const float* g_r,
  * (-is_and, -int(depth), id); an AND keeps its two smallest-pos legal fan-ins, or - with fewer than two -
  * the two smallest-pos PI/AND nodes other than itself (a kept legal fan-in keeps its inversion value).
  * Outputs: out_edge_index rows of stride `cap` (>= 2n), out_edge_attr [cap], *out_count = edges written;
- * node_depth int64 [n] = breadth-first level from the PIs over the CLEANED edges (-1 unreachable);
+ * node_depth int64 [n] = breadth-first level from the PIs over the CLEANED edges (-1 unreachable), or NULL
+ * to leave that walk out (AIGgan.py:105-110 calls resync_attrs right after the repair, which replaces it);
  * x_out [n,2] = (x[:,0], min(2, sum of merged inversion values entering the node over the cleaned edges)). */
 size_t aig_enforce_ws_bytes(int64_t n, int64_t E);
 int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,

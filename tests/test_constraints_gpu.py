@@ -6,7 +6,7 @@ import torch
 
 from conftest import golden_names
 from gan_amd import _abi
-from gan_amd.constraints import (aig_constraint_penalties, enforce_aig_constraints, resync_attrs,
+from gan_amd.constraints import (aig_constraint_penalties, enforce_aig_constraints, repair_and_resync, resync_attrs,
                                  validate_strict_aig)
 from gan_amd.data import Data
 from gan_amd.synth import synth_aig
@@ -98,6 +98,20 @@ def test_constraints_match_checker_on_random_graphs(n, e, depth_mode):
     assert_same_graph(fixed, fixed_ref)
     assert validate_strict_aig(fixed) == ocpu.validate_strict_aig(fixed_ref.clone())
     assert_same_graph(resync_attrs(fixed), ocpu.resync_attrs(fixed_ref))
+
+
+@pytest.mark.parametrize("n,e,depth_mode", [(300, 900, "long"), (5000, 30000, "float"), (777, 40000, None)])
+def test_repair_and_resync_is_repair_then_resync(n, e, depth_mode):
+    """The sampling tail leaves out the repair's own depth walk, whose result the resync replaces
+    (AIGgan.py:105-110): every tensor of the result equals the two calls in a row and the CPU checker's."""
+    g = junk_graph(n, e, seed=3 * n + e, depth_mode=depth_mode)
+    fused = repair_and_resync(to_dev(g))
+    two = resync_attrs(enforce_aig_constraints(to_dev(g)))
+    assert_same_graph(fused, two)
+    assert_same_graph(fused, ocpu.resync_attrs(ocpu.enforce_aig_constraints(g.clone())))
+    # an edge-free graph takes the early exits of both halves
+    empty = Data(x=g.x.clone(), edge_index=torch.zeros((2, 0), dtype=torch.long), edge_attr=torch.zeros((0, 1), dtype=torch.long))
+    assert_same_graph(repair_and_resync(to_dev(empty)), resync_attrs(enforce_aig_constraints(to_dev(empty))))
 
 
 @pytest.mark.parametrize("orientation", ["forward", "dataset"])
