@@ -308,7 +308,9 @@ def main():
                        "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
             "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
             "sample_nodes_per_sec_one_at_a_time": round(sample_nodes_per_sec_single, 1),
-            "sample_note": f"G.forward + enforce + resync per sample; bulk rate with {a.sample_in_flight} independent "
+            "sample_note": f"G.forward + enforce + resync per sample (gan_amd.constraints.repair_and_resync: same tensors as "
+                           "the two calls in a row, without the repair's own depth walk that the resync overwrites); "
+                           f"bulk rate with {a.sample_in_flight} independent "
                            "samples in flight on as many streams, and the rate of strictly one sample after another",
             "roofline": roof,
             "roofline_mfma": mfma,
