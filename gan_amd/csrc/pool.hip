@@ -132,13 +132,40 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* 
             }
         }
     }
-    if (cur >= 0) flush();
+    // The segment a half-wave ends with is not flushed by itself: the eight half-waves of a block walk
+    // 256 consecutive sorted rows, mostly of one or two levels, so their closing segments are merged per
+    // level in LDS first - one atomic per block, level and column instead of one per half-wave.
+    __shared__ unsigned long long seg[HW_PER_BLOCK][H];
+    __shared__ int seg_level[HW_PER_BLOCK];
+    if (l == 0) seg_level[hw] = cur;
+    if (cur >= 0) {
+        seg[hw][l * 4 + 0] = pack_max(mx.x, mi.x);
+        seg[hw][l * 4 + 1] = pack_max(mx.y, mi.y);
+        seg[hw][l * 4 + 2] = pack_max(mx.z, mi.z);
+        seg[hw][l * 4 + 3] = pack_max(mx.w, mi.w);
+    }
     reinterpret_cast<float4*>(&red[hw][0])[l] = sum;
     __syncthreads();
     if (threadIdx.x < H) {
+        const int f = threadIdx.x;
         float s = 0.f;
-        for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][threadIdx.x];
-        partial[(size_t)blockIdx.x * H + threadIdx.x] = s;
+        for (int k = 0; k < HW_PER_BLOCK; ++k) s += red[k][f];
+        partial[(size_t)blockIdx.x * H + f] = s;
+        int lev = -1;
+        unsigned long long best = 0ull;
+        for (int k = 0; k < HW_PER_BLOCK; ++k) {  // levels ascend with k (sorted rows)
+            const int lk = seg_level[k];
+            if (lk < 0) continue;
+            const unsigned long long v = seg[k][f];
+            if (lk != lev) {
+                if (lev >= 0) atomicMax(table + (size_t)lev * H + f, best);
+                lev = lk;
+                best = v;
+            } else if (v > best) {
+                best = v;
+            }
+        }
+        if (lev >= 0) atomicMax(table + (size_t)lev * H + f, best);
     }
 }
 
