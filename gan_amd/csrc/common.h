@@ -55,4 +55,19 @@ inline int grid_for(int64_t items, int per_block, int cap = 1 << 20) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not
+// see (after the builtin it waits for ALL memory traffic before the next LDS read, which would put the
+// whole load latency in front of the products it is meant to hide behind).  The kernel waits itself:
+// counted wait + barrier at the top of a trip.  lds_byte_addr: wave-uniform LDS address of the 1 KB
+// the 64 lanes fill.
+__device__ __forceinline__ void load_to_lds16_uncounted(const float* src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :
+                 : "s"(lds_byte_addr), "v"(src)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_address(const float* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const float*)p;
+}
+
 }  // namespace aig

@@ -26,11 +26,6 @@ constexpr int WG_SMALL_BLOCKS_MAX = 512;   // small F: partials are at most 2 KB
 constexpr int TILE = 64;
 constexpr size_t WGRAD_LDS = (size_t)2 * 2 * TILE * H * sizeof(float);
 
-__device__ __forceinline__ void load_to_lds16(const float* src, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
 __global__ __launch_bounds__(256) void k_wgrad128(int n, const float* __restrict__ g, const float* __restrict__ x,
                                                   float* __restrict__ partial /*[grid][128][128]*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][g|x][TILE][H]
@@ -40,24 +35,28 @@ __global__ __launch_bounds__(256) void k_wgrad128(int n, const float* __restrict
     const int n0 = blockIdx.x * chunk, n1 = min(n, n0 + chunk);
     const int ntiles = n1 > n0 ? (n1 - n0 + TILE - 1) / TILE : 0;
     // wave w, instruction q fills tile rows 2(4q+w) and 2(4q+w)+1; lane -> (row parity kh, 16-byte column col)
+    // The loads are issued from inline asm: after the builtin the compiler waits for ALL memory traffic
+    // before the next LDS read, i.e. for tile t+1 before the products of tile t.  These are this kernel's
+    // only memory operations until the epilogue, so "none outstanding" at the top of a trip is exact.
+    const unsigned lds0 = lds_address(lds);
     auto fetch = [&](int tile, int buf) {
-        float* G = lds + (size_t)buf * 2 * TILE * H;
-        float* X = G + TILE * H;
+        const unsigned G = lds0 + (unsigned)((size_t)buf * 2 * TILE * H * sizeof(float));
+        const unsigned X = G + (unsigned)(TILE * H * sizeof(float));
 #pragma unroll
         for (int q = 0; q < TILE / 8; ++q) {
             const int pr = 2 * (4 * q + w);
             const int row = n0 + tile * TILE + pr + kh;
             const size_t off = (size_t)(row < n1 ? row : n0) * H + 4 * col;  // rows past the range: any valid row
-            load_to_lds16(g + off, G + pr * H);
-            load_to_lds16(x + off, X + pr * H);
+            load_to_lds16_uncounted(g + off, __builtin_amdgcn_readfirstlane(G + (unsigned)(pr * H * sizeof(float))));
+            load_to_lds16_uncounted(x + off, __builtin_amdgcn_readfirstlane(X + (unsigned)(pr * H * sizeof(float))));
         }
     };
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     if (ntiles > 0) fetch(0, 0);
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        __syncthreads();  // drains this wave's loads of tile `tile`, then meets the other waves: the tile is
-                          // complete and the other buffer is no longer being read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of tile `tile` ...
+        __syncthreads();  // ... and everybody else's: the tile is complete, the other buffer no longer read
         const int rows = n1 - (n0 + tile * TILE);
         if (rows < TILE) {  // last, ragged tile: rows past the range must not contribute
             float* G = lds + (size_t)buf * 2 * TILE * H;
@@ -67,16 +66,26 @@ __global__ __launch_bounds__(256) void k_wgrad128(int n, const float* __restrict
         if (tile + 1 < ntiles) fetch(tile + 1, buf ^ 1);
         const float* G = lds + (size_t)buf * 2 * TILE * H + 32 * w + col;
         const float* X = lds + (size_t)buf * 2 * TILE * H + TILE * H + col;
+        // operands of pair kk+1 are requested before the four products of pair kk are issued
+        auto products = [&](int kk_end) {
+            float a = G[kh * H];
+            float b0 = X[kh * H], b1 = X[kh * H + 32], b2 = X[kh * H + 64], b3 = X[kh * H + 96];
 #pragma unroll 8
-        for (int kk = 0; kk < TILE / 2; ++kk) {
-            const int ro = (2 * kk + kh) * H;
-            const float a = G[ro];
-            const float b0 = X[ro], b1 = X[ro + 32], b2 = X[ro + 64], b3 = X[ro + 96];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
-        }
+            for (int kk = 0; kk < kk_end; ++kk) {
+                const int rn = (2 * (kk + 1 < kk_end ? kk + 1 : kk) + kh) * H;
+                const float na = G[rn];
+                const float n0 = X[rn], n1 = X[rn + 32], n2 = X[rn + 64], n3 = X[rn + 96];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+                a = na; b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // (the four x values come as two 2-address reads)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        };
+        if (rows >= TILE) products(TILE / 2);
+        else products((rows + 1) / 2);  // a ragged tile: only its (zero-padded) pairs of rows
     }
     float* out = partial + (size_t)blockIdx.x * H * H;
 #pragma unroll
