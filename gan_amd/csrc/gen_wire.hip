@@ -176,22 +176,39 @@ __device__ void nth_element_(RowView<S>& q, int nth, int c) {
 constexpr int SEL_THREADS = 128;
 constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets two blocks share a CU
 
-__global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, const float* __restrict__ logits,
+__global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
                                                              const int* __restrict__ cnt,
                                                              const int* __restrict__ want, int* __restrict__ sel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* val = reinterpret_cast<float*>(smem);                               // [SEL_CAP][SEL_THREADS+1]
-    unsigned char* idx = smem + SEL_CAP * (SEL_THREADS + 1) * sizeof(float);   // [SEL_CAP][SEL_THREADS]
+    float* val = reinterpret_cast<float*>(smem);                                     // [cap][SEL_THREADS+1]
+    unsigned char* idx = smem + (size_t)cap * (SEL_THREADS + 1) * sizeof(float);     // [cap][SEL_THREADS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row_base = blockIdx.x * SEL_THREADS;
 
-    // cooperative fill: each wave copies the short rows of its own 64 threads, coalesced along the row
-    for (int t = 0; t < 64; ++t) {
-        const int slot = wave * 64 + t, r = row_base + slot;
-        if (r >= rows) break;
-        const int c = cnt[r], k = min(want[r], c);
-        if (k <= 0 || k * 64 <= c) continue;
-        for (int j = lane; j < c; j += 64) val[j * (SEL_THREADS + 1) + slot] = logits[static_cast<size_t>(r) * ld + j];
+    // cooperative fill: each wave copies the short rows of its own 64 threads, coalesced along the row,
+    // eight rows (two loads each: rows have fewer than 128 entries) in flight at a time
+    const int my_r = row_base + tid;
+    const int my_c = my_r < rows ? cnt[my_r] : 0;
+    const int my_k = my_r < rows ? min(want[my_r], my_c) : 0;
+    const bool my_need = my_k > 0 && my_k * 64 > my_c;   // replayed on the LDS copy
+    for (int t0 = 0; t0 < 64; t0 += 8) {
+        float v0[8], v1[8];
+        int cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u;
+            cc[u] = __shfl(my_need ? my_c : 0, t, 64);
+            // unconditional loads at clamped addresses (a load under a condition becomes a branch with a wait)
+            const float* row = logits + static_cast<size_t>(min(row_base + wave * 64 + t, rows - 1)) * ld;
+            v0[u] = row[min(lane, ld - 1)];
+            v1[u] = row[min(lane + 64, ld - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int slot = wave * 64 + t0 + u;
+            if (lane < cc[u]) val[lane * (SEL_THREADS + 1) + slot] = v0[u];
+            if (lane + 64 < cc[u]) val[(lane + 64) * (SEL_THREADS + 1) + slot] = v1[u];
+        }
     }
     __syncthreads();
 
@@ -243,7 +260,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, c
     sel[2 * r + 1] = s1;
 }
 
-constexpr size_t SEL_LDS = SEL_CAP * (SEL_THREADS + 1) * sizeof(float) + SEL_CAP * SEL_THREADS;
+// LDS of a block whose longest replayed row has `cap` entries (rows are at most ld long): with the 64
+// candidates of the default window three blocks share a CU instead of two
+constexpr size_t sel_lds(int cap) { return (size_t)cap * ((SEL_THREADS + 1) * sizeof(float) + SEL_THREADS); }
+constexpr size_t SEL_LDS = sel_lds(SEL_CAP);
 
 // ------------------------------------------------------------------------------------------ emit
 __device__ __forceinline__ int inv_bit(const float* __restrict__ A2, const float* __restrict__ B2,
@@ -435,8 +455,9 @@ extern "C" int aig_topk_select(int64_t rows, int64_t ld, const float* logits, co
         attr_set = true;
     }
     int64_t blocks = (rows + SEL_THREADS - 1) / SEL_THREADS;
-    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)blocks), dim3(SEL_THREADS), SEL_LDS, s, (int)rows, (int)ld, logits,
-                       cnt, want, sel);
+    const int cap = ld < SEL_CAP ? (int)ld : SEL_CAP;
+    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)blocks), dim3(SEL_THREADS), sel_lds(cap), s, (int)rows, (int)ld, cap,
+                       logits, cnt, want, sel);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
