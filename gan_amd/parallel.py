@@ -27,6 +27,9 @@ def env_world() -> tuple:
 
 def init_distributed(backend: Optional[str] = None) -> tuple:
     rank, local_rank, world = env_world()
+    # this ROCm stack shares device memory between processes through dmabuf only; RCCL needs it said before
+    # the HIP runtime starts (an environment that already says otherwise is left alone)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         if backend is None:
             # "nccl" is RCCL on ROCm; AIG_DIST_BACKEND=gloo lets several ranks rehearse on one GPU
