@@ -251,8 +251,11 @@ class Trainer:
                               candidate_k=args.candidate_k).to(device)
         self.D = AIGDiscriminator(in_dim=2, hidden_dim=args.d_hidden).to(device)
         parallel.broadcast_parameters([self.G, self.D])
-        self.opt_G = torch.optim.Adam(self.G.parameters(), lr=args.lr, betas=(0.5, 0.9))
-        self.opt_D = torch.optim.Adam(self.D.parameters(), lr=args.lr, betas=(0.5, 0.9))
+        # the same update as train.py:221-222; on a HIP device the single-kernel ("fused") form of it, one
+        # launch per step instead of a dozen multi-tensor launches
+        fused = {"fused": True} if device.type == "cuda" and os.environ.get("AIG_NO_FUSED_ADAM") is None else {}
+        self.opt_G = torch.optim.Adam(self.G.parameters(), lr=args.lr, betas=(0.5, 0.9), **fused)
+        self.opt_D = torch.optim.Adam(self.D.parameters(), lr=args.lr, betas=(0.5, 0.9), **fused)
         self.reducer = parallel.FlatGradAllReduce(self.D.parameters())
         self._d_params = [p for p in self.D.parameters() if p.requires_grad]
         self._captured: "OrderedDict[tuple, CapturedCriticTerms]" = OrderedDict()
