@@ -47,14 +47,14 @@ SIGNATURES = {
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_bwd": (INT, [I64, I64] + [P] * 27 + [P, SZ, P]),
-    "aig_level_pool_bwd": (INT, [I64, I64, P, P, P, P, P, P]),
+    "aig_level_pool_bwd": (INT, [I64, I64, P, P, P, P, P, P, P]),
     "aig_level_pool_bwd_adj_ws_bytes": (SZ, [I64]),
-    "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
+    "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_gp_forward": (INT, [I64] + [P] * 10 + [P]),
     "aig_gp_input_grad_ws_bytes": (SZ, [I64]),
-    "aig_gp_input_grad": (INT, [I64, I64] + [P] * 13 + [P, SZ, P]),
+    "aig_gp_input_grad": (INT, [I64, I64] + [P] * 14 + [P, SZ, P]),
     "aig_gp_param_grad_ws_bytes": (SZ, [I64]),
-    "aig_gp_param_grad": (INT, [I64, I64] + [P] * 19 + [P, SZ, P]),
+    "aig_gp_param_grad": (INT, [I64, I64] + [P] * 20 + [P, SZ, P]),
     "aig_linear128": (INT, [I64, P, P, INT, P, INT, P, P]),
     "aig_linear_in2": (INT, [I64, P, P, P, P]),
     "aig_head_fwd": (INT, [P] * 9 + [P]),
@@ -64,8 +64,9 @@ SIGNATURES = {
     "aig_wgrad": (INT, [I64, I64, P, P, P, P, SZ, P]),
     "aig_level_plan_ws_bytes": (SZ, [I64, I64]),
     "aig_level_plan": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
+    "aig_level_plan_dyn": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),
-    "aig_level_pool_fwd": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, SZ, P]),
+    "aig_level_pool_fwd": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
     "aig_enforce_ws_bytes": (SZ, [I64, I64]),
     "aig_enforce": (INT, [I64, I64, P, P, P, INT, P, P, I64, P, P, P, P, P, SZ, P]),
     "aig_penalties_ws_bytes": (SZ, [I64, I64]),

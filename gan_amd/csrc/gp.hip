@@ -26,6 +26,10 @@ __device__ __forceinline__ float d_elu(float h) { return h > 0.f ? 1.f : h + 1.f
 __device__ __forceinline__ float dd_elu(float h) { return h > 0.f ? 0.f : h + 1.f; }
 __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : expm1f(z); }
 
+// number of levels L + 1: from the plan's device-side header when the plan was built without a host read
+// (meta[0] = deepest level), else from the caller's L
+__device__ __forceinline__ int level_count(int L, const int* __restrict__ meta) { return (meta ? meta[0] : L) + 1; }
+
 __device__ __forceinline__ float halfwave_sum(float v) {
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, 32);
@@ -56,12 +60,12 @@ __device__ __forceinline__ float4 readout_pull(int i, int lvl, float wi, float i
 }
 
 // d_h[i,c] = w[i] g[c] + [argmax[level(i),c] == i] g[128+c] / (L+1)
-__global__ __launch_bounds__(THREADS) void k_pool_bwd(int n, int L, const float* __restrict__ g,
+__global__ __launch_bounds__(THREADS) void k_pool_bwd(int n, int L, const int* __restrict__ meta, const float* __restrict__ g,
                                                       const int* __restrict__ node_level, const float* __restrict__ w,
                                                       const int* __restrict__ argmax, float* __restrict__ d_h) {
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const float4 g_mean = reinterpret_cast<const float4*>(g)[l], g_max = reinterpret_cast<const float4*>(g + H)[l];
-    const float inv_levels = 1.f / (float)(L + 1);
+    const float inv_levels = 1.f / (float)(level_count(L, meta));
     const int4* argmax4 = reinterpret_cast<const int4*>(argmax);
     const Rows r = block_rows(n);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK)
@@ -82,13 +86,14 @@ __device__ __forceinline__ void block_colsum(float (*red)[WIDTH], float* __restr
 }
 
 // adjoint of k_pool_bwd: out[c] = sum_i w[i] gg[i,c], out[128+c] = sum_i [argmax == i] gg[i,c] / (L+1)
-__global__ __launch_bounds__(THREADS) void k_pool_bwd_adj(int n, int L, const float* __restrict__ gg,
+__global__ __launch_bounds__(THREADS) void k_pool_bwd_adj(int n, int L, const int* __restrict__ meta,
+                                                          const float* __restrict__ gg,
                                                           const int* __restrict__ node_level,
                                                           const float* __restrict__ w, const int* __restrict__ argmax,
                                                           float* __restrict__ partial /*[grid][256]*/) {
     __shared__ float red[HW_PER_BLOCK][2 * H];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
-    const float inv_levels = 1.f / (float)(L + 1);
+    const float inv_levels = 1.f / (float)(level_count(L, meta));
     const int4* argmax4 = reinterpret_cast<const int4*>(argmax);
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sx = sm;
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -150,13 +155,13 @@ __global__ __launch_bounds__(THREADS) void k_gp_enc(int n, const float* __restri
 }
 
 // g_z2 = (P^T g_r) * elu'(z2)
-__global__ __launch_bounds__(THREADS) void k_gp_gz2(int n, int L, const float* __restrict__ g_r,
+__global__ __launch_bounds__(THREADS) void k_gp_gz2(int n, int L, const int* __restrict__ meta, const float* __restrict__ g_r,
                                                     const int* __restrict__ node_level, const float* __restrict__ w,
                                                     const int* __restrict__ argmax, const float* __restrict__ h2,
                                                     float* __restrict__ g_z2) {
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const float4 g_mean = reinterpret_cast<const float4*>(g_r)[l], g_max = reinterpret_cast<const float4*>(g_r + H)[l];
-    const float inv_levels = 1.f / (float)(L + 1);
+    const float inv_levels = 1.f / (float)(level_count(L, meta));
     const int4* argmax4 = reinterpret_cast<const int4*>(argmax);
     const Rows r = block_rows(n);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
@@ -234,7 +239,8 @@ __global__ __launch_bounds__(THREADS) void k_gp_back1(int n, const float* __rest
 
 // ubar_gh2 = ubar_gz2 * elu'(z2);  dz2 = ubar_gz2 * g_h2 * elu''(z2)  (g_h2 = P^T g_r, recomputed);
 // block partials of [ colsum(dz2) | sum_i w_i ubar_gh2 | sum_i [argmax == i] ubar_gh2 / (L+1) ]
-__global__ __launch_bounds__(THREADS) void k_gp_back2(int n, int L, const float* __restrict__ ubar_gz2,
+__global__ __launch_bounds__(THREADS) void k_gp_back2(int n, int L, const int* __restrict__ meta,
+                                                      const float* __restrict__ ubar_gz2,
                                                       const float* __restrict__ h2, const float* __restrict__ g_r,
                                                       const int* __restrict__ node_level, const float* __restrict__ w,
                                                       const int* __restrict__ argmax, float* __restrict__ dz2,
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_back2(int n, int L, const float*
     __shared__ float red[HW_PER_BLOCK][3 * H];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const float4 g_mean = reinterpret_cast<const float4*>(g_r)[l], g_max = reinterpret_cast<const float4*>(g_r + H)[l];
-    const float inv_levels = 1.f / (float)(L + 1);
+    const float inv_levels = 1.f / (float)(level_count(L, meta));
     const int4* argmax4 = reinterpret_cast<const int4*>(argmax);
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sb = zero, sm = zero, sx = zero;
@@ -306,13 +312,13 @@ int gp_blocks(int64_t n) {
 using namespace aig;
 
 // --------------------------------------------------------------------------------------------- readout backward
-extern "C" int aig_level_pool_bwd(int64_t n, int64_t L, const float* g, const int32_t* node_level, const float* w,
-                                  const int32_t* argmax, float* d_h, void* stream) {
+extern "C" int aig_level_pool_bwd(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g, const int32_t* node_level,
+                                  const float* w, const int32_t* argmax, float* d_h, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && L < INT_MAX, "aig_level_pool_bwd: bad sizes");
     if (n == 0) return AIG_OK;
     AIG_REQUIRE(g && node_level && w && argmax && d_h, "aig_level_pool_bwd: null pointer");
     hipLaunchKernelGGL(k_pool_bwd, dim3(gp_blocks(n)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), (int)n, (int)L,
-                       g, node_level, w, argmax, d_h);
+                       lvl_meta, g, node_level, w, argmax, d_h);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -322,8 +328,9 @@ extern "C" size_t aig_level_pool_bwd_adj_ws_bytes(int64_t n) {
     return align_up((size_t)GP_BLOCKS_MAX * 2 * H * 4) + 256;
 }
 
-extern "C" int aig_level_pool_bwd_adj(int64_t n, int64_t L, const float* gg, const int32_t* node_level, const float* w,
-                                      const int32_t* argmax, float* out, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_meta, const float* gg,
+                                      const int32_t* node_level, const float* w, const int32_t* argmax, float* out,
+                                      void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && L < INT_MAX, "aig_level_pool_bwd_adj: bad sizes");
     AIG_REQUIRE(out, "aig_level_pool_bwd_adj: null output");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -335,7 +342,8 @@ extern "C" int aig_level_pool_bwd_adj(int64_t n, int64_t L, const float* gg, con
     if (ws_bytes < aig_level_pool_bwd_adj_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_level_pool_bwd_adj: workspace too small");
     float* partial = static_cast<float*>(ws);
     const int g = gp_blocks(n);
-    hipLaunchKernelGGL(k_pool_bwd_adj, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, gg, node_level, w, argmax, partial);
+    hipLaunchKernelGGL(k_pool_bwd_adj, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, lvl_meta, gg, node_level, w, argmax,
+                       partial);
     hipLaunchKernelGGL(k_sum_cols, dim3(2 * H), dim3(256), 0, s, g, 2 * H, partial, out);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -358,8 +366,8 @@ extern "C" size_t aig_gp_input_grad_ws_bytes(int64_t n) {
     return align_up((size_t)GP_BLOCKS_MAX * 4) + 256;
 }
 
-extern "C" int aig_gp_input_grad(int64_t n, int64_t L, const float* g_r, const int32_t* node_level, const float* w,
-                                 const int32_t* argmax, const float* W1, const float* W2, const float* h1,
+extern "C" int aig_gp_input_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                                 const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1,
                                  const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
                                  void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX && L >= 0 && L < INT_MAX, "aig_gp_input_grad: bad sizes");
@@ -368,7 +376,8 @@ extern "C" int aig_gp_input_grad(int64_t n, int64_t L, const float* g_r, const i
     if (ws_bytes < aig_gp_input_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_input_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int g = gp_blocks(n);
-    hipLaunchKernelGGL(k_gp_gz2, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, g_r, node_level, w, argmax, h2, g_z2);
+    hipLaunchKernelGGL(k_gp_gz2, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, lvl_meta, g_r, node_level, w, argmax, h2,
+                       g_z2);
     AIG_LAUNCH_CHECK();
     int rc = aig_linear128(n, g_z2, W2, 1, nullptr, 0, g_h1, stream);
     if (rc) return rc;
@@ -386,8 +395,8 @@ extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
            align_up((size_t)H * H * 4) + align_up(wg > wg2 ? wg : wg2) + 1024;
 }
 
-extern "C" int aig_gp_param_grad(int64_t n, int64_t L, const float* coef, const float* g_r, const int32_t* node_level,
-                                 const float* w, const int32_t* argmax, const float* W1, const float* W2,
+extern "C" int aig_gp_param_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* coef, const float* g_r,
+                                 const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2,
                                  const float* xhat, const float* h1, const float* h2, const float* g_z2,
                                  const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1,
                                  float* dW2, float* db2, float* ubar_gr, void* ws, size_t ws_bytes, void* stream) {
@@ -415,8 +424,8 @@ extern "C" int aig_gp_param_grad(int64_t n, int64_t L, const float* coef, const 
     hipLaunchKernelGGL(k_gp_back1, dim3(g), dim3(THREADS), 0, s, (int)n, coef, g_x, W1, h1, g_h1, u, ubar_gh1, dz1);
     AIG_LAUNCH_CHECK();
     if ((rc = aig_linear128(n, ubar_gh1, W2, 0, nullptr, 0, ubar_gz2, stream))) return rc;
-    hipLaunchKernelGGL(k_gp_back2, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, ubar_gz2, h2, g_r, node_level, w, argmax,
-                       dz2, partial);
+    hipLaunchKernelGGL(k_gp_back2, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, lvl_meta, ubar_gz2, h2, g_r, node_level, w,
+                       argmax, dz2, partial);
     // columns 0..127 -> db2, 128..383 -> ubar_gr
     hipLaunchKernelGGL(k_sum_cols, dim3(H), dim3(256), 0, s, g, 3 * H, partial, db2);
     hipLaunchKernelGGL(k_sum_cols, dim3(2 * H), dim3(256), 0, s, g, 3 * H, partial + H, ubar_gr);

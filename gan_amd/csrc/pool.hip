@@ -23,15 +23,56 @@ constexpr int THREADS = 256;
 constexpr int HW_PER_BLOCK = THREADS / 32;
 constexpr int ROWS_PER_HW = 32;  // sorted rows walked by one half-wave
 
-__global__ void k_level_keys(int n, int L, const long long* __restrict__ depth, unsigned* __restrict__ key,
-                             int* __restrict__ ids) {
+// Plan header, four int32 in device memory, for a plan built without a host read of the depth vector
+// (aig_level_plan_dyn): {deepest level L, nodes with a level, flags, 0}; flag bit 0 = no node carries a valid
+// depth (every node is then pooled in level 0, discriminator.py:68-72), bit 1 = a depth exceeded the caller's cap.
+constexpr int META_L = 0, META_NVALID = 1, META_FLAGS = 2;
+
+__global__ void k_level_keys(int n, int L, const int* __restrict__ meta, const long long* __restrict__ depth,
+                             unsigned* __restrict__ key, int* __restrict__ ids) {
+    // with a header, L is the capacity: ignored nodes sort behind every level the cap allows
+    const unsigned ignored = (unsigned)(L + 1);
+    const bool flat = meta && (meta[META_FLAGS] & 1);
+    if (meta) L = meta[META_L];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        long long d = depth ? depth[i] : 0;
-        key[i] = (d >= 0 && d <= L) ? (unsigned)d : (unsigned)(L + 1);  // negative depth = ignored node
+        long long d = (depth && !flat) ? depth[i] : 0;
+        key[i] = (d >= 0 && d <= L) ? (unsigned)d : ignored;  // negative depth = ignored node
         ids[i] = i;
     }
 }
 
+// deepest level and number of nodes with a level, by integer atomics into the zeroed header (meta[0] starts at -1)
+__global__ void k_level_scan(int n, int L_cap, const long long* __restrict__ depth, int* __restrict__ meta) {
+    int top = -1, cnt = 0, over = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const long long d = depth[i];
+        if (d >= 0) {
+            if (d > L_cap) { over = 1; continue; }
+            top = max(top, (int)d);
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        top = max(top, __shfl_xor(top, off));
+        cnt += __shfl_xor(cnt, off);
+        over |= __shfl_xor(over, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (top >= 0) atomicMax(meta + META_L, top);
+        if (cnt) atomicAdd(meta + META_NVALID, cnt);
+        if (over) atomicOr(meta + META_FLAGS, 2);
+    }
+}
+__global__ void k_level_meta_finish(int n, int* __restrict__ meta) {
+    if (meta[META_L] < 0) {  // no valid depth at all: one level holding every node
+        meta[META_L] = 0;
+        meta[META_NVALID] = n;
+        meta[META_FLAGS] |= 1;
+    }
+}
+
+// (L is the capacity when the plan has a header: the entries past the deepest level all equal the valid count)
 __global__ void k_level_ptr(int n, int L, const unsigned* __restrict__ skey, int* __restrict__ lvl_ptr) {
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= L + 1; v += gridDim.x * blockDim.x) {
         int lo = 0, hi = n;
@@ -44,9 +85,10 @@ __global__ void k_level_ptr(int n, int L, const unsigned* __restrict__ skey, int
 }
 
 // node_level[i] (or -1) and w[i]
-__global__ void k_level_weights(int n, int L, const unsigned* __restrict__ skey, const int* __restrict__ perm,
-                                const int* __restrict__ lvl_ptr, int* __restrict__ node_level,
-                                float* __restrict__ w) {
+__global__ void k_level_weights(int n, int L, const int* __restrict__ meta, const unsigned* __restrict__ skey,
+                                const int* __restrict__ perm, const int* __restrict__ lvl_ptr,
+                                int* __restrict__ node_level, float* __restrict__ w) {
+    if (meta) L = meta[META_L];
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         unsigned l = skey[p];
         int i = perm[p];
@@ -71,7 +113,8 @@ __device__ __forceinline__ float unpack_val(unsigned long long p) {
     return __uint_as_float(b);
 }
 
-__global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* __restrict__ h,
+__global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const int* __restrict__ meta,
+                                                       const float* __restrict__ h,
                                                        const int* __restrict__ perm,
                                                        const int* __restrict__ node_level,
                                                        const float* __restrict__ w,
@@ -80,6 +123,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* 
     __shared__ float red[HW_PER_BLOCK][H];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int item = blockIdx.x * HW_PER_BLOCK + hw;
+    if (meta) nvalid = meta[META_NVALID];   // the grid covers every node; half-waves past the valid rows add nothing
     const int p0 = item * ROWS_PER_HW, p1 = min(nvalid, p0 + ROWS_PER_HW);
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,12 +216,14 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const float* 
 // One block per feature f: out[f] = sum of the walk's partials, out[H+f] = 1/(L+1) * sum over
 // non-empty levels of the level maximum (strided partial sums, then a fixed-shape tree: reproducible);
 // argmax[l*H + f] = node holding that maximum (-1 for an empty level).
-__global__ __launch_bounds__(256) void k_pool_finish(int nb, int L, const float* __restrict__ partial,
+__global__ __launch_bounds__(256) void k_pool_finish(int nb, int L, const int* __restrict__ meta,
+                                                     const float* __restrict__ partial,
                                                      const unsigned long long* __restrict__ table,
                                                      const int* __restrict__ lvl_ptr, float* __restrict__ out,
                                                      int* __restrict__ argmax) {
     __shared__ float red_s[256], red_m[256];
     const int f = blockIdx.x, t = threadIdx.x;
+    if (meta) L = meta[META_L];
     float s = 0.f, m = 0.f;
     for (int b = t; b < nb; b += 256) s += partial[(size_t)b * H + f];
     for (int l = t; l <= L; l += 256) {
@@ -222,12 +268,24 @@ extern "C" size_t aig_level_plan_ws_bytes(int64_t n, int64_t L) {
     return 3 * align_up((size_t)n * 4) + align_up(sort_temp_bytes(n, key_bits(L + 1))) + 256;
 }
 
-extern "C" int aig_level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
-                              int32_t* node_level, float* w, void* ws, size_t ws_bytes, void* stream) {
+namespace {
+int level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr, int32_t* node_level,
+               float* w, int32_t* meta, bool dyn, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && L < INT_MAX - 2, "aig_level_plan: bad sizes n=%lld L=%lld",
                 (long long)n, (long long)L);
-    AIG_REQUIRE(lvl_ptr, "aig_level_plan: null lvl_ptr");
+    AIG_REQUIRE(lvl_ptr && (!dyn || meta), "aig_level_plan: null lvl_ptr or header");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dyn) {
+        AIG_HIP_CHECK(hipMemsetAsync(meta, 0, 16, s));
+        AIG_HIP_CHECK(hipMemsetAsync(meta, 0xFF, 4, s));   // meta[0] = -1
+        if (depth && n > 0) {
+            hipLaunchKernelGGL(k_level_scan, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, (int)n, (int)L,
+                               reinterpret_cast<const long long*>(depth), meta);
+            AIG_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_level_meta_finish, dim3(1), dim3(1), 0, s, (int)n, meta);
+        AIG_LAUNCH_CHECK();
+    }
     if (n == 0) {
         AIG_HIP_CHECK(hipMemsetAsync(lvl_ptr, 0, (size_t)(L + 2) * 4, s));
         return AIG_OK;
@@ -243,14 +301,27 @@ extern "C" int aig_level_plan(int64_t n, int64_t L, const int64_t* depth, int32_
     size_t tb = sort_temp_bytes(n, bits);
     void* temp = c.take<char>(tb);
     const int g = grid_for(n, 256, 4096);
-    hipLaunchKernelGGL(k_level_keys, dim3(g), dim3(256), 0, s, (int)n, (int)L, reinterpret_cast<const long long*>(depth),
-                       key, ids);
+    hipLaunchKernelGGL(k_level_keys, dim3(g), dim3(256), 0, s, (int)n, (int)L, (const int*)meta,
+                       reinterpret_cast<const long long*>(depth), key, ids);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, perm, (size_t)n, 0, bits, s));
     hipLaunchKernelGGL(k_level_ptr, dim3(grid_for(L + 2, 256, 4096)), dim3(256), 0, s, (int)n, (int)L, skey, lvl_ptr);
-    hipLaunchKernelGGL(k_level_weights, dim3(g), dim3(256), 0, s, (int)n, (int)L, skey, perm, lvl_ptr, node_level, w);
+    hipLaunchKernelGGL(k_level_weights, dim3(g), dim3(256), 0, s, (int)n, (int)L, (const int*)meta, skey, perm, lvl_ptr,
+                       node_level, w);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+}  // namespace
+
+extern "C" int aig_level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
+                              int32_t* node_level, float* w, void* ws, size_t ws_bytes, void* stream) {
+    return level_plan(n, L, depth, perm, lvl_ptr, node_level, w, nullptr, false, ws, ws_bytes, stream);
+}
+
+extern "C" int aig_level_plan_dyn(int64_t n, int64_t L_cap, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
+                                  int32_t* node_level, float* w, int32_t* lvl_meta, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    return level_plan(n, L_cap, depth, perm, lvl_ptr, node_level, w, lvl_meta, true, ws, ws_bytes, stream);
 }
 
 extern "C" size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L) {
@@ -259,9 +330,10 @@ extern "C" size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L) {
     return align_up((size_t)(L + 1) * H * 8) + align_up(blocks * H * 4) + 256;
 }
 
-extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const float* h, const int32_t* perm,
-                                  const int32_t* lvl_ptr, const int32_t* node_level, const float* w, float* out,
-                                  int32_t* argmax, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                                  const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level,
+                                  const float* w, float* out, int32_t* argmax, void* ws, size_t ws_bytes,
+                                  void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && nvalid >= 0 && nvalid <= n, "aig_level_pool_fwd: bad sizes");
     AIG_REQUIRE(out && argmax && lvl_ptr && ws, "aig_level_pool_fwd: null pointer");
     if (ws_bytes < aig_level_pool_fwd_ws_bytes(n, L))
@@ -278,11 +350,12 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const fl
         int64_t items = (nvalid + ROWS_PER_HW - 1) / ROWS_PER_HW;
         blocks = (int)((items + HW_PER_BLOCK - 1) / HW_PER_BLOCK);
         partial = c.take<float>((size_t)blocks * H);
-        hipLaunchKernelGGL(k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, h, perm, node_level, w, table,
-                           partial);
+        hipLaunchKernelGGL(k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, lvl_meta, h, perm, node_level, w,
+                           table, partial);
         AIG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_pool_finish, dim3(H), dim3(256), 0, s, blocks, (int)L, partial, table, lvl_ptr, out, argmax);
+    hipLaunchKernelGGL(k_pool_finish, dim3(H), dim3(256), 0, s, blocks, (int)L, lvl_meta, partial, table, lvl_ptr, out,
+                       argmax);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -195,6 +195,12 @@ class GraphLoader:
         if seed is None:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
         self._gen.manual_seed(seed)
+        # deepest level per graph, from the host-side data: consumers that size device structures by it
+        # (gan_amd.train.depth_top) then need no host read of a batch that already lives on the GPU
+        self.depth_tops = []
+        for d in self.data_list:
+            nd = getattr(d, "node_depth", None)
+            self.depth_tops.append(-1 if nd is None or nd.numel() == 0 else int(nd.max().item()))
 
     def _batches(self) -> List[List[int]]:
         n = len(self.data_list)
@@ -213,4 +219,5 @@ class GraphLoader:
         for idxs in self._batches():
             b = Batch.from_data_list([self.data_list[i] for i in idxs])
             b.sample_ids = list(idxs)
+            b._depth_top = max(self.depth_tops[i] for i in idxs)
             yield b

@@ -7,23 +7,30 @@ Drop-in for ``models.discriminator.AIGDiscriminator`` of the reference
 (ONE score per call, also for a ``Batch`` of several graphs: all of them are pooled by level
 together, discriminator.py:89-100).
 
-Where the work runs:
-* dense projections ``x W^T`` and the 256-128-64-1 head: torch (rocBLAS), with autograd;
-* attention logits, per-target softmax, neighbour aggregation, bias and ELU: one fused HIP
-  kernel over a by-target CSR (``aig_gat_fwd``), backward in ``aig_gat_bwd``;
-* level-wise mean/max readout: one HIP pass (``aig_level_pool_fwd``); its backward is a weighted
-  broadcast plus a scatter expressed in torch ops so that it can be differentiated again;
-* a graph without edges (the gradient-penalty interpolate of train.py:141-152) needs no kernel
-  in the attention layers: softmax over the lone self loop is exactly 1, so a layer is
-  ``elu(x W^T + bias)`` and the whole pass supports double backward.
+Where the work runs (every item is a kernel of libaig_hip.so; torch supplies memory, streams, autograd
+bookkeeping and the optimiser):
+* dense projections ``x W^T`` (``aig_linear_in2`` for the two input features, ``aig_linear128`` on the f32
+  matrix cores for the second layer), their input gradients and weight gradients (``aig_wgrad``);
+* attention logits, per-target softmax, neighbour aggregation, bias and ELU: one fused kernel over a
+  by-target CSR (``aig_gat_fwd``), backward in ``aig_gat_bwd``;
+* level-wise mean/max readout: one pass (``aig_level_pool_fwd``); its backward (``aig_level_pool_bwd``) is
+  linear in the incoming gradient and has its own adjoint kernel, so it can be differentiated again;
+* the 256-128-64-1 head: one launch forward, one backward (``aig_head_fwd`` / ``aig_head_bwd``); torch modules
+  only where the autograd form of the gradient penalty differentiates the head twice;
+* a graph without edges (the gradient-penalty interpolate of train.py:141-152) needs no attention kernel:
+  softmax over the lone self loop is exactly 1, so a layer is ``elu(x W^T + bias)``; the penalty and its
+  parameter gradient have a closed form (``gradient_penalty_closed_form``).
+
+Graph structure (by-target CSR, level plan) is either derived from the tensors of a call and cached, or - for
+inputs that live in fixed buffers and are refilled every step - held in ``GraphCSR`` / ``DynLevelPlan`` objects
+the caller rebuilds in place (``data._csr`` / ``data._plan``), which is what lets a whole critic term be recorded
+once per tensor SHAPE as a HIP graph and replayed on every minibatch of that shape.
 """
 from __future__ import annotations
 
 import math
 from collections import OrderedDict
 from typing import Optional
-
-import os
 
 import torch
 import torch.nn as nn
@@ -37,10 +44,12 @@ HIDDEN = 128
 
 
 class GraphCSR:
-    """By-target and by-source edge lists of one (batched) graph, built on the GPU once."""
+    """By-target and by-source edge lists of one (batched) graph, built on the GPU.  ``E`` counts the columns
+    handed in; columns with an endpoint outside ``[0, n)`` (the ``-1`` padding of train.py:108-123) and self
+    loops are dropped by the builder, so a padded edge list needs no host-side filtering.  ``rebuild`` fills
+    the same buffers from a new edge list of the same width."""
 
     def __init__(self, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], n: int):
-        lib = _abi.lib()
         dev = edge_index.device
         E = int(edge_index.size(1))
         self.n, self.E = int(n), E
@@ -55,6 +64,13 @@ class GraphCSR:
         self.hub_tab = torch.empty((E // 33 + 2, 4), **i32)   # nodes with more than 32 out-edges, see aig_abi.h
         self.csr_ea = torch.empty(max(E, 1), **f32)
         self.loop_ea = torch.empty(max(n, 1), **f32)
+        self.rebuild(edge_index, edge_attr)
+
+    def rebuild(self, edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor]) -> None:
+        lib = _abi.lib()
+        n, E, dev = self.n, self.E, edge_index.device
+        if int(edge_index.size(1)) != E:
+            raise _abi.AigAbiError(f"GraphCSR.rebuild: {int(edge_index.size(1))} edge columns, built for {E}")
         ei = edge_index.contiguous()
         ea = None if edge_attr is None else edge_attr.reshape(-1).float().contiguous()
         ws = _abi.workspace(lib.aig_gat_csr_ws_bytes(n, E), dev)
@@ -95,6 +111,37 @@ class LevelPlan:
                                       _abi.stream()), "aig_level_plan")
         # lvl_ptr[L + 1] = nodes in levels 0..L; without a depth vector every node sits in level 0
         self.nvalid = (nvalid if nvalid is not None else n) if n > 0 else 0
+        self.meta = None      # L and nvalid are host values (see DynLevelPlan for the other case)
+
+
+class DynLevelPlan:
+    """The same plan for a depth vector that lives in a fixed buffer and changes between uses: the deepest
+    level is found on the device and kept in a small header (``meta``) that the readout kernels read, so
+    neither building nor using the plan needs a host read, and the launches have the same shapes for every
+    depth vector with ``n`` entries and levels up to ``level_cap``.  ``L`` / ``nvalid`` hold the capacities."""
+
+    def __init__(self, n: int, level_cap: int, device):
+        self.n, self.L, self.nvalid = int(n), int(level_cap), int(n)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.perm = torch.empty(max(n, 1), **i32)
+        self.node_level = torch.empty(max(n, 1), **i32)
+        self.lvl_ptr = torch.empty(self.L + 2, **i32)
+        self.w = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+        self.meta = torch.zeros(4, **i32)
+
+    def rebuild(self, node_depth: torch.Tensor) -> None:
+        """Enqueue the plan of ``node_depth`` (int64 ``[n]``, negative = ignored node) on the current stream."""
+        lib = _abi.lib()
+        if node_depth.dtype != torch.int64 or int(node_depth.numel()) != self.n or not node_depth.is_contiguous():
+            raise _abi.AigAbiError("DynLevelPlan.rebuild takes a contiguous int64 depth vector of the planned length")
+        ws = _abi.workspace(lib.aig_level_plan_ws_bytes(self.n, self.L), node_depth.device)
+        _abi.check(lib.aig_level_plan_dyn(self.n, self.L, _abi.ptr(node_depth), _abi.ptr(self.perm), _abi.ptr(self.lvl_ptr),
+                                          _abi.ptr(self.node_level), _abi.ptr(self.w), _abi.ptr(self.meta),
+                                          _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_level_plan_dyn")
+
+    def overflowed(self) -> bool:
+        """True when a depth of the last rebuild exceeded ``level_cap`` (one host read; a debugging aid)."""
+        return bool(int(self.meta[2].item()) & 2)
 
 
 class _GATAggregate(torch.autograd.Function):
@@ -190,16 +237,13 @@ def _linear_in2(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return y
 
 
-_USE_LINEAR128 = os.environ.get("AIG_NO_LINEAR128", "") == ""
-
-
 def _is_in2(x: torch.Tensor, w: torch.Tensor) -> bool:
-    return (_USE_LINEAR128 and x.dim() == 2 and x.size(1) == 2 and tuple(w.shape) == (HIDDEN, 2)
+    return (x.dim() == 2 and x.size(1) == 2 and tuple(w.shape) == (HIDDEN, 2)
             and x.dtype == torch.float32 and x.is_cuda)
 
 
 def _is128(x: torch.Tensor, w: torch.Tensor) -> bool:
-    return _USE_LINEAR128 and x.dim() == 2 and x.size(1) == HIDDEN and tuple(w.shape) == (HIDDEN, HIDDEN) and x.dtype == torch.float32
+    return x.dim() == 2 and x.size(1) == HIDDEN and tuple(w.shape) == (HIDDEN, HIDDEN) and x.dtype == torch.float32
 
 
 def _matmul_wt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -259,7 +303,7 @@ class _LevelPool(torch.autograd.Function):
         out = torch.empty((1, 2 * HIDDEN), dtype=torch.float32, device=dev)
         argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
         ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), dev)
-        _abi.check(_abi.timed("aig_level_pool_fwd", lib.aig_level_pool_fwd, plan.n, plan.nvalid, plan.L, _abi.ptr(h), _abi.ptr(plan.perm),
+        _abi.check(_abi.timed("aig_level_pool_fwd", lib.aig_level_pool_fwd, plan.n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h), _abi.ptr(plan.perm),
                                           _abi.ptr(plan.lvl_ptr), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
                                           _abi.ptr(out), _abi.ptr(argmax), _abi.ptr(ws), ws.numel(), _abi.stream()),
                    "aig_level_pool_fwd")
@@ -282,7 +326,7 @@ class _LevelPoolBwd(torch.autograd.Function):
     def forward(ctx, g, plan: LevelPlan, argmax, n: int):
         g = g.contiguous()
         d_h = torch.empty((n, HIDDEN), dtype=torch.float32, device=g.device)
-        _abi.check(_abi.lib().aig_level_pool_bwd(n, plan.L, _abi.ptr(g), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+        _abi.check(_abi.lib().aig_level_pool_bwd(n, plan.L, _abi.ptr(plan.meta), _abi.ptr(g), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
                                                  _abi.ptr(argmax), _abi.ptr(d_h), _abi.stream()), "aig_level_pool_bwd")
         ctx.plan, ctx.n = plan, n
         ctx.save_for_backward(argmax)
@@ -296,7 +340,7 @@ class _LevelPoolBwd(torch.autograd.Function):
         gg = gg.contiguous()
         out = torch.empty((1, 2 * HIDDEN), dtype=torch.float32, device=gg.device)
         ws = _abi.workspace(lib.aig_level_pool_bwd_adj_ws_bytes(n), gg.device)
-        _abi.check(lib.aig_level_pool_bwd_adj(n, plan.L, _abi.ptr(gg), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+        _abi.check(lib.aig_level_pool_bwd_adj(n, plan.L, _abi.ptr(plan.meta), _abi.ptr(gg), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
                                               _abi.ptr(argmax), _abi.ptr(out), _abi.ptr(ws), ws.numel(), _abi.stream()),
                    "aig_level_pool_bwd_adj")
         return out, None, None, None
@@ -427,13 +471,14 @@ class AIGDiscriminator(nn.Module):
         return self._lvl_cache.lookup(key, lambda: (LevelPlan(node_depth, n, device), node_depth))[0]
 
     def gradient_penalty_closed_form(self, x_real: torch.Tensor, x_fake: torch.Tensor, alpha: torch.Tensor,
-                                     node_depth: Optional[torch.Tensor]):
+                                     node_depth: Optional[torch.Tensor], plan=None):
         """``gradient_penalty(use_edges=False)`` of train.py:133-152 and its gradient w.r.t. the critic's
         parameters without autograd on the node tensors: on an empty edge list each attention layer
         is ``elu(x W^T + b)``, which makes the penalty a closed form (four [n,128]x[128,128]
         products, three node-dimension weight gradients, a few row-wise passes; the head's input
         gradient and its second-order share come from the head kernels).  Returns ``(gp, grad_norm, grads)`` with ``grads`` a dict
-        parameter -> gradient of ``gp`` (parameters the edge-free pass never touches are absent)."""
+        parameter -> gradient of ``gp`` (parameters the edge-free pass never touches are absent).  ``plan``: a
+        level plan of ``node_depth`` the caller already holds (else it is looked up / built here)."""
         lib = _abi.lib()
         dev = x_real.device
         n = int(x_real.size(0))
@@ -444,7 +489,8 @@ class AIGDiscriminator(nn.Module):
         W2, b2 = self.gat2.lin.weight.detach().contiguous(), self.gat2.bias.detach().contiguous()
         if tuple(W1.shape) != (HIDDEN, 2):
             raise NotImplementedError("closed-form gradient penalty is built for in_dim=2")
-        plan = self.level_plan(node_depth, n, dev)
+        if plan is None:
+            plan = self.level_plan(node_depth, n, dev)
         st = _abi.stream()
         xhat = torch.empty((n, 2), **f32)
         h1, h2 = torch.empty((n, HIDDEN), **f32), torch.empty((n, HIDDEN), **f32)
@@ -454,7 +500,7 @@ class AIGDiscriminator(nn.Module):
         r = torch.empty((1, 2 * HIDDEN), **f32)
         argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
         ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(n, plan.L), dev)
-        _abi.check(lib.aig_level_pool_fwd(n, plan.nvalid, plan.L, _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
+        _abi.check(lib.aig_level_pool_fwd(n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
                                           _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(r), _abi.ptr(argmax),
                                           _abi.ptr(ws), ws.numel(), st), "aig_level_pool_fwd")
         # head: s = out(mlp(r)), g_r = ds/dr (the backward kernel of the head with ds = 1)
@@ -471,18 +517,20 @@ class AIGDiscriminator(nn.Module):
         g_z2, g_h1, g_z1 = (torch.empty((n, HIDDEN), **f32) for _ in range(3))
         g_x, norm_sq = torch.empty((n, 2), **f32), torch.empty(1, **f32)
         ws = _abi.workspace(lib.aig_gp_input_grad_ws_bytes(n), dev)
-        _abi.check(lib.aig_gp_input_grad(n, plan.L, _abi.ptr(g_r_c), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+        _abi.check(lib.aig_gp_input_grad(n, plan.L, _abi.ptr(plan.meta), _abi.ptr(g_r_c), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
                                          _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(h1), _abi.ptr(h2),
                                          _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(norm_sq),
                                          _abi.ptr(ws), ws.numel(), st), "aig_gp_input_grad")
         norm = torch.sqrt(norm_sq[0])
         gp = (norm - 1.0) ** 2
-        coef = (2.0 * (norm - 1.0) / norm).reshape(1).contiguous()
+        # d gp / d g_x = coef * g_x; at norm = 0 autograd's torch.norm has the zero subgradient (train.py:150), so
+        # the penalty's gradient vanishes there instead of becoming 0 * inf (decided on the device, no host read)
+        coef = torch.where(norm > 0, 2.0 * (norm - 1.0) / norm, torch.zeros_like(norm)).reshape(1).contiguous()
         dW1, db1 = torch.empty((HIDDEN, 2), **f32), torch.empty(HIDDEN, **f32)
         dW2, db2 = torch.empty((HIDDEN, HIDDEN), **f32), torch.empty(HIDDEN, **f32)
         u_gr = torch.empty((1, 2 * HIDDEN), **f32)
         ws = _abi.workspace(lib.aig_gp_param_grad_ws_bytes(n), dev)
-        _abi.check(lib.aig_gp_param_grad(n, plan.L, _abi.ptr(coef), _abi.ptr(g_r_c), _abi.ptr(plan.node_level),
+        _abi.check(lib.aig_gp_param_grad(n, plan.L, _abi.ptr(plan.meta), _abi.ptr(coef), _abi.ptr(g_r_c), _abi.ptr(plan.node_level),
                                          _abi.ptr(plan.w), _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(xhat),
                                          _abi.ptr(h1), _abi.ptr(h2), _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1),
                                          _abi.ptr(g_x), _abi.ptr(dW1), _abi.ptr(db1), _abi.ptr(dW2), _abi.ptr(db2),
@@ -497,8 +545,7 @@ class AIGDiscriminator(nn.Module):
         return gp.detach(), norm.detach(), grads
 
     def _head_is_fused(self, r: torch.Tensor) -> bool:
-        return (tuple(r.shape) == (1, 2 * HIDDEN) and r.dtype == torch.float32 and self.hidden_dim == HIDDEN and
-                os.environ.get("AIG_NO_FUSED_HEAD") != "1")
+        return tuple(r.shape) == (1, 2 * HIDDEN) and r.dtype == torch.float32 and self.hidden_dim == HIDDEN
 
     def forward(self, data: Data, twice_differentiable: bool = False) -> torch.Tensor:
         """The fused head kernel is differentiable once.  When the node features themselves require a
@@ -513,11 +560,20 @@ class AIGDiscriminator(nn.Module):
         edge_index = data.edge_index
         has_edges = edge_index is not None and edge_index.numel() > 0
         edge_attr = data.edge_attr if (hasattr(data, "edge_attr") and data.edge_attr is not None) else None
-        csr = self.graph_csr(edge_index, edge_attr, n) if has_edges else None
+        # a caller that keeps its inputs in fixed buffers hands over the structures it rebuilt in place
+        csr = data.__dict__.get("_csr") if hasattr(data, "__dict__") else None
+        if csr is None:
+            csr = self.graph_csr(edge_index, edge_attr, n) if has_edges else None
+        elif csr.n != n:
+            raise _abi.AigAbiError(f"data._csr was built for {csr.n} nodes, the graph has {n}")
         h = self.gat1(x, csr)
         h = self.gat2(h, csr)
         nd = data.node_depth if (hasattr(data, "node_depth") and data.node_depth is not None) else None
-        plan = self.level_plan(nd, n, x.device)
+        plan = data.__dict__.get("_plan") if hasattr(data, "__dict__") else None
+        if plan is None:
+            plan = self.level_plan(nd, n, x.device)
+        elif plan.n != n:
+            raise _abi.AigAbiError(f"data._plan was built for {plan.n} nodes, the graph has {n}")
         graph_repr = _LevelPool.apply(h, plan)           # [1, 2H]
         if not twice_differentiable and self._head_is_fused(graph_repr):
             return _CriticHead.apply(graph_repr, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,

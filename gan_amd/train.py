@@ -40,7 +40,7 @@ from .constraints import (aig_constraint_penalties, enforce_aig_constraints, enf
                           validate_strict_aig)
 from .data import Batch, Data, GraphLoader
 from .dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
-from .discriminator import AIGDiscriminator
+from .discriminator import AIGDiscriminator, DynLevelPlan, GraphCSR
 from .generator import AIGGenerator
 
 METRIC_FIELDS = ["step", "epoch", "D_real", "D_fake", "gap", "grad_norm", "loss_D", "loss_G", "gp", "pen"]
@@ -147,11 +147,12 @@ def mean_score(D, data: Data) -> torch.Tensor:
 
 
 def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool = True,
-                     alpha: Optional[torch.Tensor] = None):
+                     alpha: Optional[torch.Tensor] = None, plan=None):
     """Node-feature gradient penalty on an edge-free interpolate (train.py:141-152).
 
     Returns ``(gp, grad_norm)``.  Only the branch the reference's loop takes is provided
-    (``use_edges=False``, train.py:261); its edge-interpolating branch is never reached there."""
+    (``use_edges=False``, train.py:261); its edge-interpolating branch is never reached there.
+    ``plan``: a level plan of ``real_pad.node_depth`` the caller already holds."""
     if use_edges:
         raise NotImplementedError("only the node-only gradient penalty (use_edges=False) is implemented")
     if alpha is None:
@@ -159,6 +160,8 @@ def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool 
     x_inter = (alpha * real_pad.x + (1 - alpha) * fake_pad.x).requires_grad_(True)
     inter = Data(x=x_inter, edge_index=torch.zeros((2, 0), dtype=torch.long, device=device),
                  edge_attr=torch.zeros((0, 1), dtype=torch.float32, device=device), node_depth=real_pad.node_depth)
+    if plan is not None:
+        inter._plan = plan
     out = D(inter)
     grads = torch.autograd.grad(out.sum(), [x_inter], create_graph=True, retain_graph=True, only_inputs=True)
     grad_norm = torch.norm(grads[0].reshape(-1), p=2)
@@ -166,63 +169,132 @@ def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool 
     return gp, grad_norm.detach()
 
 
+def count_edges(edge_index: Optional[torch.Tensor]) -> torch.Tensor:
+    """Edge columns that are edges: no negative (padding) endpoint and no self loop (batching turns the ``-1``
+    padding of every graph but the first into self loops, see gan_amd/data.py).  A device scalar, no host read."""
+    if edge_index is None or edge_index.numel() == 0:
+        return torch.zeros((), dtype=torch.long, device=None if edge_index is None else edge_index.device)
+    return ((edge_index.min(dim=0).values >= 0) & (edge_index[0] != edge_index[1])).sum()
+
+
+def depth_top(batch: Data) -> int:
+    """Deepest level of a minibatch (-1 without one).  ``GraphLoader`` notes it on the batches it makes from its
+    host-side data; for any other batch it is read once (a host read when the batch is on the GPU) and kept on
+    the object."""
+    top = batch.__dict__.get("_depth_top")
+    if top is None:
+        nd = getattr(batch, "node_depth", None)
+        top = -1 if nd is None or nd.numel() == 0 else int(nd.max().item())
+        batch._depth_top = top
+    return top
+
+
 class CapturedCriticTerms:
     """``-mean(D(real))`` and ``gp_lambda * GP`` with their gradients w.r.t. the critic's parameters,
-    recorded once as two HIP graphs and replayed every critic iteration (two graphs, because the
-    real-side term does not depend on the fakes and can run while they are still being generated).
+    recorded ONCE PER MINIBATCH SHAPE as HIP graphs and replayed for every minibatch of that shape.
 
-    Both terms only see tensors of fixed shape and address (the real graph of a sample, the padded
-    node features of the fake, alpha, the parameters), and together they are about half of the
-    ~1300 kernel launches of a training step, which is bound by launch rate rather than by the
-    GPU.  ``loss_D`` is a sum, so its gradient is the replayed gradient plus the eagerly computed
-    gradient of ``mean(D(fake))`` - the same numbers as one backward pass up to the order of one
-    floating-point addition per parameter."""
+    Every minibatch of a run is padded to ``(max_nodes, max_edges)`` (train.py:200-204), so the real batch
+    always has the same tensor shapes.  Its tensors are copied into fixed buffers (``load``), and everything
+    that depends on their CONTENT is part of the recording: the by-target / by-source edge lists (the builder
+    drops the ``-1`` padding columns itself), the level plan (its level count lives in device memory, see
+    ``DynLevelPlan``), both critic evaluations and their backward passes.  Three graphs: ``prep`` (edge lists +
+    plan, once per step), the real-side term (does not depend on the fakes, so its first replay runs while they
+    are still being generated) and the penalty term.
 
-    def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], real_padded: Batch, real_for_D: Data,
+    Together the two terms are about half of the ~1300 kernel launches of a training step, which is bound by
+    launch rate rather than by the GPU.  ``loss_D`` is a sum, so its gradient is the replayed gradient plus the
+    eagerly computed gradient of ``mean(D(fake))`` - the same numbers as one backward pass up to the order of
+    one floating-point addition per parameter."""
+
+    def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], example: Batch, level_cap: int,
                  gp_lambda: float, device: torch.device, closed_form_gp: bool = True):
-        self.x_fake = torch.empty_like(real_padded.x, dtype=torch.float32)
-        self.x_fake.copy_(real_padded.x)
-        self.alpha = torch.full((1, 1), 0.5, device=device)
-        real_pad = Data(x=real_padded.x.float().clone(), node_depth=real_padded.node_depth)
+        n = int(example.x.size(0))
+        e_cols = 0 if example.edge_index is None else int(example.edge_index.size(1))
+        self.n, self.e_cols, self.level_cap = n, e_cols, int(level_cap)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_real = torch.zeros((n, 2), **f32)
+        self.ei = torch.full((2, e_cols), -1, dtype=torch.int64, device=device)
+        self.ea = torch.zeros((e_cols, 1), **f32)
+        self.depth = torch.full((n,), -1, dtype=torch.int64, device=device)
+        self.x_fake = torch.zeros((n, 2), **f32)
+        self.alpha = torch.full((1, 1), 0.5, **f32)
+        self.csr = GraphCSR(self.ei, self.ea, n) if e_cols > 0 else None
+        self.plan = DynLevelPlan(n, self.level_cap, device)
+        self.real_for_D = Data(x=self.x_real, edge_index=self.ei, edge_attr=self.ea, node_depth=self.depth)
+        self.real_for_D._csr, self.real_for_D._plan = self.csr, self.plan
+        real_pad = Data(x=self.x_real, node_depth=self.depth)
         fake_pad = Data(x=self.x_fake)
-        self._inputs = (real_pad, fake_pad, real_for_D)
+        self.captures = 0
+        self._copy_in(example)
+        self.x_fake.copy_(self.x_real)
+
+        def prep():
+            if self.csr is not None:
+                self.csr.rebuild(self.ei, self.ea)
+            self.plan.rebuild(self.depth)
+            return count_edges(self.ei)
 
         def compute_real():
-            d_real = mean_score(D, real_for_D)
+            d_real = mean_score(D, self.real_for_D)
             return d_real.detach(), torch.autograd.grad(-d_real, params, allow_unused=True)
 
         def compute_gp():
             if closed_form_gp:
-                gp, gn, gp_grads = D.gradient_penalty_closed_form(real_pad.x, fake_pad.x, self.alpha, real_pad.node_depth)
+                gp, gn, gp_grads = D.gradient_penalty_closed_form(self.x_real, self.x_fake, self.alpha, self.depth,
+                                                                  plan=self.plan)
                 scaled = dict(zip([p for p in params if p in gp_grads],
                                   torch._foreach_mul([gp_grads[p] for p in params if p in gp_grads], gp_lambda)))
                 return gp, gn, [scaled.get(p) for p in params]
-            gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha)
+            gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha, plan=self.plan)
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
         cur = torch.cuda.current_stream(device)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):      # builds the cached CSR / level plans, sizes the allocator
+        with torch.cuda.stream(side):      # sizes the allocator's pools before anything is recorded
             for _ in range(2):
+                prep()
                 compute_real()
                 compute_gp()
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
-        # the recorded kernels hold raw addresses of the cached plans: keep the plan objects alive
-        n = int(real_pad.x.size(0))
-        self._plans = (D.graph_csr(real_for_D.edge_index, real_for_D.edge_attr, n)
-                       if real_for_D.edge_index.numel() > 0 else None,
-                       D.level_plan(real_for_D.node_depth, n, device), D.level_plan(real_pad.node_depth, n, device))
-        self.graph_real, self.graph_gp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.graph_prep, self.graph_real, self.graph_gp = (torch.cuda.CUDAGraph() for _ in range(3))
         # thread-local capture: a communicator's watchdog thread may query events while we record
+        with torch.cuda.graph(self.graph_prep, capture_error_mode="thread_local"):
+            self.edges_real = prep()
         with torch.cuda.graph(self.graph_real, capture_error_mode="thread_local"):
             self.d_real, grads_real = compute_real()
         with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
             self.gp, self.grad_norm, grads_gp = compute_gp()
+        self.captures = 1
         self._adds = []   # (parameters, recorded gradients) per graph
         for grads in (grads_real, grads_gp):
             self._adds.append(([p for p, g in zip(params, grads) if g is not None], [g for g in grads if g is not None]))
+        self.graph_prep.replay()           # the recording itself executes nothing: build the example's structures
+
+    def fits(self, batch: Batch) -> bool:
+        e_cols = 0 if batch.edge_index is None else int(batch.edge_index.size(1))
+        return int(batch.x.size(0)) == self.n and e_cols == self.e_cols and depth_top(batch) <= self.level_cap
+
+    def _copy_in(self, batch: Batch) -> None:
+        self.x_real.copy_(batch.x)
+        if self.e_cols:
+            self.ei.copy_(batch.edge_index)
+            ea = getattr(batch, "edge_attr", None)
+            if ea is not None and ea.numel() == self.e_cols:
+                self.ea.copy_(ea.reshape(-1, 1))
+            else:
+                self.ea.zero_()
+        nd = getattr(batch, "node_depth", None)
+        if nd is not None:
+            self.depth.copy_(nd)
+        else:
+            self.depth.zero_()      # no depth vector: every node in one level (discriminator.py:92-96)
+
+    def load(self, batch: Batch) -> None:
+        """Make ``batch`` the real minibatch of the following replays: four copies and one graph launch."""
+        self._copy_in(batch)
+        self.graph_prep.replay()
 
     def replay_real(self) -> None:
         self.graph_real.replay()
@@ -253,20 +325,20 @@ class Trainer:
         parallel.broadcast_parameters([self.G, self.D])
         # the same update as train.py:221-222; on a HIP device the single-kernel ("fused") form of it, one
         # launch per step instead of a dozen multi-tensor launches
-        fused = {"fused": True} if device.type == "cuda" and os.environ.get("AIG_NO_FUSED_ADAM") is None else {}
+        fused = {"fused": True} if device.type == "cuda" else {}
         self.opt_G = torch.optim.Adam(self.G.parameters(), lr=args.lr, betas=(0.5, 0.9), **fused)
         self.opt_D = torch.optim.Adam(self.D.parameters(), lr=args.lr, betas=(0.5, 0.9), **fused)
         self.reducer = parallel.FlatGradAllReduce(self.D.parameters())
         self._d_params = [p for p in self.D.parameters() if p.requires_grad]
-        self._captured: "OrderedDict[tuple, CapturedCriticTerms]" = OrderedDict()
-        self._real_for_D: Dict[tuple, Data] = {}
+        self._captured: "OrderedDict[tuple, CapturedCriticTerms]" = OrderedDict()   # by minibatch shape
+        self.captures = 0     # recordings made so far (one per minibatch shape, unless a level cap was outgrown)
         self.graph_capture = bool(getattr(args, "graph_capture", True))
         self.closed_form_gp = bool(getattr(args, "closed_form_gp", True))
         self.global_step = 0
         self._templates: Dict[int, Data] = {}
         self.last: Dict[str, torch.Tensor] = {}
-        self._edges_last = None   # device scalar: edge columns of the last step's critic inputs
-        self._raw_depth: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+        self._edges_last = None   # device scalar: edges of the last step's critic inputs (real + fake)
+        self.level_cap = int(getattr(args, "level_cap", 0) or 0)   # deepest level the recordings are sized for
         # random draws of the loop (train.py:143,241,276); tests substitute recorded values
         self.draw_z = lambda: torch.randn(args.z_dim, device=device)
         self.draw_alpha = lambda: torch.rand(1, 1, device=device)
@@ -275,7 +347,7 @@ class Trainer:
         self.side_stream = torch.cuda.Stream(device=device)
         # ... and so do the critic's fakes (generator pass and repair), underneath the recorded
         # real-side term of the first critic iteration
-        self.overlap_fakes = not bool(getattr(args, "no_overlap", False)) and os.environ.get("AIG_NO_OVERLAP") != "1"
+        self.overlap_fakes = not bool(getattr(args, "no_overlap", False))
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
 
     def _mark(self, label: str) -> None:
@@ -308,25 +380,31 @@ class Trainer:
         return out
 
     def _captured_terms(self, real_padded: Batch) -> Optional[CapturedCriticTerms]:
-        """The recorded real-side / gradient-penalty terms of this minibatch, or None when graph
-        capture is off or the minibatch carries no sample ids to recognise it by."""
-        ids = getattr(real_padded, "sample_ids", None)
-        if not self.graph_capture or ids is None:
+        """The recorded real-side / gradient-penalty terms for minibatches of this shape (None when graph
+        capture is off).  A recording is sized for depth levels up to a cap; a minibatch deeper than that
+        replaces it by one with twice the room."""
+        if not self.graph_capture:
             return None
-        key = tuple(int(i) for i in ids)
-        if key in self._captured:
+        e_cols = 0 if real_padded.edge_index is None else int(real_padded.edge_index.size(1))
+        key = (int(real_padded.x.size(0)), e_cols)
+        terms = self._captured.get(key)
+        if terms is not None and terms.fits(real_padded):
             self._captured.move_to_end(key)
-            return self._captured[key]
-        terms = CapturedCriticTerms(self.D, self._d_params, real_padded, sanitize_for_D(real_padded),
-                                    self.args.gp_lambda, self.device, closed_form_gp=self.closed_form_gp)
+            return terms
+        top = max(depth_top(real_padded), 0)
+        cap = max(self.level_cap, 2 * top, 64)
+        self._captured.pop(key, None)
+        terms = CapturedCriticTerms(self.D, self._d_params, real_padded, cap, self.args.gp_lambda, self.device,
+                                    closed_form_gp=self.closed_form_gp)
+        self.captures += 1
         self._captured[key] = terms
-        if len(self._captured) > 4:       # every entry pins the activations of its graph
+        if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
             self._captured.popitem(last=False)
         return terms
 
     @property
     def edges_last_step(self) -> int:
-        """Edge columns the critic saw in the last step: real + fake, ``-1`` padding excluded (one host read)."""
+        """Edges the critic saw in the last step: real + fake, padding columns and self loops excluded (one host read)."""
         return 0 if self._edges_last is None else int(self._edges_last.item())
 
     def _pad_batch(self, graphs: List[Data]) -> Batch:
@@ -346,7 +424,11 @@ class Trainer:
         real_replayed = False
         try:
             terms = self._captured_terms(real_padded)
-            real_for_D = terms._inputs[2] if terms is not None else sanitize_for_D(real_padded)
+            if terms is not None:
+                terms.load(real_padded)
+                real_for_D, edges_real = terms.real_for_D, terms.edges_real
+            else:
+                real_for_D, edges_real = sanitize_for_D(real_padded), count_edges(real_padded.edge_index)
             fakes_stream = self.side_stream if (terms is not None and self.overlap_fakes) else main_stream
             fakes_stream.wait_stream(main_stream)
             if fakes_stream is not main_stream:
@@ -360,10 +442,10 @@ class Trainer:
                 corr_fakes_once = [enforce_finish(h) for h in repairs]
                 fake_padded = self._pad_batch(corr_fakes_once)
                 fake_for_D = fake_padded
-                edges_fake = valid_edge_mask(fake_padded).sum()
+                edges_fake = count_edges(fake_padded.edge_index)
             main_stream.wait_stream(fakes_stream)
             self._mark("fakes ready")
-            self._edges_last = edges_fake + int(real_for_D.edge_index.size(1))
+            self._edges_last = edges_fake + edges_real
         except Exception as e:
             if self.world == 1:
                 raise
@@ -421,18 +503,11 @@ class Trainer:
             pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
             loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
         raw_batch_for_D = self._pad_batch(raw_gen)
-        ids = getattr(real_padded, "sample_ids", None)
-        if ids is not None:
-            # the generator hands the template's depths through unchanged, so the padded depth vector of
-            # a minibatch is the same every time: keeping the first one lets the critic reuse its level plan
-            key = tuple(int(i) for i in ids)
-            kept = self._raw_depth.get(key)
-            if kept is None or kept.shape != raw_batch_for_D.node_depth.shape:
-                self._raw_depth[key] = raw_batch_for_D.node_depth
-                if len(self._raw_depth) > 16:
-                    self._raw_depth.popitem(last=False)
-            else:
-                raw_batch_for_D.node_depth = kept
+        if terms is not None:
+            # the generator hands the template's depths through unchanged (generator.py:211-217) and the templates
+            # are the real minibatch's graphs, so the padded depth vector of the raw batch is the real batch's:
+            # the critic reuses the level plan that the recorded terms rebuilt for this step
+            raw_batch_for_D._plan = terms.plan
         loss_G_adv = -mean_score(D, raw_batch_for_D)
         main_stream.wait_stream(self.side_stream)
         loss_pen.record_stream(main_stream)
@@ -492,6 +567,8 @@ def train(args) -> None:
     padded_list = [pad_data(d, max_nodes=max_nodes, max_edges=max_edges) for d in data_list]
     loader = GraphLoader(padded_list, batch_size=args.batch_size, shuffle=True,
                          seed=args.seed if world == 1 else (args.seed or 0), rank=rank, world_size=world)
+    # size the recorded critic terms for the deepest graph of the dataset, so that no minibatch outgrows them
+    args.level_cap = max([0] + loader.depth_tops)
     trainer = Trainer(args, max_nodes, max_edges, device, rank, world)
     logger = MetricsLogger(args.out_dir)
 

@@ -217,24 +217,37 @@ size_t aig_level_plan_ws_bytes(int64_t n, int64_t L);
 int aig_level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
                    int32_t* node_level, float* w, void* ws, size_t ws_bytes, void* stream);
 
+/* The same plan without the caller's host read of the deepest level (discriminator.py:76 reads it with .item()):
+ * the level count is found on the device and left in a four-word header
+ *   lvl_meta[0] = L, the deepest level (0 when no node carries a valid depth: every node is then pooled in level 0,
+ *                 discriminator.py:68-72), lvl_meta[1] = nodes with a level, lvl_meta[2] = flags (bit 0: no valid
+ *                 depth; bit 1: a depth exceeded L_cap - such nodes are left out, the caller must re-plan), lvl_meta[3] = 0
+ * L_cap bounds the level the caller expects (sizes: lvl_ptr[L_cap+2], the argmax table and workspaces of the
+ * consumers are sized with L_cap in place of L).  The consumers below take the header as `lvl_meta`; with a header
+ * their `L` (and `nvalid` = n) arguments are capacities, with NULL they are the values themselves.  A sequence of
+ * calls built this way has fixed launch shapes for a given (n, L_cap) and can be recorded in a HIP graph and
+ * replayed on new depth vectors of that shape. */
+int aig_level_plan_dyn(int64_t n, int64_t L_cap, const int64_t* depth, int32_t* perm, int32_t* lvl_ptr,
+                       int32_t* node_level, float* w, int32_t* lvl_meta, void* ws, size_t ws_bytes, void* stream);
+
 /* out[0:128] = mean over levels 0..L of the level means, out[128:256] = mean over levels of the level
  * maxima (an empty level counts as a zero vector); argmax[l*128+f] = smallest node id attaining the
  * maximum of feature f in level l (-1 for an empty level), which is where the gradient goes.
  * nvalid = number of nodes with a level (= lvl_ptr[L+1]). */
 size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L);
-int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const float* h, const int32_t* perm,
-                       const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
+int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                       const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
                        float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of the readout (what autograd derives from discriminator.py:64-91): with g = dLoss/d out [256],
  *   d_h[i,c] = w[i] g[c] + [argmax[level(i),c] == i] g[128+c] / (L+1)
  * and its adjoint (needed when the gradient penalty differentiates a second time): for gg [n,128]
  *   out[c] = sum_i w[i] gg[i,c],   out[128+c] = sum_i [argmax[level(i),c] == i] gg[i,c] / (L+1). */
-int aig_level_pool_bwd(int64_t n, int64_t L, const float* g, const int32_t* node_level, const float* w,
-                       const int32_t* argmax, float* d_h, void* stream);
+int aig_level_pool_bwd(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g, const int32_t* node_level,
+                       const float* w, const int32_t* argmax, float* d_h, void* stream);
 size_t aig_level_pool_bwd_adj_ws_bytes(int64_t n);
-int aig_level_pool_bwd_adj(int64_t n, int64_t L, const float* gg, const int32_t* node_level, const float* w,
-                           const int32_t* argmax, float* out, void* ws, size_t ws_bytes, void* stream);
+int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_meta, const float* gg, const int32_t* node_level,
+                           const float* w, const int32_t* argmax, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gradient penalty on the edge-free interpolate - gradient_penalty(use_edges=False), train.py:133-152, through
@@ -247,18 +260,19 @@ int aig_level_pool_bwd_adj(int64_t n, int64_t L, const float* gg, const int32_t*
  *                      coef = d gp / d norm / norm = 2 (norm - 1) / norm)
  *   aig_gp_param_grad  gradient of gp w.r.t. W1 [128,2], b1, W2 [128,128], b2 and ubar_gr = d gp / d g_r [256]
  *                      (the caller back-propagates ubar_gr through its head to get the head's weight gradients).
- * W1/b1 = gat1.lin.weight / gat1.bias, W2/b2 = gat2.lin.weight / gat2.bias; alpha, norm_sq, coef are device scalars.
+ * W1/b1 = gat1.lin.weight / gat1.bias, W2/b2 = gat2.lin.weight / gat2.bias; alpha, norm_sq, coef are device scalars;
+ * lvl_meta = header of a plan from aig_level_plan_dyn, or NULL when L is the plan's deepest level itself.
  * ------------------------------------------------------------------------------------------- */
 int aig_gp_forward(int64_t n, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
                    const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2, void* stream);
 size_t aig_gp_input_grad_ws_bytes(int64_t n);
-int aig_gp_input_grad(int64_t n, int64_t L, const float* g_r, const int32_t* node_level, const float* w,
-                      const int32_t* argmax, const float* W1, const float* W2, const float* h1, const float* h2,
+int aig_gp_input_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g_r, const int32_t* node_level,
+                      const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1, const float* h2,
                       float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
                       void* ws, size_t ws_bytes, void* stream);
 size_t aig_gp_param_grad_ws_bytes(int64_t n);
-int aig_gp_param_grad(int64_t n, int64_t L, const float* coef, const float* g_r, const int32_t* node_level,
-                      const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* xhat,
+int aig_gp_param_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* coef, const float* g_r,
+                      const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* xhat,
                       const float* h1, const float* h2, const float* g_z2, const float* g_h1, const float* g_z1,
                       const float* g_x, float* dW1, float* db1, float* dW2, float* db2, float* ubar_gr,
                       void* ws, size_t ws_bytes, void* stream);

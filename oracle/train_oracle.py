@@ -69,7 +69,8 @@ class CpuTrainer:
         loss_g = loss_adv + self.lambda_cons * pen
         loss_g.backward()      # reaches only the critic's parameters, as in the reference
         m.update(loss_G=float(loss_g.detach()), pen=float(pen.detach()))
-        ei_r, _ = _sanitize(real_padded)
-        ei_f, _ = _sanitize(fake_padded)
-        m["edges"] = int(ei_r.size(1) + ei_f.size(1))
+        # edges of the two critic inputs: padding columns out, and with them the self loops that batching
+        # makes of the padding of every graph but the first
+        m["edges"] = sum(int(((b.edge_index.min(dim=0).values >= 0) & (b.edge_index[0] != b.edge_index[1])).sum())
+                         for b in (real_padded, fake_padded))
         return m

@@ -12,7 +12,7 @@ import torch
 from gan_amd import _abi
 from gan_amd.data import Batch, Data
 from gan_amd.dataset import pad_data
-from gan_amd.discriminator import AIGDiscriminator, GraphCSR, LevelPlan, _LevelPool
+from gan_amd.discriminator import AIGDiscriminator, DynLevelPlan, GraphCSR, LevelPlan, _LevelPool
 from gan_amd.synth import synth_aig
 from oracle import model as omodel
 
@@ -115,6 +115,80 @@ def test_critic_forward_and_parameter_gradients(name):
     for k, v in D.named_parameters():
         assert v.grad is not None, k
         close(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=5e-4, what="grad " + k)
+
+
+def test_structures_rebuilt_in_place_give_the_same_critic():
+    """Edge lists and level plan kept in fixed buffers and rebuilt per graph (what a recorded critic term
+    replays): same scores and gradients, bit for bit, as structures derived from each graph's own tensors -
+    for depth vectors with different level counts, ignored nodes, and one without any valid depth."""
+    n, e_cols, cap = 400, 1200, 300
+    D, _ = make_critic(seed=5)
+    ei_buf = torch.full((2, e_cols), -1, dtype=torch.int64, device=DEV)
+    ea_buf = torch.zeros((e_cols, 1), dtype=torch.float32, device=DEV)
+    nd_buf = torch.full((n,), -1, dtype=torch.int64, device=DEV)
+    x_buf = torch.zeros((n, 2), device=DEV)
+    csr, plan = GraphCSR(ei_buf, ea_buf, n), DynLevelPlan(n, cap, DEV)
+    cases = []
+    for i, (n_and, window) in enumerate([(300, 4), (200, 60), (350, 2), (120, 120)]):
+        cases.append(pad_data(synth_aig(10 + i, n_and, 8, seed=20 + i, window=window, orientation="dataset"), n, e_cols))
+    none_valid = pad_data(synth_aig(9, 100, 5, seed=31, window=20, orientation="dataset"), n, e_cols)
+    none_valid.node_depth = torch.full((n,), -1, dtype=torch.long)
+    cases.append(none_valid)
+    tops = set()
+    for c in cases:
+        c = c.to(DEV)
+        x_buf.copy_(c.x); ei_buf.copy_(c.edge_index); ea_buf.copy_(c.edge_attr); nd_buf.copy_(c.node_depth)
+        csr.rebuild(ei_buf, ea_buf)
+        plan.rebuild(nd_buf)
+        L, nvalid, flags, _ = plan.meta.tolist()
+        top = int(c.node_depth.max())
+        tops.add(top)
+        assert (L, nvalid, flags) == ((top, int((c.node_depth >= 0).sum()), 0) if top >= 0 else (0, n, 1))
+        held = Data(x=x_buf, edge_index=ei_buf, edge_attr=ea_buf, node_depth=nd_buf)
+        held._csr, held._plan = csr, plan
+        D.zero_grad()
+        s1 = D(held)
+        s1.sum().backward()
+        g1 = {k: v.grad.clone() for k, v in D.named_parameters()}
+        D.zero_grad()
+        keep = c.edge_index.min(dim=0).values >= 0
+        s2 = D(Data(x=c.x, edge_index=c.edge_index[:, keep], edge_attr=c.edge_attr[keep], node_depth=c.node_depth))
+        s2.sum().backward()
+        assert torch.equal(s1, s2)
+        for k, v in D.named_parameters():
+            assert torch.equal(g1[k], v.grad), k
+        # the closed-form gradient penalty through the same plan
+        xf = torch.rand((n, 2), device=DEV)
+        al = torch.tensor([[0.3]], device=DEV)
+        gp1, gn1, gr1 = D.gradient_penalty_closed_form(c.x, xf, al, nd_buf, plan=plan)
+        gp2, gn2, gr2 = D.gradient_penalty_closed_form(c.x, xf, al, c.node_depth)
+        assert torch.equal(gp1, gp2) and torch.equal(gn1, gn2)
+        for k in gr1:
+            assert torch.equal(gr1[k], gr2[k])
+    assert len(tops) >= 4
+    # a depth beyond the cap is reported, not silently pooled
+    nd_buf.copy_(cases[0].node_depth)
+    nd_buf[5] = cap + 7
+    plan.rebuild(nd_buf)
+    assert plan.overflowed()
+
+
+def test_closed_form_penalty_with_a_vanishing_input_gradient():
+    """All head units inactive => ds/dx = 0, norm 0: the penalty is 1 and its gradient 0 (the zero
+    subgradient autograd uses for the norm, train.py:150), not NaN."""
+    from gan_amd.train import gradient_penalty
+    D, _ = make_critic(seed=2)
+    with torch.no_grad():
+        D.mlp[0].bias.fill_(-1e4)          # first head layer never fires
+    d = pad_data(synth_aig(6, 50, 4, seed=8, window=16, orientation="dataset"), 80, 160).to(DEV)
+    xf = torch.rand((80, 2), device=DEV)
+    al = torch.tensor([[0.6]], device=DEV)
+    gp, gn, grads = D.gradient_penalty_closed_form(d.x, xf, al, d.node_depth)
+    assert float(gn) == 0.0 and float(gp) == 1.0
+    for k, g in grads.items():
+        assert torch.isfinite(g).all() and float(g.abs().max()) == 0.0
+    gp_a, gn_a = gradient_penalty(D, Data(x=d.x, node_depth=d.node_depth), Data(x=xf), DEV, use_edges=False, alpha=al)
+    assert float(gn_a) == 0.0 and float(gp_a) == 1.0
 
 
 def test_gat_layer_output_and_input_gradient():

@@ -33,7 +33,8 @@ def test_training_step_matches_cpu_checker(batch, capture, gp):
     max_edges = max(g.edge_index.size(1) for g in graphs)
     padded = [pad_data(g, max_nodes, max_edges) for g in graphs]
     args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1"] +
-                                     (["--autograd-gp"] if gp == "autograd" else []))
+                                     (["--autograd-gp"] if gp == "autograd" else []) +
+                                     ([] if capture else ["--no-graph-capture"]))
     tr = Trainer(args, max_nodes, max_edges, DEV)
     gs = gen_state()
     dparams = omodel.init_discriminator_params(11)
@@ -48,10 +49,9 @@ def test_training_step_matches_cpu_checker(batch, capture, gp):
     real = Batch.from_data_list(padded)
     real.sample_ids = list(range(batch))
     step_batch = Batch.from_data_list(padded).to(DEV)
-    if capture:                      # minibatches that carry sample ids replay the recorded critic terms
-        step_batch.sample_ids = list(range(batch))
+    step_batch.sample_ids = list(range(batch))
     out = tr.step(step_batch)
-    assert (len(tr._captured) == 1) == capture
+    assert (len(tr._captured) == 1) == capture and tr.captures == int(capture)
     got = {k: float(v) for k, v in out.items()}
 
     cpu_tr = CpuTrainer(gs, dparams, 16, max_nodes, max_edges)
@@ -68,6 +68,81 @@ def test_training_step_matches_cpu_checker(batch, capture, gp):
     for k, v in tr.G.state_dict().items():
         assert torch.equal(v.cpu(), gs[k]), k
     assert all(p.grad is None for p in tr.G.parameters())
+
+
+@pytest.mark.parametrize("gp", ["closed_form", "autograd"])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_rotating_minibatches_share_one_recording(batch, gp):
+    """Six different minibatches of one padded shape, stepped through twice in a different order (what a
+    shuffling loader feeds train.py:229-233): the critic terms are recorded once for the shape and every step
+    agrees with the CPU checker run over the same sequence (its Adam state included)."""
+    n_batches = 6
+    graphs = [synth_aig(5 + (i % 4), 40 + 13 * i, 3 + (i % 3), seed=70 + i, window=8 + 6 * (i % 5), orientation="dataset")
+              for i in range(n_batches * batch)]
+    max_nodes = max(g.x.size(0) for g in graphs)
+    max_edges = max(g.edge_index.size(1) for g in graphs)
+    padded = [pad_data(g, max_nodes, max_edges) for g in graphs]
+    assert len({int(p.node_depth.max()) for p in padded}) > 2          # the level counts differ between minibatches
+    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1"] +
+                                     (["--autograd-gp"] if gp == "autograd" else []))
+    args.level_cap = max(int(p.node_depth.max()) for p in padded)
+    tr = Trainer(args, max_nodes, max_edges, DEV)
+    gs, dparams = gen_state(), omodel.init_discriminator_params(13)
+    tr.G.load_state_dict(gs)
+    tr.D.load_state_dict(dparams)
+    cpu_tr = CpuTrainer(gs, dparams, 16, max_nodes, max_edges)
+    g = torch.Generator().manual_seed(9)
+    order = list(range(n_batches)) + [4, 2, 5, 0, 3, 1]
+    for step, b in enumerate(order):
+        members = list(range(b * batch, (b + 1) * batch))
+        zs = [torch.randn(128, generator=g) for _ in range(2 * batch)]
+        alphas = [torch.rand(1, 1, generator=g) for _ in range(args.n_critic)]
+        zi, ai = iter(zs), iter(alphas)
+        tr.draw_z = lambda: next(zi).to(DEV)
+        tr.draw_alpha = lambda: next(ai).to(DEV)
+        real = Batch.from_data_list([padded[i] for i in members])
+        step_batch = Batch.from_data_list([padded[i] for i in members]).to(DEV)
+        step_batch.sample_ids = members
+        got = {k: float(v) for k, v in tr.step(step_batch).items()}
+        templates = [unpad_data(d) for d in real.to_data_list()]
+        ref = cpu_tr.step(real, templates, zs[:batch], zs[batch:], alphas, validate=True)
+        for k in ("D_real", "D_fake", "gap", "gp", "grad_norm", "loss_D", "loss_G", "pen"):
+            assert rel(got[k], ref[k]) <= 1e-4, (step, k, got[k], ref[k])
+        assert tr.edges_last_step == ref["edges"], step
+        assert tr.captures == 1 and len(tr._captured) == 1, step
+        assert not tr._captured[(max_nodes * batch, max_edges * batch)].plan.overflowed()
+    for k, v in tr.D.state_dict().items():
+        a, b_ = v.cpu().numpy(), cpu_tr.dp[k].detach().numpy()
+        assert np.abs(a - b_).max() <= 1e-4 * max(np.abs(b_).max(), 1e-3), k
+
+
+def test_recording_outgrown_by_a_deeper_minibatch_is_replaced():
+    """A minibatch whose deepest level exceeds what the recording was sized for gets a new recording (and
+    correct numbers), never a silently truncated readout."""
+    shallow = synth_aig(8, 220, 4, seed=3, window=120, orientation="dataset")
+    deep = synth_aig(8, 220, 4, seed=4, window=2, orientation="dataset")
+    assert int(deep.node_depth.max()) > 64 + 2 * int(shallow.node_depth.max())
+    mn, me = max(shallow.x.size(0), deep.x.size(0)), max(shallow.edge_index.size(1), deep.edge_index.size(1))
+    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1000"])
+    tr = Trainer(args, mn, me, DEV)
+    tr.global_step = 1
+    gs, dparams = gen_state(), omodel.init_discriminator_params(3)
+    tr.G.load_state_dict(gs)
+    tr.D.load_state_dict(dparams)
+    cpu_tr = CpuTrainer(gs, dparams, 16, mn, me)
+    g = torch.Generator().manual_seed(2)
+    for step, graph in enumerate([shallow, deep, shallow]):
+        zs = [torch.randn(128, generator=g) for _ in range(2)]
+        alphas = [torch.rand(1, 1, generator=g) for _ in range(3)]
+        zi, ai = iter(zs), iter(alphas)
+        tr.draw_z = lambda: next(zi).to(DEV)
+        tr.draw_alpha = lambda: next(ai).to(DEV)
+        real = Batch.from_data_list([pad_data(graph, mn, me)])
+        got = {k: float(v) for k, v in tr.step(Batch.from_data_list([pad_data(graph, mn, me)]).to(DEV)).items()}
+        ref = cpu_tr.step(real, [unpad_data(d) for d in real.to_data_list()], zs[:1], zs[1:], alphas, validate=False)
+        for k in ("D_real", "D_fake", "gp", "loss_D", "loss_G"):
+            assert rel(got[k], ref[k]) <= 1e-4, (step, k, got[k], ref[k])
+        assert tr.captures == (1 if step == 0 else 2)
 
 
 def test_gradient_penalty_rejects_edge_branch():
