@@ -35,17 +35,39 @@ MFMA_F32_PEAK_TF = 157.3  # dense f32 matrix peak of MI355X
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak; ~6300 GB/s is the measured copy ceiling
 
 
-def workload_graphs(name: str, rank: int):
+def workload_minibatches(name: str, rank: int, distinct: int):
+    """``distinct`` different minibatches (lists of graphs) for this rank, and a description.  The timed loop
+    walks through them in turn, as a shuffling loader over a dataset does (train.py:229-233): no two
+    consecutive steps see the same graphs."""
     from gan_amd.synth import iscas85_like, synth_aig
+    seeds = [rank * distinct + i for i in range(distinct)]
     if name == "synth100k":
-        return [synth_aig(1000, 98000, 1000, seed=rank, window=4096, orientation="dataset")], \
-            "synthetic 100k-node AIG (1000 PI / 98000 AND / 1000 PO, window 4096), one graph per step per GPU"
+        return [[synth_aig(1000, 98000, 1000, seed=s, window=4096, orientation="dataset")] for s in seeds], \
+            "synthetic 100k-node AIGs (1000 PI / 98000 AND / 1000 PO, window 4096), one graph per step per GPU"
     if name == "synth1m":
-        return [synth_aig(10000, 980000, 10000, seed=rank, window=4096, orientation="dataset")], \
-            "synthetic 1M-node AIG (10k PI / 980k AND / 10k PO, window 4096), one graph per step per GPU"
+        return [[synth_aig(10000, 980000, 10000, seed=s, window=4096, orientation="dataset")] for s in seeds], \
+            "synthetic 1M-node AIGs (10k PI / 980k AND / 10k PO, window 4096), one graph per step per GPU"
     if name == "iscas85":
-        return iscas85_like(seed=rank), "11 synthetic graphs with ISCAS85 node counts (c17..c7552), one batch of 11 per step per GPU"
+        return [iscas85_like(seed=s) for s in seeds], \
+            "synthetic graphs with ISCAS85 node counts (c17..c7552), one batch of all 11 per step per GPU"
     raise SystemExit(f"unknown workload {name}")
+
+
+def device_minibatches(groups, dev):
+    """The minibatches padded to the workload's (max_nodes, max_edges) as train.py:200-204 does, resident in HBM."""
+    from gan_amd.data import Batch
+    from gan_amd.dataset import pad_data
+    mn = max(g.x.size(0) for gs in groups for g in gs)
+    me = max(g.edge_index.size(1) for gs in groups for g in gs)
+    top = max(int(g.node_depth.max()) for gs in groups for g in gs)
+    batches, next_id = [], 0
+    for gs in groups:
+        b = Batch.from_data_list([pad_data(g, mn, me) for g in gs])
+        b._depth_top = max(int(g.node_depth.max()) for g in gs)     # noted from the host-side data, as GraphLoader does
+        b.sample_ids = list(range(next_id, next_id + len(gs)))
+        next_id += len(gs)
+        batches.append(b.to(dev))
+    return batches, mn, me, top
 
 
 def measured_peaks():
@@ -115,26 +137,26 @@ def cpu_baseline(seconds_budget: float = 25.0):
 def side_workload(name: str, dev, steps: int, warmup: int):
     """A short measurement of another BASELINE.json configuration on the same GPU (rank 0, N=1 only):
     training step time, edges/s and bulk sampling rate, reported next to the main line."""
-    from gan_amd.data import Batch
-    from gan_amd.dataset import pad_data
     from gan_amd.sample import sample_many
     from gan_amd.train import Trainer, build_parser
-    graphs, desc = workload_graphs(name, 0)
-    mn = max(g.x.size(0) for g in graphs)
-    me = max(g.edge_index.size(1) for g in graphs)
+    distinct = 8
+    groups, desc = workload_minibatches(name, 0, distinct)
+    batches, mn, me, top = device_minibatches(groups, dev)
     targs = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000"])
+    targs.level_cap = top
     tr = Trainer(targs, mn, me, dev)
     tr.global_step = 1
-    batch = Batch.from_data_list([pad_data(g, mn, me) for g in graphs]).to(dev)
-    batch.sample_ids = list(range(len(graphs)))
-    for _ in range(warmup):
-        tr.step(batch)
+    for i in range(distinct + warmup):      # one pass over the minibatches (per-sample templates), then warm-up
+        tr.step(batches[i % distinct])
     torch.cuda.synchronize()
+    edges = torch.zeros((), dtype=torch.long, device=dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(batch)
+    for i in range(steps):
+        tr.step(batches[i % distinct])
+        edges += tr._edges_last
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    batch = batches[0]
     templates = tr.templates_of(batch)
     draw = lambda: torch.randn(128, device=dev)   # noqa: E731
     list(sample_many(tr.G, ((t, draw) for t in templates)))
@@ -144,9 +166,36 @@ def side_workload(name: str, dev, steps: int, warmup: int):
         pass
     torch.cuda.synchronize()
     nodes = sum(int(t.x.size(0)) for t in templates) * steps
-    return {"workload": f"{name}: {desc}", "steps": steps, "ms_per_step": round(dt * 1e3, 3),
-            "edges_per_sec": round(tr.edges_last_step / dt, 1),
+    return {"workload": f"{name}: {desc}; {distinct} different minibatches in rotation", "steps": steps,
+            "ms_per_step": round(dt * 1e3, 3), "edges_per_sec": round(int(edges.item()) / steps / dt, 1),
+            "recordings": tr.captures,
             "sample_nodes_per_sec": round(nodes / (time.perf_counter() - s0), 1)}
+
+
+def launch_ranks(n: int) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child
+    process; one rank per GPU over RCCL.  With fewer GPUs than ranks the ranks can only rehearse the
+    data-parallel path over gloo (AIG_DIST_BACKEND=gloo), sharing the devices round-robin - said loudly, because
+    such a run measures nothing about scaling."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()       # counting devices does not start the HIP runtime
+    env = dict(os.environ)
+    if have < n:
+        if env.get("AIG_DIST_BACKEND") != "gloo":
+            print(f"[bench] --gpus {n} but only {have} GPU(s) visible: RCCL needs one device per rank "
+                  "(set AIG_DIST_BACKEND=gloo to rehearse the ranks on shared devices)", file=sys.stderr)
+            return 2
+        print(f"[bench] note: {n} ranks share {have} GPU(s) over gloo - a rehearsal, not a scaling measurement",
+              file=sys.stderr)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1)) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -160,7 +209,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true",
                     help="skip the short ISCAS85-sized measurement reported next to the main line at N=1")
+    ap.add_argument("--distinct", type=int, default=None,
+                    help="different minibatches per GPU the timed loop rotates through (default 8; 4 for synth1m)")
     a = ap.parse_args()
+    if a.distinct is None:
+        a.distinct = 4 if a.workload == "synth1m" else 8
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started as a plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes
+        # (this process has not touched the GPU: torch is imported, no HIP call was made), and leave with
+        # their exit code.  Rank 0 of the children prints the JSON line.
+        sys.exit(launch_ranks(a.gpus))
 
     from gan_amd import _abi, parallel
     from gan_amd.constraints import enforce_aig_constraints, repair_and_resync, resync_attrs
@@ -176,14 +235,13 @@ def main():
     torch.cuda.set_device(dev)
     torch.manual_seed(123)
 
-    graphs, desc = workload_graphs(a.workload, rank)
-    max_nodes = max(g.x.size(0) for g in graphs)
-    max_edges = max(g.edge_index.size(1) for g in graphs)
+    groups, desc = workload_minibatches(a.workload, rank, a.distinct)
+    batches, max_nodes, max_edges, top = device_minibatches(groups, dev)
     targs = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000"])
+    targs.level_cap = top        # train.py sizes the recorded critic terms by the deepest graph of the dataset
     trainer = Trainer(targs, max_nodes, max_edges, dev, rank, world)
     trainer.global_step = 1      # step 0 would add the save-step validation pass; steady state is measured
-    batch = Batch.from_data_list([pad_data(g, max_nodes, max_edges) for g in graphs]).to(dev)
-    batch.sample_ids = list(range(len(graphs)))
+    nb = len(batches)
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,8 +249,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        trainer.step(batch)
+    def run_steps(count, start=0, only=None):
+        edges = torch.zeros((), dtype=torch.long, device=dev)
+        for i in range(count):
+            trainer.step(batches[(start + i) % nb] if only is None else only)
+            edges += trainer._edges_last          # accumulated on the device: no host read inside the loop
+        return edges
+
+    # Set-up, not measured: one pass over the rank's minibatches, as the first epoch of a run - it builds what
+    # train.py keeps per dataset sample (the template and its generator plan) and the one recording of the critic
+    # terms for this minibatch shape.  Then the W warm-up steps, then the K timed steps, all in rotation.
+    run_steps(nb)
+    run_steps(a.warmup, start=nb)
     barrier()
     _abi.timeline.reset()
     # Only the kernel the roofline reports on is bracketed with events inside the timed region: an
@@ -200,25 +268,32 @@ def main():
     _abi.timeline.only = {"aig_gat_fwd"}
     _abi.timeline.enabled = True
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        trainer.step(batch)
+    edges_dev = run_steps(a.steps, start=nb + a.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
     _abi.timeline.enabled = False
     tl = _abi.timeline.totals_ms()
     tl_meta = dict(_abi.timeline.meta)
+    recordings = trainer.captures
+    # the same step count on ONE minibatch over and over (every per-object cache hot): the figure a loop that
+    # never changes its input would report, kept beside the rotating one
+    barrier()
+    r0 = time.perf_counter()
+    run_steps(a.steps, only=batches[0])
+    barrier()
+    ms_repeated = (time.perf_counter() - r0) * 1e3 / a.steps
     # per-entry-point GPU time from a few extra, untimed, fully instrumented steps
     inst_steps = min(3, a.steps)
     _abi.timeline.reset()
     _abi.timeline.only = None
     _abi.timeline.enabled = True
-    for _ in range(inst_steps):
-        trainer.step(batch)
+    run_steps(inst_steps)
     barrier()
     _abi.timeline.enabled = False
     tl_all = _abi.timeline.totals_ms()
+    batch = batches[0]
 
-    edges_rank = trainer.edges_last_step * a.steps
+    edges_rank = int(edges_dev.item())
     stat = torch.tensor([elapsed, float(edges_rank)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stat[:1].clone()
@@ -301,10 +376,13 @@ def main():
         out = {
             "metric": "train edges/sec (AIG nodes/sec sampled at k=64 in sample_nodes_per_sec)",
             "value": round(edges_total / elapsed, 1), "unit": "edges/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(elapsed * 1e3 / a.steps, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(elapsed * 1e3 / a.steps, 3),
+            "ms_per_step_repeated_batch": round(ms_repeated, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {desc}; candidate-k 64, n_critic 3, hidden 128, fp32",
-                       "edges_per_step_per_gpu": trainer.edges_last_step,
+            "config": {"workload": f"{a.workload}: {desc}; {nb} different minibatches per GPU in rotation inside the timed "
+                                   "region; candidate-k 64, n_critic 3, hidden 128, fp32",
+                       "distinct_minibatches_per_gpu": nb, "critic_term_recordings": recordings,
+                       "edges_per_step_per_gpu": round(edges_rank / a.steps, 1),
                        "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
             "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
             "sample_nodes_per_sec_one_at_a_time": round(sample_nodes_per_sec_single, 1),
@@ -321,7 +399,7 @@ def main():
         if world == 1 and not a.no_side_workloads and a.workload != "iscas85":
             # BASELINE.json configs[1] (ISCAS85-sized graphs, one minibatch of all of them): bound by launches
             # and Python, not by the GPU - reported for completeness, the roofline figures above are not its
-            del trainer, batch, templates
+            del trainer, batch, batches, templates
             import gc
             gc.collect()
             torch.cuda.empty_cache()

@@ -267,6 +267,7 @@ class CapturedCriticTerms:
         with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
             self.gp, self.grad_norm, grads_gp = compute_gp()
         self.captures = 1
+        self._stages = (prep, compute_real, compute_gp)    # the recorded work, callable eagerly (diagnostics)
         self._adds = []   # (parameters, recorded gradients) per graph
         for grads in (grads_real, grads_gp):
             self._adds.append(([p for p, g in zip(params, grads) if g is not None], [g for g in grads if g is not None]))

@@ -43,8 +43,11 @@ class CpuTrainer:
         return model.discriminator_forward(self.dp, b.x, ei, ea, b.node_depth)
 
     def step(self, real_padded: Batch, templates: List[Data], zs_critic: List[torch.Tensor],
-             zs_gen: List[torch.Tensor], alphas: List[torch.Tensor], validate: bool = True) -> Dict[str, float]:
-        raw = [self._fake(t, z) for t, z in zip(templates, zs_critic)]
+             zs_gen: List[torch.Tensor], alphas: List[torch.Tensor], validate: bool = True,
+             raw_critic: List[Data] = None, raw_generator: List[Data] = None) -> Dict[str, float]:
+        """``raw_critic`` / ``raw_generator``: raw graphs to use in place of this class's own generator pass (a
+        replay of a recorded run of the reference feeds in the graphs that run's generator emitted)."""
+        raw = [self._fake(t, z) for t, z in zip(templates, zs_critic)] if raw_critic is None else raw_critic
         corr = [cpu.enforce_aig_constraints(r) for r in raw]
         fake_padded = Batch.from_data_list([pad_data(c, self.max_nodes, self.max_edges) for c in corr])
         m: Dict[str, float] = {}
@@ -58,7 +61,7 @@ class CpuTrainer:
             self.opt.step()
             m.update(D_real=float(d_real.detach()), D_fake=float(d_fake.detach()), gap=float((d_real - d_fake).detach()), gp=float(gp.detach()),
                      grad_norm=float(gn), loss_D=float(loss_d.detach()))
-        raw_gen = [self._fake(t, z) for t, z in zip(templates, zs_gen)]
+        raw_gen = [self._fake(t, z) for t, z in zip(templates, zs_gen)] if raw_generator is None else raw_generator
         raw_batch = Batch.from_data_list([pad_data(r, self.max_nodes, self.max_edges) for r in raw_gen])
         self.opt.zero_grad()
         loss_adv = -self._score(raw_batch).mean()

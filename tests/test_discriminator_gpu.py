@@ -15,6 +15,7 @@ from gan_amd.dataset import pad_data
 from gan_amd.discriminator import AIGDiscriminator, DynLevelPlan, GraphCSR, LevelPlan, _LevelPool
 from gan_amd.synth import synth_aig
 from oracle import model as omodel
+from util_golden import critic_case_graph, critic_cases
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -117,11 +118,56 @@ def test_critic_forward_and_parameter_gradients(name):
         close(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=5e-4, what="grad " + k)
 
 
+_CD, _CPARAMS, _CNAMES = critic_cases()
+
+
+@pytest.mark.parametrize("name", _CNAMES)
+def test_critic_against_reference_execution(name):
+    """Scores, parameter gradients and the gradient penalty recorded from the reference's own
+    models/discriminator.py and train.py (tests/golden/make_golden_critic.py; the attention layer inside was
+    the restated one - everything around it, readout, head, sanitising, penalty, is the reference's code)."""
+    from gan_amd.train import gradient_penalty, sanitize_for_D
+    g = critic_case_graph(_CD, name).to(DEV)
+    D = AIGDiscriminator()
+    D.load_state_dict(_CPARAMS)
+    D = D.to(DEV)
+    pre = name + "/"
+    inp = sanitize_for_D(g) if name.startswith("padded") else g
+    score = D(inp)
+    close(score.detach().cpu().numpy(), _CD[pre + "score"], what="score")
+    if pre + "grad/out.weight" in _CD.files:
+        score.sum().backward()
+        for k, v in D.named_parameters():
+            close(v.grad.cpu().numpy(), _CD[pre + "grad/" + k], rtol=5e-4, what="grad " + k)
+    if name.startswith("padded"):
+        # the critic also takes the padded edge list as it is (the edge-list builder drops the -1 columns)
+        assert torch.equal(D(g), score)
+    if pre + "gp" in _CD.files:
+        xf = torch.from_numpy(_CD[pre + "gp_fake_x"]).to(DEV)
+        al = torch.from_numpy(_CD[pre + "gp_alpha"]).to(DEV)
+        gp, gn, grads = D.gradient_penalty_closed_form(g.x, xf, al, g.node_depth)
+        close(gp.cpu().numpy(), _CD[pre + "gp"], what="gp (closed form)")
+        close(gn.cpu().numpy(), _CD[pre + "gp_grad_norm"], what="grad norm (closed form)")
+        D.zero_grad()
+        gp_a, gn_a = gradient_penalty(D, Data(x=g.x, node_depth=g.node_depth), Data(x=xf), DEV, use_edges=False, alpha=al)
+        close(gp_a.detach().cpu().numpy(), _CD[pre + "gp"], what="gp (autograd)")
+        close(gn_a.cpu().numpy(), _CD[pre + "gp_grad_norm"], what="grad norm (autograd)")
+        if pre + "gp_grad/out.weight" in _CD.files:
+            gp_a.backward()
+            named = dict(D.named_parameters())
+            for k, v in named.items():
+                key = pre + "gp_grad/" + k
+                if key in _CD.files:
+                    close(v.grad.cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (autograd) " + k)
+                    if v in grads:
+                        close(grads[v].cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (closed form) " + k)
+
+
 def test_structures_rebuilt_in_place_give_the_same_critic():
     """Edge lists and level plan kept in fixed buffers and rebuilt per graph (what a recorded critic term
     replays): same scores and gradients, bit for bit, as structures derived from each graph's own tensors -
     for depth vectors with different level counts, ignored nodes, and one without any valid depth."""
-    n, e_cols, cap = 400, 1200, 300
+    n, e_cols, cap = 400, 1200, 380
     D, _ = make_critic(seed=5)
     ei_buf = torch.full((2, e_cols), -1, dtype=torch.int64, device=DEV)
     ea_buf = torch.zeros((e_cols, 1), dtype=torch.float32, device=DEV)

@@ -130,3 +130,101 @@ def test_topk_oracle_matches_live_torch_topk():
             if k <= c:
                 want = torch.topk(torch.from_numpy(row), k).indices.tolist()
                 assert ocpu.topk(row, k).tolist() == want
+
+
+# ------------------------------------------------------------------------------------------------------
+# The critic side against the reference's own discriminator.py / train.py (run with the restated attention layer
+# standing in for torch_geometric's; tests/golden/make_golden_critic.py): level readout, head, sanitising,
+# gradient penalty, loss assembly, optimiser steps.
+from util_golden import TrainRun, critic_case_graph, critic_cases  # noqa: E402
+
+_CD, _CPARAMS, _CNAMES = critic_cases()
+
+
+def _close(a, b, rtol, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+    assert err <= rtol, f"{what}: max error {err:.3e}"
+
+
+@pytest.mark.parametrize("name", _CNAMES)
+def test_critic_oracle_matches_reference_forward(name):
+    from gan_amd.train import sanitize_for_D
+    g = critic_case_graph(_CD, name)
+    p = {k: v.clone().requires_grad_(True) for k, v in _CPARAMS.items()}
+    pre = name + "/"
+    if name.startswith("padded"):
+        # sanitize_for_D of the product (plain tensor code, device-agnostic) and of the checker against the reference's
+        s = sanitize_for_D(g)
+        assert np.array_equal(s.edge_index.numpy(), _CD[pre + "san_edge_index"])
+        assert np.array_equal(s.edge_attr.numpy(), _CD[pre + "san_edge_attr"])
+        ei, ea = omodel.sanitize_edges(g.edge_index, g.edge_attr)
+        assert np.array_equal(ei.numpy(), _CD[pre + "san_edge_index"]) and np.array_equal(ea.numpy(), _CD[pre + "san_edge_attr"])
+    else:
+        ei, ea = g.edge_index, g.edge_attr
+    score = omodel.discriminator_forward(p, g.x, ei, ea, getattr(g, "node_depth", None) if hasattr(g, "node_depth") else None)
+    _close(score.detach().numpy(), _CD[pre + "score"], 1e-6, "score")
+    if pre + "grad/out.weight" in _CD.files:
+        score.sum().backward()
+        for k in p:
+            _close(p[k].grad.numpy(), _CD[pre + "grad/" + k], 1e-5, "grad " + k)
+    if pre + "gp" in _CD.files:
+        p2 = {k: v.clone().requires_grad_(True) for k, v in _CPARAMS.items()}
+        gp, gn = omodel.gradient_penalty(p2, g.x, torch.from_numpy(_CD[pre + "gp_fake_x"]), g.node_depth,
+                                         torch.from_numpy(_CD[pre + "gp_alpha"]))
+        _close(gp.detach().numpy(), _CD[pre + "gp"], 1e-5, "gp")
+        _close(gn.numpy(), _CD[pre + "gp_grad_norm"], 1e-6, "grad norm")
+        if pre + "gp_grad/out.weight" in _CD.files:
+            gp.backward()
+            for k in p2:
+                if pre + "gp_grad/" + k in _CD.files:
+                    _close(p2[k].grad.numpy(), _CD[pre + "gp_grad/" + k], 1e-4, "gp grad " + k)
+
+
+def replay_cpu(run: TrainRun):
+    """The recorded run stepped through by the CPU checker's trainer, fed the run's draws and raw graphs."""
+    from gan_amd.data import Batch
+    from gan_amd.dataset import pad_data, unpad_data
+    from oracle.train_oracle import CpuTrainer
+    mn = max(g.x.size(0) for g in run.graphs)
+    me = max(g.edge_index.size(1) for g in run.graphs)
+    padded = [pad_data(g, mn, me) for g in run.graphs]
+    tr = CpuTrainer(gen_state(), run.d_init, run.arg("--candidate-k", 512), mn, me, lr=run.arg("--lr", 1e-4, float),
+                    gp_lambda=run.arg("--gp-lambda", 10.0, float), lambda_cons=run.arg("--lambda-cons", 1e-2, float),
+                    n_critic=run.arg("--n-critic", 3))
+    rows, states, last_epoch = [], {}, 0
+    for e, members, call, a, validate in run.steps():
+        if e != last_epoch:
+            states[last_epoch] = {k: v.detach().clone() for k, v in tr.dp.items()}
+            last_epoch = e
+        real = Batch.from_data_list([padded[i] for i in members])
+        templates = [unpad_data(d) for d in real.to_data_list()]
+        k = len(members)
+        raw_c = [run.raw(call + j, templates[j].node_depth) for j in range(k)]
+        raw_g = [run.raw(call + k + j, templates[j].node_depth) for j in range(k)]
+        rows.append(tr.step(real, templates, run.z[call:call + k], run.z[call + k:call + 2 * k],
+                            run.alpha[a:a + tr.n_critic], validate=validate, raw_critic=raw_c, raw_generator=raw_g))
+    states[last_epoch] = {k: v.detach().clone() for k, v in tr.dp.items()}
+    return rows, states
+
+
+@pytest.mark.parametrize("name", ["bs1", "bs3"])
+def test_cpu_trainer_follows_reference_training_run(name):
+    """train.py:229-360 executed by the reference (4 minibatches of one graph; 2 epochs of one minibatch of three):
+    every metrics.csv row and the critic saved at the end of each epoch."""
+    run = TrainRun(name)
+    rows, states = replay_cpu(run)
+    assert len(rows) == len(run.metrics)
+    for step, (got, ref) in enumerate(zip(rows, run.metrics)):
+        for k in ("D_real", "D_fake", "gap", "grad_norm", "loss_D", "loss_G", "gp", "pen"):
+            assert abs(got[k] - ref[k]) <= 2e-5 * max(abs(ref[k]), 1e-3), (step, k, got[k], ref[k])
+    # Adam divides every gradient element by its own running magnitude, so an element that is rounding noise
+    # (threads add in another order than the recording's single thread) still moves its weight by up to lr per
+    # step: weights are compared to a tenth of one such step
+    lr = run.arg("--lr", 1e-4, float)
+    for e, sd in states.items():
+        ref = run.epoch_state(e)
+        assert set(ref) == set(sd)
+        for k in ref:
+            diff = float((sd[k] - ref[k]).abs().max())
+            assert diff <= 1e-6 * float(ref[k].abs().max()) + 0.1 * lr, (e, k, diff)

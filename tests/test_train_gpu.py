@@ -13,7 +13,7 @@ from gan_amd.synth import synth_aig
 from gan_amd.train import Trainer, build_parser, gradient_penalty, sanitize_for_D
 from oracle import model as omodel
 from oracle.train_oracle import CpuTrainer
-from util_golden import gen_state
+from util_golden import TrainRun, gen_state
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -143,6 +143,52 @@ def test_recording_outgrown_by_a_deeper_minibatch_is_replaced():
         for k in ("D_real", "D_fake", "gp", "loss_D", "loss_G"):
             assert rel(got[k], ref[k]) <= 1e-4, (step, k, got[k], ref[k])
         assert tr.captures == (1 if step == 0 else 2)
+
+
+@pytest.mark.parametrize("name", ["bs1", "bs3"])
+@pytest.mark.parametrize("mode", ["hip_graph", "eager", "autograd_gp"])
+def test_training_follows_reference_run(name, mode):
+    """A whole ``train(args)`` run recorded from the reference's own train.py (tests/golden/make_golden_critic.py;
+    its attention layer is the restated one): the same dataset, initial critic, draws and raw generator outputs
+    fed to ``Trainer.step`` give the same metrics.csv rows within 1e-4 and the same critic at each epoch's end."""
+    run = TrainRun(name)
+    mn = max(g.x.size(0) for g in run.graphs)
+    me = max(g.edge_index.size(1) for g in run.graphs)
+    padded = [pad_data(g, mn, me) for g in run.graphs]
+    extra = {"hip_graph": [], "eager": ["--no-graph-capture"], "autograd_gp": ["--autograd-gp"]}[mode]
+    args = build_parser().parse_args(["--dataset-dir", "unused"] + run.argv + extra)
+    tr = Trainer(args, mn, me, DEV)
+    tr.G.load_state_dict(gen_state())
+    tr.D.load_state_dict(run.d_init)
+    zi, ai = iter(run.z), iter(run.alpha)
+    tr.draw_z = lambda: next(zi).to(DEV)
+    tr.draw_alpha = lambda: next(ai).to(DEV)
+    feed = []
+    tr.G = lambda template, z: feed.pop(0)      # the recorded run's raw graphs stand in for the generator pass
+    last_epoch = 0
+
+    def check_epoch(e):
+        ref = run.epoch_state(e)
+        for k, v in tr.D.state_dict().items():
+            diff = float((v.cpu() - ref[k]).abs().max())
+            assert diff <= 1e-4 * float(ref[k].abs().max()) + 0.1 * args.lr, (e, k, diff)
+
+    for step, (e, members, call, a, validate) in enumerate(run.steps()):
+        if e != last_epoch:
+            check_epoch(last_epoch)
+            last_epoch = e
+        assert validate == (tr.global_step % args.save_every == 0)
+        b = Batch.from_data_list([padded[i] for i in members]).to(DEV)
+        b.sample_ids = members
+        k = len(members)
+        depth = [padded[i].node_depth for i in members]
+        feed[:] = [run.raw(call + j, depth[j % k]).to(DEV) for j in range(2 * k)]
+        got = {key: float(v) for key, v in tr.step(b).items()}
+        assert not feed
+        ref = run.metrics[step]
+        for key in ("D_real", "D_fake", "gap", "grad_norm", "loss_D", "loss_G", "gp", "pen"):
+            assert abs(got[key] - ref[key]) <= 1e-4 * max(abs(ref[key]), 1e-3), (step, key, got[key], ref[key])
+    check_epoch(last_epoch)
 
 
 def test_gradient_penalty_rejects_edge_branch():
