@@ -64,6 +64,11 @@ __global__ void k_level_scan(int n, int L_cap, const long long* __restrict__ dep
         if (over) atomicOr(meta + META_FLAGS, 2);
     }
 }
+// (a kernel rather than two small overlapping hipMemsetAsync calls: recorded in a HIP graph, the 16-byte clear
+// of such a pair was observed not to take effect on replay)
+__global__ void k_level_meta_init(int* __restrict__ meta) {
+    if (threadIdx.x < 4) meta[threadIdx.x] = threadIdx.x == META_L ? -1 : 0;
+}
 __global__ void k_level_meta_finish(int n, int* __restrict__ meta) {
     if (meta[META_L] < 0) {  // no valid depth at all: one level holding every node
         meta[META_L] = 0;
@@ -123,7 +128,9 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const int* __
     __shared__ float red[HW_PER_BLOCK][H];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     const int item = blockIdx.x * HW_PER_BLOCK + hw;
-    if (meta) nvalid = meta[META_NVALID];   // the grid covers every node; half-waves past the valid rows add nothing
+    // with a header the grid covers every node and half-waves past the valid rows add nothing (never more rows
+    // than the launch was sized for, whatever the header says)
+    if (meta) nvalid = min(nvalid, meta[META_NVALID]);
     const int p0 = item * ROWS_PER_HW, p1 = min(nvalid, p0 + ROWS_PER_HW);
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -276,8 +283,8 @@ int level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_
     AIG_REQUIRE(lvl_ptr && (!dyn || meta), "aig_level_plan: null lvl_ptr or header");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dyn) {
-        AIG_HIP_CHECK(hipMemsetAsync(meta, 0, 16, s));
-        AIG_HIP_CHECK(hipMemsetAsync(meta, 0xFF, 4, s));   // meta[0] = -1
+        hipLaunchKernelGGL(k_level_meta_init, dim3(1), dim3(64), 0, s, meta);
+        AIG_LAUNCH_CHECK();
         if (depth && n > 0) {
             hipLaunchKernelGGL(k_level_scan, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, (int)n, (int)L,
                                reinterpret_cast<const long long*>(depth), meta);

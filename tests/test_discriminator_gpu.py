@@ -157,10 +157,16 @@ def test_critic_against_reference_execution(name):
             named = dict(D.named_parameters())
             for k, v in named.items():
                 key = pre + "gp_grad/" + k
-                if key in _CD.files:
-                    close(v.grad.cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (autograd) " + k)
-                    if v in grads:
-                        close(grads[v].cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (closed form) " + k)
+                if key not in _CD.files:
+                    continue
+                if v.grad is None:
+                    # attention parameters: softmax over the lone self loop is constant, the reference's
+                    # autograd reports exact zeros where this package reports "no gradient"
+                    assert v not in grads and float(np.abs(_CD[key]).max()) == 0.0, k
+                    continue
+                close(v.grad.cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (autograd) " + k)
+                if v in grads:
+                    close(grads[v].cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (closed form) " + k)
 
 
 def test_structures_rebuilt_in_place_give_the_same_critic():

@@ -111,9 +111,12 @@ def test_rotating_minibatches_share_one_recording(batch, gp):
         assert tr.edges_last_step == ref["edges"], step
         assert tr.captures == 1 and len(tr._captured) == 1, step
         assert not tr._captured[(max_nodes * batch, max_edges * batch)].plan.overflowed()
+    # 36 Adam steps later: Adam divides every gradient element by its own running magnitude, so an element that
+    # is rounding noise still moves its weight by up to lr per step - weights are held to a tenth of that
+    opt_steps = len(order) * args.n_critic
     for k, v in tr.D.state_dict().items():
         a, b_ = v.cpu().numpy(), cpu_tr.dp[k].detach().numpy()
-        assert np.abs(a - b_).max() <= 1e-4 * max(np.abs(b_).max(), 1e-3), k
+        assert np.abs(a - b_).max() <= 1e-4 * max(np.abs(b_).max(), 1e-3) + 0.1 * args.lr * opt_steps, k
 
 
 def test_recording_outgrown_by_a_deeper_minibatch_is_replaced():
