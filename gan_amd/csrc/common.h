@@ -53,6 +53,11 @@ inline int grid_for(int64_t items, int per_block, int cap = 1 << 20) {
     return static_cast<int>(g);
 }
 
+// Fills `bytes` (a multiple of 4, 4-byte aligned) with a 32-bit word by a kernel.  The library never calls
+// hipMemsetAsync: recorded in a HIP graph, a memset node of this ROCm release writes garbage into the head or tail of
+// its range from the second replay on (tools/graph_memset_probe2.py), and every entry point here may be recorded.
+hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not

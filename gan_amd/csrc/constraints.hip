@@ -703,7 +703,7 @@ int run_types_pos(hipStream_t s, int n, const float* x, int* types, int* pos, in
     hipLaunchKernelGGL(k_type_flags, dim3(g256(n + 1)), dim3(256), 0, s, n, x, types, flags);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, flags, scan, Cnt4{0, 0, 0, 0}, (size_t)(n + 1), Cnt4Plus(), s));
-    if (small) AIG_HIP_CHECK(hipMemsetAsync(small, 0xFF, 3 * sizeof(int), s));
+    if (small) AIG_HIP_CHECK(fill_words(small, 0xFFFFFFFFu, 3 * sizeof(int), s));
     hipLaunchKernelGGL(k_pos, dim3(g256(n)), dim3(256), 0, s, n, types, scan, pos, small);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -871,8 +871,8 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
 
     int rc = run_types_pos(s, N, x, types, pos, nullptr, flags, scan, temp, tb);
     if (rc) return rc;
-    AIG_HIP_CHECK(hipMemsetAsync(counters, 0, 64 * sizeof(int), s));
-    AIG_HIP_CHECK(hipMemsetAsync(indeg, 0, (size_t)(N + 2) * sizeof(int), s));
+    AIG_HIP_CHECK(fill_words(counters, 0u, 64 * sizeof(int), s));
+    AIG_HIP_CHECK(fill_words(indeg, 0u, (size_t)(N + 2) * sizeof(int), s));
     hipLaunchKernelGGL(k_pen_edges, dim3(g256(M)), dim3(256), 0, s, N, M, ei, types, pos, counters, indeg, key64,
                        key_src, key_dst, ids, eflag);
     AIG_LAUNCH_CHECK();
@@ -954,8 +954,8 @@ extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const
     size_t tb = sort_temp<unsigned>(E, 32);
     void* temp = c.take<char>(tb);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
-    AIG_HIP_CHECK(hipMemsetAsync(icnt, 0, (size_t)(N + 2) * 4, s));
-    AIG_HIP_CHECK(hipMemsetAsync(indeg, 0, (size_t)(N + 2) * 4, s));
+    AIG_HIP_CHECK(fill_words(icnt, 0u, (size_t)(N + 2) * 4, s));
+    AIG_HIP_CHECK(fill_words(indeg, 0u, (size_t)(N + 2) * 4, s));
     hipLaunchKernelGGL(k_rs_edges, dim3(g256(M)), dim3(256), 0, s, N, M, ei, reinterpret_cast<const long long*>(edge_attr),
                        icnt, indeg, key, ids);
     AIG_LAUNCH_CHECK();

@@ -15,8 +15,22 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+__global__ void k_fill_words(unsigned* __restrict__ p, unsigned word, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = word;
+}
+}  // namespace
+
+hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s) {
+    const size_t words = bytes / 4;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_words, dim3(grid_for((int64_t)words, 256 * 8, 2048)), dim3(256), 0, s,
+                       static_cast<unsigned*>(p), word, words);
+    return hipGetLastError();
+}
+
 }  // namespace aig
 
-extern "C" int aig_abi_version(void) { return 1; }
+extern "C" int aig_abi_version(void) { return 2; }
 
 extern "C" const char* aig_last_error(void) { return aig::err_buf(); }

@@ -228,7 +228,7 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
     AIG_REQUIRE(dW, "aig_wgrad: null output");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
-        AIG_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)H * F * 4, s));
+        AIG_HIP_CHECK(fill_words(dW, 0u, (size_t)H * F * 4, s));
         return AIG_OK;
     }
     AIG_REQUIRE(g && x && ws, "aig_wgrad: null pointer");

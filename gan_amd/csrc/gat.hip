@@ -804,10 +804,10 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     int4* tab = reinterpret_cast<int4*>(hub_tab);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (E == 0) {
-        AIG_HIP_CHECK(hipMemsetAsync(row_ptr, 0, (size_t)(n + 1) * 4, s));
-        AIG_HIP_CHECK(hipMemsetAsync(col_ptr, 0, (size_t)(n + 1) * 4, s));
-        if (n) AIG_HIP_CHECK(hipMemsetAsync(loop_ea, 0, (size_t)n * 4, s));
-        AIG_HIP_CHECK(hipMemsetAsync(tab, 0, sizeof(int4), s));   // no hubs
+        AIG_HIP_CHECK(fill_words(row_ptr, 0u, (size_t)(n + 1) * 4, s));
+        AIG_HIP_CHECK(fill_words(col_ptr, 0u, (size_t)(n + 1) * 4, s));
+        if (n) AIG_HIP_CHECK(fill_words(loop_ea, 0u, (size_t)n * 4, s));
+        AIG_HIP_CHECK(fill_words(tab, 0u, sizeof(int4), s));   // no hubs
         return AIG_OK;
     }
     AIG_REQUIRE(edge_index && csr_src && csr_ea && csr_eid && csc_pos && csc_dst && ws, "aig_gat_csr: null pointer");
@@ -900,13 +900,13 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
                 "aig_gat_bwd: d_lin_edge_w and d_att_edge come together and need lin_edge_w and att_edge");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
-        AIG_HIP_CHECK(hipMemsetAsync(d_att_src, 0, H * 4, s));
-        AIG_HIP_CHECK(hipMemsetAsync(d_att_dst, 0, H * 4, s));
-        AIG_HIP_CHECK(hipMemsetAsync(d_ce, 0, HEADS * 4, s));
-        AIG_HIP_CHECK(hipMemsetAsync(d_bias, 0, H * 4, s));
+        AIG_HIP_CHECK(fill_words(d_att_src, 0u, H * 4, s));
+        AIG_HIP_CHECK(fill_words(d_att_dst, 0u, H * 4, s));
+        AIG_HIP_CHECK(fill_words(d_ce, 0u, HEADS * 4, s));
+        AIG_HIP_CHECK(fill_words(d_bias, 0u, H * 4, s));
         if (d_lin_edge_w) {
-            AIG_HIP_CHECK(hipMemsetAsync(d_lin_edge_w, 0, H * 4, s));
-            AIG_HIP_CHECK(hipMemsetAsync(d_att_edge, 0, H * 4, s));
+            AIG_HIP_CHECK(fill_words(d_lin_edge_w, 0u, H * 4, s));
+            AIG_HIP_CHECK(fill_words(d_att_edge, 0u, H * 4, s));
         }
         return AIG_OK;
     }

@@ -264,7 +264,7 @@ extern "C" int aig_gen_candidates(int64_t n, int64_t K, const int32_t* types, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     AIG_REQUIRE(eoff, "aig_gen_candidates: null eoff");
     if (n == 0) {
-        AIG_HIP_CHECK(hipMemsetAsync(eoff, 0, 4, s));
+        AIG_HIP_CHECK(fill_words(eoff, 0u, 4, s));
         return AIG_OK;
     }
     AIG_REQUIRE(types && order && rank && want && cnt && cand && fb && ws, "aig_gen_candidates: null pointer");
@@ -281,7 +281,7 @@ extern "C" int aig_gen_candidates(int64_t n, int64_t K, const int32_t* types, co
     int* ne = c.take<int>(n + 1);
     size_t tb = scan_temp_bytes(n + 1);
     void* temp = c.take<char>(tb);
-    AIG_HIP_CHECK(hipMemsetAsync(ne + n, 0, 4, s));
+    AIG_HIP_CHECK(fill_words(ne + n, 0u, 4, s));
     hipLaunchKernelGGL(k_cand_blkid, dim3((nwords * 64 + 255) / 256), dim3(256), 0, s, (int)n, types, rank, blkid, wmin);
     hipLaunchKernelGGL(k_cand_bmax, dim3((nblk * 64 + 255) / 256), dim3(256), 0, s, (int)n, order, bmax);
     hipLaunchKernelGGL(k_cand_prefix, dim3((nblk * 64 + 255) / 256), dim3(256), 0, s, (int)n, (int)K, blkid, wmin,

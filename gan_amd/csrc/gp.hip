@@ -335,7 +335,7 @@ extern "C" int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_m
     AIG_REQUIRE(out, "aig_level_pool_bwd_adj: null output");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (n == 0) {
-        AIG_HIP_CHECK(hipMemsetAsync(out, 0, 2 * H * 4, s));
+        AIG_HIP_CHECK(fill_words(out, 0u, 2 * H * 4, s));
         return AIG_OK;
     }
     AIG_REQUIRE(gg && node_level && w && argmax && ws, "aig_level_pool_bwd_adj: null pointer");

@@ -64,8 +64,7 @@ __global__ void k_level_scan(int n, int L_cap, const long long* __restrict__ dep
         if (over) atomicOr(meta + META_FLAGS, 2);
     }
 }
-// (a kernel rather than two small overlapping hipMemsetAsync calls: recorded in a HIP graph, the 16-byte clear
-// of such a pair was observed not to take effect on replay)
+// (a kernel, not hipMemsetAsync: see fill_words in common.h)
 __global__ void k_level_meta_init(int* __restrict__ meta) {
     if (threadIdx.x < 4) meta[threadIdx.x] = threadIdx.x == META_L ? -1 : 0;
 }
@@ -294,7 +293,7 @@ int level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_
         AIG_LAUNCH_CHECK();
     }
     if (n == 0) {
-        AIG_HIP_CHECK(hipMemsetAsync(lvl_ptr, 0, (size_t)(L + 2) * 4, s));
+        AIG_HIP_CHECK(fill_words(lvl_ptr, 0u, (size_t)(L + 2) * 4, s));
         return AIG_OK;
     }
     AIG_REQUIRE(perm && node_level && w && ws, "aig_level_plan: null pointer");
@@ -349,7 +348,7 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const in
     hipStream_t s = static_cast<hipStream_t>(stream);
     Carver c(ws);
     unsigned long long* table = c.take<unsigned long long>((size_t)(L + 1) * H);
-    AIG_HIP_CHECK(hipMemsetAsync(table, 0, (size_t)(L + 1) * H * 8, s));
+    AIG_HIP_CHECK(fill_words(table, 0u, (size_t)(L + 1) * H * 8, s));
     int blocks = 0;
     float* partial = nullptr;
     if (nvalid > 0) {

@@ -194,12 +194,18 @@ class CapturedCriticTerms:
     recorded ONCE PER MINIBATCH SHAPE as HIP graphs and replayed for every minibatch of that shape.
 
     Every minibatch of a run is padded to ``(max_nodes, max_edges)`` (train.py:200-204), so the real batch
-    always has the same tensor shapes.  Its tensors are copied into fixed buffers (``load``), and everything
-    that depends on their CONTENT is part of the recording: the by-target / by-source edge lists (the builder
-    drops the ``-1`` padding columns itself), the level plan (its level count lives in device memory, see
-    ``DynLevelPlan``), both critic evaluations and their backward passes.  Three graphs: ``prep`` (edge lists +
-    plan, once per step), the real-side term (does not depend on the fakes, so its first replay runs while they
-    are still being generated) and the penalty term.
+    always has the same tensor shapes.  Its tensors are copied into fixed buffers (``load``); what depends on
+    their CONTENT is rebuilt in place, in buffers of fixed address, before the replays: the by-target /
+    by-source edge lists (the builder drops the ``-1`` padding columns itself) and the level plan (its level
+    count lives in device memory, see ``DynLevelPlan``).  Two graphs: the real-side term (does not depend on the
+    fakes, so its first replay runs while they are still being generated) and the penalty term.
+
+    What is recorded is made of this package's kernels and elementwise torch operations only.  The structure
+    builders (device-wide sorts) and anything that reduces through torch are kept out of the recordings: a
+    memset node of a recorded graph writes garbage on this ROCm release from the second replay on
+    (tools/graph_memset_probe2.py), and library sorts and torch's multi-block reductions clear their scratch
+    with memsets.  For the same reason the autograd form of the penalty (``--autograd-gp``) is evaluated
+    eagerly every iteration; only its closed form is recorded.
 
     Together the two terms are about half of the ~1300 kernel launches of a training step, which is bound by
     launch rate rather than by the GPU.  ``loss_D`` is a sum, so its gradient is the replayed gradient plus the
@@ -224,15 +230,9 @@ class CapturedCriticTerms:
         self.real_for_D._csr, self.real_for_D._plan = self.csr, self.plan
         real_pad = Data(x=self.x_real, node_depth=self.depth)
         fake_pad = Data(x=self.x_fake)
-        self.captures = 0
-        self._copy_in(example)
+        self._params = params
+        self.load(example)
         self.x_fake.copy_(self.x_real)
-
-        def prep():
-            if self.csr is not None:
-                self.csr.rebuild(self.ei, self.ea)
-            self.plan.rebuild(self.depth)
-            return count_edges(self.ei)
 
         def compute_real():
             d_real = mean_score(D, self.real_for_D)
@@ -248,36 +248,39 @@ class CapturedCriticTerms:
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha, plan=self.plan)
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
+        self._compute_gp = compute_gp
         cur = torch.cuda.current_stream(device)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):      # sizes the allocator's pools before anything is recorded
             for _ in range(2):
-                prep()
                 compute_real()
                 compute_gp()
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
-        self.graph_prep, self.graph_real, self.graph_gp = (torch.cuda.CUDAGraph() for _ in range(3))
         # thread-local capture: a communicator's watchdog thread may query events while we record
-        with torch.cuda.graph(self.graph_prep, capture_error_mode="thread_local"):
-            self.edges_real = prep()
+        self.graph_real = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_real, capture_error_mode="thread_local"):
             self.d_real, grads_real = compute_real()
-        with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
-            self.gp, self.grad_norm, grads_gp = compute_gp()
-        self.captures = 1
-        self._stages = (prep, compute_real, compute_gp)    # the recorded work, callable eagerly (diagnostics)
-        self._adds = []   # (parameters, recorded gradients) per graph
-        for grads in (grads_real, grads_gp):
-            self._adds.append(([p for p, g in zip(params, grads) if g is not None], [g for g in grads if g is not None]))
-        self.graph_prep.replay()           # the recording itself executes nothing: build the example's structures
+        self._grads_real = self._present(grads_real)
+        self.graph_gp = None
+        if closed_form_gp:
+            self.graph_gp = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
+                self.gp, self.grad_norm, grads_gp = compute_gp()
+            self._grads_gp = self._present(grads_gp)
+
+    def _present(self, grads):
+        """(parameters, gradients) of the parameters a term reaches."""
+        return ([p for p, g in zip(self._params, grads) if g is not None], [g for g in grads if g is not None])
 
     def fits(self, batch: Batch) -> bool:
         e_cols = 0 if batch.edge_index is None else int(batch.edge_index.size(1))
         return int(batch.x.size(0)) == self.n and e_cols == self.e_cols and depth_top(batch) <= self.level_cap
 
-    def _copy_in(self, batch: Batch) -> None:
+    def load(self, batch: Batch) -> None:
+        """Make ``batch`` the real minibatch of the following replays: four copies into the fixed buffers, then
+        its edge lists and level plan rebuilt in place (eagerly: a few dozen launches per training step)."""
         self.x_real.copy_(batch.x)
         if self.e_cols:
             self.ei.copy_(batch.edge_index)
@@ -291,11 +294,14 @@ class CapturedCriticTerms:
             self.depth.copy_(nd)
         else:
             self.depth.zero_()      # no depth vector: every node in one level (discriminator.py:92-96)
-
-    def load(self, batch: Batch) -> None:
-        """Make ``batch`` the real minibatch of the following replays: four copies and one graph launch."""
-        self._copy_in(batch)
-        self.graph_prep.replay()
+        if self.csr is not None:
+            self.csr.rebuild(self.ei, self.ea)
+        self.plan.rebuild(self.depth)
+        # the minibatch's edge count is a property of the minibatch: counted once, kept on the object
+        count = batch.__dict__.get("_edge_count")
+        if count is None:
+            count = batch._edge_count = count_edges(batch.edge_index)
+        self.edges_real = count
 
     def replay_real(self) -> None:
         self.graph_real.replay()
@@ -303,14 +309,18 @@ class CapturedCriticTerms:
     def replay_gp(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
         self.x_fake.copy_(x_fake)
         self.alpha.copy_(alpha.reshape(1, 1))
-        self.graph_gp.replay()
+        if self.graph_gp is not None:
+            self.graph_gp.replay()
+        else:
+            self.gp, self.grad_norm, grads_gp = self._compute_gp()
+            self._grads_gp = self._present(grads_gp)
 
     def replay(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
         self.replay_real()
         self.replay_gp(x_fake, alpha)
 
     def add_gradients(self) -> None:
-        for ps, gs in self._adds:
+        for ps, gs in (self._grads_real, self._grads_gp):
             torch._foreach_add_([p.grad for p in ps], gs)
 
 
