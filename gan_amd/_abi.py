@@ -67,6 +67,7 @@ SIGNATURES = {
     "aig_level_plan_dyn": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),
     "aig_level_pool_fwd": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "aig_level_pool_fwd_noalloc": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P]),
     "aig_enforce_ws_bytes": (SZ, [I64, I64]),
     "aig_enforce": (INT, [I64, I64, P, P, P, INT, P, P, I64, P, P, P, P, P, SZ, P]),
     "aig_penalties_ws_bytes": (SZ, [I64, I64]),

@@ -10,6 +10,7 @@
 // per-block partials added in block order.  No floating-point atomics.
 #include <climits>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -364,4 +365,49 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const in
                        argmax);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The readout for callers that must not allocate: its packed-maximum table and block partials live in a
+// file-scope device array instead of a caller-provided workspace.  Every GPU the library runs on holds its
+// own copy of the array (at its own address) until the process ends.
+namespace {
+static __device__ __align__(256) unsigned char scratch[AIG_NOALLOC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[MAX_DEVICES] = {};   // device address of `scratch` on device d, once looked up there
+
+// Device address of this device's copy of `scratch`.  The array's name is only a host-side handle: the address
+// comes from hipGetSymbolAddress, asked once per device with that device current.
+int scratch_address(void** out) {
+    int dev = -1;
+    AIG_HIP_CHECK(hipGetDevice(&dev));
+    AIG_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "aig_level_pool_fwd_noalloc: device index %d beyond %d", dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        AIG_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        AIG_REQUIRE(p != nullptr, "aig_level_pool_fwd_noalloc: no device address for the scratch array");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return AIG_OK;
+}
+}  // namespace
+
+extern "C" int aig_level_pool_fwd_noalloc(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                                          const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level,
+                                          const float* w, float* out, int32_t* argmax, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && L < INT_MAX - 2, "aig_level_pool_fwd_noalloc: bad sizes");
+    const size_t need = aig_level_pool_fwd_ws_bytes(n, L);
+    if (need > (size_t)AIG_NOALLOC_SCRATCH_BYTES)
+        return fail(AIG_ELIMIT, "aig_level_pool_fwd_noalloc: n=%lld nodes with %lld levels need %zu bytes of scratch, the "
+                    "built-in array holds %zu (use aig_level_pool_fwd with a workspace of your own)",
+                    (long long)n, (long long)L + 1, need, (size_t)AIG_NOALLOC_SCRATCH_BYTES);
+    void* ptr = nullptr;
+    if (int rc = scratch_address(&ptr)) return rc;
+    // the array keeps the previous call's contents: aig_level_pool_fwd clears the table it carves out of it
+    return aig_level_pool_fwd(n, nvalid, L, lvl_meta, h, perm, lvl_ptr, node_level, w, out, argmax, ptr,
+                              (size_t)AIG_NOALLOC_SCRATCH_BYTES, stream);
 }

@@ -33,6 +33,7 @@ extern "C" {
 #define AIG_ELIMIT (-4)      /* size beyond a documented limit */
 
 #define AIG_MAX_CANDIDATE_K 1024 /* candidate window limit of the generator kernels */
+#define AIG_NOALLOC_SCRATCH_BYTES (4u << 20) /* built-in scratch of aig_level_pool_fwd_noalloc, per GPU */
 #define AIG_HIDDEN 128           /* hidden width the kernels are built for (reference default) */
 
 int aig_abi_version(void);
@@ -238,6 +239,20 @@ size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L);
 int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
                        const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
                        float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+
+/* The same readout for callers that cannot allocate device memory or are not allowed to - code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (which allocates
+ * freely through torch): same arguments and results as aig_level_pool_fwd, without the workspace.  The table of
+ * level maxima and the block partials live in an array built into the library, AIG_NOALLOC_SCRATCH_BYTES (4 MiB) on
+ * every GPU the library runs on, held until the process ends; the call performs no hipMalloc / hipFree and calls no
+ * allocating routine.  Limit: aig_level_pool_fwd_ws_bytes(n, L) <= AIG_NOALLOC_SCRATCH_BYTES (e.g. one million nodes
+ * with up to 2,000 levels, or 100,000 nodes with 3,900); beyond it the call returns AIG_ELIMIT and touches nothing.
+ * All calls on one GPU share that GPU's array: it keeps the last call's contents (the call clears what it needs
+ * zeroed itself), and two calls whose kernels overlap in time on one GPU - different streams, different host
+ * threads - race on it.  Serialise them, or use aig_level_pool_fwd with separate workspaces. */
+int aig_level_pool_fwd_noalloc(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                               const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
+                               float* out, int32_t* argmax, void* stream);
 
 /* Backward of the readout (what autograd derives from discriminator.py:64-91): with g = dLoss/d out [256],
  *   d_h[i,c] = w[i] g[c] + [argmax[level(i),c] == i] g[128+c] / (L+1)
