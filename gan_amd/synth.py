@@ -50,7 +50,7 @@ def _longest_path_levels(n: int, src: np.ndarray, dst: np.ndarray) -> np.ndarray
 
 
 def synth_aig_arrays(n_pi: int, n_and: int, n_po: int, seed: int = 0, window: int = 4096,
-                     orientation: str = "forward") -> Dict[str, np.ndarray]:
+                     orientation: str = "forward", compute_depth: bool = True) -> Dict[str, np.ndarray]:
     if n_pi < 2 and n_and > 0:
         raise ValueError("need at least 2 primary inputs to give an AND two distinct fan-ins")
     rng = np.random.default_rng(seed)
@@ -79,7 +79,8 @@ def synth_aig_arrays(n_pi: int, n_and: int, n_po: int, seed: int = 0, window: in
         e_src, e_dst = dst, src                            # gate -> fan-in
     else:
         raise ValueError(f"unknown orientation {orientation!r}")
-    depth = _longest_path_levels(n, e_src, e_dst)
+    # (the level sweep is the slow part at a million nodes: a caller that takes depths from elsewhere skips it)
+    depth = _longest_path_levels(n, e_src, e_dst) if compute_depth else np.zeros(n, dtype=np.int64)
     x = np.stack([types, inv_cnt], 1).astype(np.float32)
     return {
         "x": x,
@@ -90,10 +91,11 @@ def synth_aig_arrays(n_pi: int, n_and: int, n_po: int, seed: int = 0, window: in
 
 
 def synth_aig(n_pi: int, n_and: int, n_po: int, seed: int = 0, window: int = 4096,
-              orientation: str = "forward", shuffle_ids: bool = False) -> Data:
+              orientation: str = "forward", shuffle_ids: bool = False, compute_depth: bool = True) -> Data:
     """One synthetic AIG as a ``Data``.  ``shuffle_ids`` relabels nodes at random
-    (types no longer grouped), which exercises the rank != index paths."""
-    a = synth_aig_arrays(n_pi, n_and, n_po, seed, window, orientation)
+    (types no longer grouped), which exercises the rank != index paths.  ``compute_depth=False`` leaves
+    ``node_depth`` at zero."""
+    a = synth_aig_arrays(n_pi, n_and, n_po, seed, window, orientation, compute_depth)
     if shuffle_ids:
         rng = np.random.default_rng(seed + 7919)
         n = a["x"].shape[0]

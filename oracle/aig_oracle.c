@@ -59,9 +59,12 @@ int orc_build_order(int64_t n, const int64_t *types, const double *depth, int64_
  * ------------------------------------------------------------------------------------------ */
 int64_t orc_candidates(int64_t n, const int64_t *types, const int64_t *order, int64_t K,
                        int64_t *tgt, int64_t *cand, int64_t *cnt, int64_t *fb) {
-    int64_t *sorted = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1)); /* seen non-PO ids, ascending */
-    int64_t ns = 0, max_seen = -1, T = 0;
-    if (!sorted) return -1;
+    /* Only the K largest seen non-PO ids can ever enter a window (generator.py:157-158 keeps cand_idx[-K:] of the
+     * ascending id list), so that is all that is kept: `top` holds them ascending, `ns` counts every seen one. */
+    int64_t cap = K > 0 ? K : 1;
+    int64_t *top = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    int64_t ntop = 0, ns = 0, max_seen = -1, T = 0;
+    if (!top) return -1;
     for (int64_t r = 0; r < n; ++r) {
         int64_t v = order[r];
         if (types[v] != PI_T) {
@@ -69,19 +72,27 @@ int64_t orc_candidates(int64_t n, const int64_t *types, const int64_t *order, in
             tgt[T] = v;
             cnt[T] = c;
             fb[T] = (c == 0) ? max_seen : -1;
-            for (int64_t j = 0; j < c; ++j) cand[T * K + j] = sorted[ns - c + j];
+            for (int64_t j = 0; j < c; ++j) cand[T * K + j] = top[ntop - c + j];
             ++T;
         }
         if (v > max_seen) max_seen = v;
         if (types[v] != PO_T) { /* becomes a possible source */
-            int64_t lo = 0, hi = ns;
-            while (lo < hi) { int64_t m = (lo + hi) / 2; if (sorted[m] < v) lo = m + 1; else hi = m; }
-            memmove(sorted + lo + 1, sorted + lo, sizeof(int64_t) * (size_t)(ns - lo));
-            sorted[lo] = v;
             ++ns;
+            if (K > 0 && (ntop < K || v > top[0])) {
+                int64_t lo = 0, hi = ntop;
+                while (lo < hi) { int64_t m = (lo + hi) / 2; if (top[m] < v) lo = m + 1; else hi = m; }
+                if (ntop < K) {          /* room left: shift the tail up */
+                    memmove(top + lo + 1, top + lo, sizeof(int64_t) * (size_t)(ntop - lo));
+                    top[lo] = v;
+                    ++ntop;
+                } else {                 /* full: the smallest drops out, everything below the slot shifts down */
+                    memmove(top, top + 1, sizeof(int64_t) * (size_t)(lo - 1));
+                    top[lo - 1] = v;
+                }
+            }
         }
     }
-    free(sorted);
+    free(top);
     return T;
 }
 

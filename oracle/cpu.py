@@ -116,10 +116,25 @@ def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def node_proj(state, x: np.ndarray, z: np.ndarray):
-    """Position-independent node pipeline (see aig_oracle.c) -> (h_cond [n,128], proj [4,n,128])."""
+def node_proj(state, x: np.ndarray, z: np.ndarray, dedup_rows: Optional[bool] = None):
+    """Position-independent node pipeline (see aig_oracle.c) -> (h_cond [n,128], proj [4,n,128]).
+
+    The pipeline is a function of a node's own feature row (and z) alone, evaluated by one fixed chain of
+    operations per row, so equal rows give equal bits: with ``dedup_rows`` (default: from 4096 rows on) it is
+    evaluated once per DISTINCT row and copied out - what makes million-node templates checkable in seconds
+    (AIG features take a handful of distinct values)."""
     x, z = _f32(x), _f32(z).reshape(-1)
     n = int(x.shape[0])
+    if dedup_rows is None:
+        dedup_rows = n >= 4096
+    if dedup_rows and n > 0:
+        # rows compared by their bits (so that -0.0 / NaN payloads are not merged with their look-alikes)
+        keys = np.ascontiguousarray(x).view(np.uint32).reshape(n, -1)
+        uniq, inverse = np.unique(keys, axis=0, return_inverse=True)
+        if uniq.shape[0] < n:
+            h_u, proj_u = node_proj(state, uniq.view(np.float32), z, dedup_rows=False)
+            inverse = inverse.reshape(-1)
+            return h_u[inverse], proj_u[:, inverse]
     ws = []
     for k in GEN_KEYS:
         ws += [_f32(state[k + ".weight"]), _f32(state[k + ".bias"])]
