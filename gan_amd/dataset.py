@@ -11,8 +11,11 @@ Behaviour follows utilities/data_process.py of the reference:
   the padded size otherwise - private attributes do not survive ``Batch.from_data_list`` /
   ``to_data_list``, which is how the reference's training templates stay padded;
 * files carry the plain dict ``{x, edge_index, edge_attr, node_depth}`` (the form the
-  reference's exporters accept too); a pickled torch_geometric object is only read when
-  torch_geometric itself can be imported.
+  reference's exporters accept too).  A pickled torch_geometric object - what the reference's own
+  ``torch.load(..., weights_only=False)`` reads (:18) - executes code from the file when loaded, so it is read
+  only when the caller says the files are trusted (``allow_pickle=True``, ``--allow-pickle`` on the CLIs) and
+  torch_geometric itself can be imported.  The other direction is one-way too: samples written here are plain
+  dicts, which the reference's exporters read but its ``load_pt_dataset`` skips (it keeps ``Data`` instances only).
 """
 from __future__ import annotations
 
@@ -40,21 +43,24 @@ def _to_graph(obj: Any) -> Optional[Data]:
     return None
 
 
-def _read(path: str):
+def _read(path: str, allow_pickle: bool = False):
     try:
         return torch.load(path, weights_only=True)
     except Exception:
+        if not allow_pickle:
+            raise
         import torch_geometric  # noqa: F401 - unpickling a PyG object needs its classes
         return torch.load(path, weights_only=False)
 
 
-def load_pt_dataset(dataset_dir: str, max_files: Optional[int] = None) -> List[Data]:
+def load_pt_dataset(dataset_dir: str, max_files: Optional[int] = None, allow_pickle: bool = False) -> List[Data]:
     """Graphs of every ``*.pt`` under ``dataset_dir`` in sorted file order; unreadable files are
-    reported and skipped."""
+    reported and skipped.  ``allow_pickle``: also read files that only a full unpickle can read (trusted
+    files only: unpickling runs code from the file)."""
     graphs: List[Data] = []
     for path in sorted(glob.glob(os.path.join(dataset_dir, "*.pt")))[:max_files]:
         try:
-            g = _to_graph(_read(path))
+            g = _to_graph(_read(path, allow_pickle))
         except Exception as exc:
             print(f"[WARN] failed loading {path}: {exc}")
             continue

@@ -102,6 +102,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--num-samples", type=int, default=1, help="extension: bulk sampling")
     ap.add_argument("--in-flight", type=int, default=4, help="extension: samples kept in flight during bulk sampling")
+    ap.add_argument("--allow-pickle", action="store_true",
+                    help="extension: also read dataset files that need a full unpickle (trusted files only)")
     return ap
 
 
@@ -115,7 +117,7 @@ def main(argv=None) -> None:
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
 
-    dataset = load_pt_dataset(args.dataset_dir, max_files=None)
+    dataset = load_pt_dataset(args.dataset_dir, max_files=None, allow_pickle=args.allow_pickle)
     if len(dataset) == 0:
         raise RuntimeError(f"No .pt files in {args.dataset_dir}")
     tpl = dataset[min(args.template_idx, len(dataset) - 1)].to(device)

@@ -567,7 +567,7 @@ def train(args) -> None:
         torch.manual_seed(args.seed)
         torch.cuda.manual_seed_all(args.seed)
 
-    data_list = load_pt_dataset(args.dataset_dir, max_files=args.max_files)
+    data_list = load_pt_dataset(args.dataset_dir, max_files=args.max_files, allow_pickle=getattr(args, "allow_pickle", False))
     if len(data_list) == 0:
         raise RuntimeError("No .pt files found in dataset_dir")
     max_nodes = max(d.x.size(0) for d in data_list) if args.max_nodes is None else args.max_nodes
@@ -640,6 +640,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--unpad-templates", action="store_true",
                    help="Strip padding rows from templates (the reference keeps them padded).")
     p.add_argument("--no-progress", action="store_true")
+    p.add_argument("--allow-pickle", action="store_true",
+                   help="also read dataset files that need a full unpickle (pickled torch_geometric objects); trusted files only")
     p.add_argument("--autograd-gp", dest="closed_form_gp", action="store_false",
                    help="compute the gradient penalty by double backward (autograd) instead of its closed form")
     p.add_argument("--no-overlap", dest="no_overlap", action="store_true",
