@@ -99,39 +99,73 @@ def gat_fwd_bytes(n: int, e: int) -> int:
 
 
 def cpu_baseline(seconds_budget: float = 25.0):
-    """One training step of the CPU checker on a bounded sample (10k-node synthetic AIG)."""
+    """The CPU checker (the oracle this repository holds its kernels to: kind "port") timed on this host on
+    BASELINE.json's CPU configuration: the eleven ISCAS85-sized graphs, one epoch of ``train.py`` steps at
+    batch-size 1 (templates keep the padded size, as in the reference) and one ``AIGgan.py`` sample per graph at
+    candidate-k 64 - once on ONE torch thread and once on all the cores this process may use.  The reference's
+    own Python path cannot run here (it imports torch_geometric); the timings measured for it on the same kind of
+    graph when this work was surveyed are quoted as ``reference_python``."""
     import numpy as np
-    from gan_amd.data import Batch
+    from gan_amd.data import Batch, Data
     from gan_amd.dataset import pad_data, unpad_data
-    from gan_amd.synth import synth_aig
+    from gan_amd.synth import iscas85_like, synth_aig
+    from oracle import cpu as ocpu
     from oracle import model as omodel
     from oracle.train_oracle import CpuTrainer
-    n_and = 9800
-    g = synth_aig(100, n_and, 100, seed=0, window=1024, orientation="dataset")
-    mn, me = g.x.size(0), g.edge_index.size(1)
-    real = Batch.from_data_list([pad_data(g, mn, me)])
     w = np.load(os.path.join(ROOT, "tests", "golden", "gen_weights.npz"))
     gs = {k: torch.from_numpy(w[k]) for k in w.files}
-    tr = CpuTrainer(gs, omodel.init_discriminator_params(0), 64, mn, me)
+    graphs = iscas85_like(seed=0)
+    mn = max(g.x.size(0) for g in graphs)
+    me = max(g.edge_index.size(1) for g in graphs)
+    padded = [pad_data(g, mn, me) for g in graphs]
     gen = torch.Generator().manual_seed(0)
     zs = [torch.randn(128, generator=gen) for _ in range(2)]
     alphas = [torch.rand(1, 1, generator=gen) for _ in range(3)]
-    templates = [unpad_data(d) for d in real.to_data_list()]
-    threads = torch.get_num_threads()
+    all_cores = torch.get_num_threads()
+
+    def epoch_and_samples(threads):
+        torch.set_num_threads(threads)
+        tr = CpuTrainer(gs, omodel.init_discriminator_params(0), 64, mn, me)
+        t0 = time.perf_counter()
+        edges = 0
+        for p in padded:
+            real = Batch.from_data_list([p])
+            templates = [unpad_data(d) for d in real.to_data_list()]
+            edges += tr.step(real, templates, zs[:1], zs[1:], alphas, validate=False)["edges"]
+        t_train = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        nodes = 0
+        for g in graphs:
+            raw = omodel.generator_forward_canonical(gs, g.x, g.node_depth, zs[0], 64)
+            d = Data(x=raw["x"], edge_index=raw["edge_index"], edge_attr=raw["edge_attr"], node_depth=g.node_depth.clone())
+            ocpu.resync_attrs(ocpu.enforce_aig_constraints(d))
+            nodes += int(g.x.size(0))
+        t_sample = time.perf_counter() - t0
+        return {"threads": threads, "train_edges_per_sec": round(edges / t_train, 1), "epoch_seconds": round(t_train, 3),
+                "sample_nodes_per_sec": round(nodes / t_sample, 1), "sample_seconds": round(t_sample, 3)}
+
+    one = epoch_and_samples(1)
+    many = epoch_and_samples(all_cores) if all_cores > 1 else one
+    torch.set_num_threads(all_cores)
+    best = max((one, many), key=lambda r: r["train_edges_per_sec"])
+    # secondary datum: one step on a 10k-node graph (the size at which the CPU step still takes seconds)
+    g10 = synth_aig(100, 9800, 100, seed=0, window=1024, orientation="dataset")
+    real10 = Batch.from_data_list([pad_data(g10, g10.x.size(0), g10.edge_index.size(1))])
+    tr10 = CpuTrainer(gs, omodel.init_discriminator_params(0), 64, g10.x.size(0), g10.edge_index.size(1))
     t0 = time.perf_counter()
-    steps = 0
-    edges = 0
-    while True:
-        m = tr.step(real, templates, zs[:1], zs[1:], alphas, validate=False)
-        edges += m["edges"]
-        steps += 1
-        if time.perf_counter() - t0 > seconds_budget * 0.5 or steps >= 3:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": edges / dt, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} full training step(s) of the CPU checker on a 10k-node synthetic AIG "
-                      f"(100 PI / {n_and} AND / 100 PO, candidate-k 64), {dt:.1f} s; dense critic ops on "
-                      f"{threads} torch threads, generator/constraint checker single-threaded C"}
+    m10 = tr10.step(real10, [unpad_data(d) for d in real10.to_data_list()], zs[:1], zs[1:], alphas, validate=False)
+    t10 = time.perf_counter() - t0
+    return {"value": best["train_edges_per_sec"], "unit": "edges/s", "cores": best["threads"], "kind": "port",
+            "sample": f"one epoch of train.py steps (11 steps, batch-size 1, graphs padded to {mn} nodes / {me} edges) plus one "
+                      "AIGgan.py sample per graph at candidate-k 64 on the eleven ISCAS85-sized synthetic graphs, CPU checker "
+                      "(generator / constraints: single-threaded C; critic: torch CPU ops on the stated threads)",
+            "one_thread": one, "all_cores": many, "host_threads_available": all_cores,
+            "step_on_10k_node_graph": {"edges_per_sec": round(m10["edges"] / t10, 1), "seconds": round(t10, 2), "threads": all_cores},
+            "reference_python": {"note": "the reference's unmodified Python path, measured when the work was surveyed (1 CPU thread, "
+                                         "synthetic forward AIGs, candidate-k 64); it cannot be run on this box",
+                                 "AIGGenerator.forward": "0.843 s at 2,300 nodes (2,728 nodes/s); 0.171 s at 486 nodes",
+                                 "enforce_aig_constraints": "107 s at 2,300 nodes; 4.16 s at 486 nodes (quadratic)",
+                                 "aig_constraint_penalties / validate_strict_aig": "0.061 s / 0.162 s at 2,300 nodes"}}
 
 
 def side_workload(name: str, dev, steps: int, warmup: int):

@@ -58,6 +58,10 @@ inline int grid_for(int64_t items, int per_block, int cap = 1 << 20) {
 // its range from the second replay on (tools/graph_memset_probe2.py), and every entry point here may be recorded.
 hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s);
 
+// Raises `kernel`'s dynamic-LDS limit to at least `bytes` on the CURRENT device, once per kernel and device
+// (a kernel attribute belongs to the device's copy of the code object); safe to call from several threads.
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not

@@ -427,13 +427,7 @@ int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* re
         AIG_LAUNCH_CHECK();
         return AIG_OK;
     }
-    static bool attr_set = false;  // idempotent; racing threads set the same value
-    if (!attr_set) {
-        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<MODE>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (TRAV_LDS_MAX_N / 8) + 2 * TRAV_QCAP * 4));
-        attr_set = true;
-    }
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_traverse_lds<MODE>), (size_t)((TRAV_LDS_MAX_N / 8) + 2 * TRAV_QCAP * 4)));
     const int g = (N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096;
     hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[0].ptr, jobs.j[0].adj, rec0);
     if (njobs > 1) hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[1].ptr, jobs.j[1].adj, rec1);

@@ -1,4 +1,7 @@
 // Error reporting and version of libaig_hip.so.
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace aig {
@@ -20,6 +23,30 @@ __global__ void k_fill_words(unsigned* __restrict__ p, unsigned word, size_t wor
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = word;
 }
 }  // namespace
+
+// (kernel, device) pairs whose dynamic-LDS limit has been raised, and to how much
+namespace {
+struct LdsGrant { const void* kernel; int device; size_t bytes; };
+std::mutex g_lds_mutex;
+std::vector<LdsGrant> g_lds_grants;
+}  // namespace
+
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    for (LdsGrant& g : g_lds_grants)
+        if (g.kernel == kernel && g.device == dev) {
+            if (g.bytes >= bytes) return hipSuccess;
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) g.bytes = bytes;
+            return e;
+        }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) g_lds_grants.push_back({kernel, dev, bytes});
+    return e;
+}
 
 hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s) {
     const size_t words = bytes / 4;

@@ -236,12 +236,7 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
     float* partial = static_cast<float*>(ws);
     int nb;
     if (F == 128) {
-        static bool attr_set = false;  // idempotent; racing threads set the same value
-        if (!attr_set) {
-            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad128),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGRAD_LDS));
-            attr_set = true;
-        }
+        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wgrad128), (size_t)(WGRAD_LDS)));
         nb = wg_blocks(n, 2 * TILE, WG_BLOCKS_MAX);
         hipLaunchKernelGGL(k_wgrad128, dim3(nb), dim3(256), WGRAD_LDS, s, (int)n, g, x, partial);
     } else if (F == 1) {

@@ -495,12 +495,7 @@ constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * H) * sizeof(float);
 
 template <int ACT>
 int launch_linear(hipStream_t s, int M, const float* X, const Chunk& ck) {
-    static bool attr_set = false;  // raising the dynamic LDS limit is idempotent; racing threads set the same value
-    if (!attr_set) {
-        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear128<ACT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LINEAR_LDS));
-        attr_set = true;
-    }
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128<ACT>), (size_t)(LINEAR_LDS)));
     int ntiles = (M + BM - 1) / BM;
     int gx = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL((k_linear128<ACT>), dim3(gx), dim3(THREADS), LINEAR_LDS, s, M, X, ck);
@@ -548,12 +543,7 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
     // block of node_proj.0 is the bias vector zb[0]) in one pass over the rows
     float* hc = h_cond ? h_cond : bufA;
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node_mlp3),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)MLP3_LDS));
-            attr_set = true;
-        }
+        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_node_mlp3), (size_t)(MLP3_LDS)));
         Mlp3 p{};
         p.x = x;
         p.enc0_w = w->enc0_w;
@@ -572,12 +562,7 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
     // first Linear of both edge MLPs, split into source block / target block (+ z block and bias)
     const size_t plane = static_cast<size_t>(n) * H;
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node_proj4),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)PROJ4_LDS));
-            attr_set = true;
-        }
+        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_node_proj4), (size_t)(PROJ4_LDS)));
         Proj4 q{};
         q.x = hc;
         q.w[0] = w->sc0_w;     q.b[0] = zb + 3 * H; q.out[0] = proj;

@@ -420,12 +420,7 @@ extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const i
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (K <= 128) {
         const size_t lds = (size_t)(K + SCORE_T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
-        static size_t lds_allowed = 0;   // raising the dynamic LDS limit is idempotent
-        if (lds > lds_allowed) {
-            AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_tiled),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_allowed = lds;
-        }
+        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled), lds));
         const int64_t tb = (n + SCORE_T - 1) / SCORE_T;
         hipLaunchKernelGGL(k_score_tiled, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, order, rank, cnt, cand,
                            projA, projB, w2, b2, logits);
@@ -448,12 +443,7 @@ extern "C" int aig_topk_select(int64_t rows, int64_t ld, const float* logits, co
     if (rows == 0) return AIG_OK;
     AIG_REQUIRE(logits && cnt && want && sel, "aig_topk_select: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AIG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_topk_select),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEL_LDS));
-        attr_set = true;
-    }
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select), (size_t)(SEL_LDS)));
     int64_t blocks = (rows + SEL_THREADS - 1) / SEL_THREADS;
     const int cap = ld < SEL_CAP ? (int)ld : SEL_CAP;
     hipLaunchKernelGGL(k_topk_select, dim3((unsigned)blocks), dim3(SEL_THREADS), sel_lds(cap), s, (int)rows, (int)ld, cap,
