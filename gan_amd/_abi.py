@@ -37,6 +37,8 @@ SIGNATURES = {
     "aig_gen_candidates": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
     "aig_gen_node_proj_ws_bytes": (SZ, [I64]),
     "aig_gen_node_proj": (INT, [I64, P, P, C.POINTER(GenWeights), P, P, P, SZ, P]),
+    "aig_gen_node_proj_bf16_ws_bytes": (SZ, [I64]),
+    "aig_gen_node_proj_bf16": (INT, [I64, I64, P, P, C.POINTER(GenWeights), P, P, P, SZ, P]),
     "aig_gen_score": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, P]),
     "aig_topk_select_ws_bytes": (SZ, [I64, I64]),
     "aig_topk_select": (INT, [I64, I64, P, P, P, P, P, SZ, P]),

@@ -491,6 +491,167 @@ __global__ __launch_bounds__(THREADS) void k_node_proj4(int M, int rpb, Proj4 p)
     else drain_all<8>(Drain{s1, p.out[3], prev_row0, M}, tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same node pipeline on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, f32 accumulate): inputs of
+// every product - activations and weights - are rounded to bf16 (round to nearest even), sums, biases
+// and activations stay f32, outputs are stored as f32.  One kernel for all seven 128x128 products of a
+// 64-row tile: a wave owns 32 output columns of every layer and keeps their weights, packed as matrix
+// fragments, in registers (7 x 32 registers); tiles go LDS -> LDS between layers as bf16, an f32 staging
+// tile turns each output into whole 512-byte rows for the store.  Eight products per 32x32 block instead
+// of 64, so the kernel is bound by the 2 KB of output per row, not by the matrix cores.  As in the f32
+// pipeline a result depends on its own input row only (one fixed chain of operations per element), so
+// equal rows give equal bits wherever they sit.
+// Rows may belong to several samples of one template that differ in z alone (bulk sampling): then the
+// z-dependent bias vectors are per sample, and a tile never straddles two samples.
+// ---------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+constexpr int BF_LD = H + 8;    // bf16 elements per LDS row: 272 bytes, rows stay 16-byte aligned
+constexpr int ST_LD = H + 4;    // floats per row of the staging tile
+constexpr int PIPE_LAYERS = 7;  // enc2, proj0 (node half), proj2, scorer src / tgt, attr src / tgt
+constexpr size_t PIPE_LDS = 2 * BM * BF_LD * sizeof(__bf16) + BM * ST_LD * sizeof(float);
+
+struct PipeBf16 {
+    const float* x;        // [x_rows][2]
+    const float* enc0_w;   // [128][2]
+    const float* enc0_b;   // [128]
+    const __bf16* wpack;   // [7][4 waves][8 steps][64 lanes][8]: fragment-major weights
+    const float* b[PIPE_LAYERS];     // bias vectors (never null)
+    int zdep[PIPE_LAYERS];           // 1: the vector depends on z - sample s uses b + s * zstride
+    int zstride;
+    int rows_per_sample;   // 0: one sample; else tile t belongs to sample t*64 / rows_per_sample and reads x row (row % rows_per_sample)
+    float* h_cond;         // [M][128] or null
+    float* out[4];         // [M][128] each
+};
+
+// wpack[l][wave][s][lane][j] = bf16(W_l[wave*32 + (lane & 31)][16 s + 8 (lane >> 5) + j])
+struct PackSrc {
+    const float* w[PIPE_LAYERS];
+    int ldw[PIPE_LAYERS];
+};
+__global__ void k_pack_bf16(PackSrc src, __bf16* __restrict__ wpack) {
+    const int l = blockIdx.x / 8, idx = (blockIdx.x % 8) * 256 + threadIdx.x;  // 4 waves x 8 steps x 64 lanes fragments a layer
+    const int lane = idx & 63, s = (idx >> 6) & 7, wave = idx >> 9;
+    const float* row = src.w[l] + static_cast<size_t>(wave * 32 + (lane & 31)) * src.ldw[l] + 16 * s + 8 * (lane >> 5);
+    const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+    bf16x8 v;
+    v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+    v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    *reinterpret_cast<bf16x8*>(wpack + (static_cast<size_t>(l) * 2048 + idx) * 8) = v;
+}
+
+// one layer of a 64-row tile: acc = tile W^T (A operand = the wave's weight fragments, B operand = tile rows,
+// so a lane ends up with four groups of four consecutive output columns of tile rows frow and frow + 32)
+template <bool RELU, bool TO_BF16, bool TO_STAGE>
+__device__ __forceinline__ void pipe_layer(const __bf16* tin, const bf16x8 (&w)[8], const float* __restrict__ bias,
+                                           __bf16* tout, float* stage, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, frow = lane & 31, fh = lane >> 5;
+    f32x16 acc0 = {0}, acc1 = {0};
+    const __bf16* r0 = tin + frow * BF_LD + 8 * fh;
+    const __bf16* r1 = r0 + 32 * BF_LD;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(r0 + 16 * s);
+        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(r1 + 16 * s);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], x0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], x1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = wave * 32 + 8 * q + 4 * fh;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+        float4 y0 = make_float4(acc0[4 * q] + bv.x, acc0[4 * q + 1] + bv.y, acc0[4 * q + 2] + bv.z, acc0[4 * q + 3] + bv.w);
+        float4 y1 = make_float4(acc1[4 * q] + bv.x, acc1[4 * q + 1] + bv.y, acc1[4 * q + 2] + bv.z, acc1[4 * q + 3] + bv.w);
+        if (RELU) {
+            y0 = make_float4(fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f), fmaxf(y0.z, 0.f), fmaxf(y0.w, 0.f));
+            y1 = make_float4(fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f), fmaxf(y1.z, 0.f), fmaxf(y1.w, 0.f));
+        }
+        if (TO_BF16) {
+            bf16x4 p0, p1;
+            p0[0] = (__bf16)y0.x; p0[1] = (__bf16)y0.y; p0[2] = (__bf16)y0.z; p0[3] = (__bf16)y0.w;
+            p1[0] = (__bf16)y1.x; p1[1] = (__bf16)y1.y; p1[2] = (__bf16)y1.z; p1[3] = (__bf16)y1.w;
+            *reinterpret_cast<bf16x4*>(tout + frow * BF_LD + col) = p0;
+            *reinterpret_cast<bf16x4*>(tout + (frow + 32) * BF_LD + col) = p1;
+        }
+        if (TO_STAGE) {
+            *reinterpret_cast<float4*>(stage + frow * ST_LD + col) = y0;
+            *reinterpret_cast<float4*>(stage + (frow + 32) * ST_LD + col) = y1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void k_node_pipe_bf16(int M, PipeBf16 p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipe[];
+    __bf16* const t0 = reinterpret_cast<__bf16*>(smem_pipe);
+    __bf16* const t1 = t0 + BM * BF_LD;
+    float* const stage = reinterpret_cast<float*>(t1 + BM * BF_LD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16x8 wr[PIPE_LAYERS][8];
+#pragma unroll
+    for (int l = 0; l < PIPE_LAYERS; ++l)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            wr[l][s] = *reinterpret_cast<const bf16x8*>(p.wpack + ((static_cast<size_t>(l) * 4 + wave) * 8 + s) * 512 + lane * 8);
+    const int c4 = tid & 31;
+    float e0[4], e1[4], eb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        e0[u] = p.enc0_w[2 * (c4 * 4 + u)];
+        e1[u] = p.enc0_w[2 * (c4 * 4 + u) + 1];
+        eb[u] = p.enc0_b[c4 * 4 + u];
+    }
+    const int ntiles = (M + BM - 1) / BM;
+    // rows of the staging tile -> global rows row0 .. (rows past M are not stored)
+    auto drain = [&](float* gout, int row0) {
+#pragma unroll
+        for (int q = 0; q < BM / 8; ++q) {
+            const int row = q * 8 + (tid >> 5);
+            if (row0 + row < M)
+                *reinterpret_cast<float4*>(gout + static_cast<size_t>(row0 + row) * H + 4 * c4) =
+                    *reinterpret_cast<const float4*>(stage + row * ST_LD + 4 * c4);
+        }
+    };
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * BM;
+        const int sample = p.rows_per_sample > 0 ? row0 / p.rows_per_sample : 0;
+        const int xrow0 = row0 - sample * p.rows_per_sample;
+        const int xlimit = p.rows_per_sample > 0 ? p.rows_per_sample : M;
+        const float* bias[PIPE_LAYERS];
+#pragma unroll
+        for (int l = 0; l < PIPE_LAYERS; ++l) bias[l] = p.b[l] + (p.zdep[l] ? static_cast<size_t>(sample) * p.zstride : 0);
+        // enc0 = Linear(2,128) + ReLU in f32, rounded to bf16 into t0 (rows past the end repeat the last row)
+#pragma unroll
+        for (int q = 0; q < BM / 8; ++q) {
+            const int row = q * 8 + (tid >> 5);
+            const float2 xv = *reinterpret_cast<const float2*>(p.x + static_cast<size_t>(min(xrow0 + row, xlimit - 1)) * 2);
+            bf16x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = (__bf16)fmaxf(fmaf(xv.y, e1[u], xv.x * e0[u]) + eb[u], 0.f);
+            *reinterpret_cast<bf16x4*>(t0 + row * BF_LD + 4 * c4) = o;
+        }
+        __syncthreads();
+        pipe_layer<true, true, false>(t0, wr[0], bias[0], t1, stage, tid);
+        __syncthreads();
+        pipe_layer<true, true, false>(t1, wr[1], bias[1], t0, stage, tid);
+        __syncthreads();
+        if (p.h_cond) {
+            pipe_layer<true, true, true>(t0, wr[2], bias[2], t1, stage, tid);
+            __syncthreads();
+            drain(p.h_cond, row0);
+        } else {
+            pipe_layer<true, true, false>(t0, wr[2], bias[2], t1, stage, tid);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            pipe_layer<false, false, true>(t1, wr[3 + o], bias[3 + o], t0, stage, tid);
+            __syncthreads();
+            drain(p.out[o], row0);
+            __syncthreads();
+        }
+    }
+}
+
 constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * H) * sizeof(float);
 
 template <int ACT>
@@ -574,6 +735,71 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
         hipLaunchKernelGGL(k_node_proj4, dim3((M + rpb - 1) / rpb), dim3(THREADS), PROJ4_LDS, s, M, rpb, q);
         AIG_LAUNCH_CHECK();
     }
+    return AIG_OK;
+}
+
+extern "C" size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples) {
+    const size_t S = static_cast<size_t>(samples > 0 ? samples : 1);
+    return align_up(static_cast<size_t>(PIPE_LAYERS) * H * H * sizeof(__bf16)) + align_up(S * 4 * H * 4) + 256;
+}
+
+extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w,
+                                      float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && samples >= 1 && n * samples < INT32_MAX, "aig_gen_node_proj_bf16: n=%lld samples=%lld out of range",
+                (long long)n, (long long)samples);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(samples == 1 || n % BM == 0, "aig_gen_node_proj_bf16: with several samples n must be a multiple of %d "
+                "(pad the template: a tile of rows belongs to one sample)", BM);
+    AIG_REQUIRE(x && z && w && proj && ws, "aig_gen_node_proj_bf16: null pointer");
+    AIG_REQUIRE(w->enc0_w && w->enc0_b && w->enc2_w && w->enc2_b && w->proj0_w && w->proj0_b && w->proj2_w &&
+                    w->proj2_b && w->sc0_w && w->sc0_b && w->at0_w && w->at0_b,
+                "aig_gen_node_proj_bf16: null weight pointer");
+    auto aligned = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+    AIG_REQUIRE(aligned(x, 8) && aligned(proj, 16) && aligned(h_cond, 16) && aligned(ws, 16) && aligned(w->enc2_w, 16) &&
+                    aligned(w->enc2_b, 16) && aligned(w->proj0_w, 16) && aligned(w->proj2_w, 16) &&
+                    aligned(w->proj2_b, 16) && aligned(w->sc0_w, 16) && aligned(w->at0_w, 16),
+                "aig_gen_node_proj_bf16: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned");
+    if (ws_bytes < aig_gen_node_proj_bf16_ws_bytes(samples))
+        return fail(AIG_EWORKSPACE, "aig_gen_node_proj_bf16: workspace %zu < %zu", ws_bytes,
+                    aig_gen_node_proj_bf16_ws_bytes(samples));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Carver c(ws);
+    __bf16* wpack = c.take<__bf16>(static_cast<size_t>(PIPE_LAYERS) * H * H);
+    float* zb = c.take<float>(static_cast<size_t>(samples) * 4 * H);  // per sample: node_proj.0, edge_scorer.0, edge_attr_pred.0, zeros
+    const int M = static_cast<int>(n * samples);
+    for (int64_t i = 0; i < samples; ++i) {   // (a handful of launches even for a large batch would be better as one: k_zbias takes one z)
+        hipLaunchKernelGGL(k_zbias, dim3(4), dim3(H), 0, s, z + i * H, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w, w->sc0_b,
+                           3 * H, 2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb + i * 4 * H);
+    }
+    AIG_LAUNCH_CHECK();
+    PackSrc src{};
+    src.w[0] = w->enc2_w;      src.ldw[0] = H;
+    src.w[1] = w->proj0_w;     src.ldw[1] = 2 * H;
+    src.w[2] = w->proj2_w;     src.ldw[2] = H;
+    src.w[3] = w->sc0_w;       src.ldw[3] = 3 * H;
+    src.w[4] = w->sc0_w + H;   src.ldw[4] = 3 * H;
+    src.w[5] = w->at0_w;       src.ldw[5] = 3 * H;
+    src.w[6] = w->at0_w + H;   src.ldw[6] = 3 * H;
+    hipLaunchKernelGGL(k_pack_bf16, dim3(PIPE_LAYERS * 8), dim3(256), 0, s, src, wpack);
+    AIG_LAUNCH_CHECK();
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_node_pipe_bf16), PIPE_LDS));
+    const size_t plane = static_cast<size_t>(M) * H;
+    PipeBf16 p{};
+    p.x = x; p.enc0_w = w->enc0_w; p.enc0_b = w->enc0_b; p.wpack = wpack;
+    p.b[0] = w->enc2_b;  p.zdep[0] = 0;
+    p.b[1] = zb;         p.zdep[1] = 1;
+    p.b[2] = w->proj2_b; p.zdep[2] = 0;
+    p.b[3] = zb + 3 * H; p.zdep[3] = 0;
+    p.b[4] = zb + H;     p.zdep[4] = 1;
+    p.b[5] = zb + 3 * H; p.zdep[5] = 0;
+    p.b[6] = zb + 2 * H; p.zdep[6] = 1;
+    p.zstride = 4 * H;
+    p.rows_per_sample = samples > 1 ? static_cast<int>(n) : 0;
+    p.h_cond = h_cond;
+    for (int o = 0; o < 4; ++o) p.out[o] = proj + o * plane;
+    const int ntiles = (M + BM - 1) / BM;
+    hipLaunchKernelGGL(k_node_pipe_bf16, dim3(ntiles < 256 ? ntiles : 256), dim3(THREADS), PIPE_LDS, s, M, p);
+    AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 

@@ -328,37 +328,39 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
 // A candidate that was processed inside the block's range (rank >= r0, r0 = the block's first scored
 // slot) sits at row K + rank - r0, any other one is found in the ascending id list of slot r0.  Same per-pair arithmetic (one fmaf chain
 // over the 128 channels in order), hence bit-identical logits.
-constexpr int SCORE_T = 64;        // slots per block
+constexpr int SCORE_T = 64;        // slots per block while the window holds at most 128 candidates
+constexpr int SCORE_T_WIDE = 32;   // ... and for windows of up to 256 (the tile must fit the 160 KB of LDS)
+constexpr int SCORE_K_TILED = 256; // wider windows take the gather kernel
 constexpr int SCORE_THREADS = 1024; // sixteen waves share one tile: the per-pair chains are latency-bound
 constexpr int SCORE_LD = H + 4;    // padded row: lanes read different rows at the same column
 
-__global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, const int* __restrict__ order,
+__global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, int T, const int* __restrict__ order,
                                                      const int* __restrict__ rank, const int* __restrict__ cnt,
                                                      const int* __restrict__ cand, const float* __restrict__ A,
                                                      const float* __restrict__ B, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, float* __restrict__ logits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* tile = reinterpret_cast<float*>(smem);                     // [K + SCORE_T][SCORE_LD]
-    int* ids = reinterpret_cast<int*>(tile + (size_t)(K + SCORE_T) * SCORE_LD);   // [K] ascending ids of slot r0
+    float* tile = reinterpret_cast<float*>(smem);                     // [K + T][SCORE_LD]
+    int* ids = reinterpret_cast<int*>(tile + (size_t)(K + T) * SCORE_LD);   // [K] ascending ids of slot r0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = tid & 31, hw = tid >> 5;
     // base slot: the first slot of the block that is scored at all (a slot that is not a target has
     // cnt = 0 and no candidate list)
     __shared__ int s_base;
-    if (tid < 64) {
-        const int rr = blockIdx.x * SCORE_T + tid;
-        const unsigned long long m = __ballot(rr < n && cnt[rr] > 0);
-        if (tid == 0) s_base = m ? blockIdx.x * SCORE_T + (__ffsll((long long)m) - 1) : -1;
+    if (tid < 64) {   // T <= 64
+        const int rr = blockIdx.x * T + tid;
+        const unsigned long long m = __ballot(tid < T && rr < n && cnt[rr] > 0);
+        if (tid == 0) s_base = m ? blockIdx.x * T + (__ffsll((long long)m) - 1) : -1;
     }
     __syncthreads();
     const int r0 = s_base;
     if (r0 < 0) return;
-    const int r_end = min(n, (int)(blockIdx.x + 1) * SCORE_T);
+    const int r_end = min(n, (int)(blockIdx.x + 1) * T);
     const int c0 = cnt[r0];
     const size_t row00 = (size_t)r0 * K;
     for (int i = tid; i < c0; i += SCORE_THREADS) ids[i] = cand[row00 + i];
     // rows: [0, c0) = candidates of slot r0, [K, K + T - 1) = nodes processed at r0 .. r0 + T - 2
-    for (int row = hw; row < K + SCORE_T - 1; row += SCORE_THREADS / 32) {
+    for (int row = hw; row < K + T - 1; row += SCORE_THREADS / 32) {
         int node = -1;
         if (row < c0) node = cand[row00 + row];
         else if (row >= K && r0 + row - K < r_end) node = order[r0 + row - K];
@@ -418,11 +420,12 @@ extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const i
     if (n == 0) return AIG_OK;
     AIG_REQUIRE(order && rank && cnt && cand && projA && projB && w2 && b2 && logits, "aig_gen_score: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (K <= 128) {
-        const size_t lds = (size_t)(K + SCORE_T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
+    if (K <= SCORE_K_TILED) {
+        const int T = K <= 128 ? SCORE_T : SCORE_T_WIDE;
+        const size_t lds = (size_t)(K + T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled), lds));
-        const int64_t tb = (n + SCORE_T - 1) / SCORE_T;
-        hipLaunchKernelGGL(k_score_tiled, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, order, rank, cnt, cand,
+        const int64_t tb = (n + T - 1) / T;
+        hipLaunchKernelGGL(k_score_tiled, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, T, order, rank, cnt, cand,
                            projA, projB, w2, b2, logits);
         AIG_LAUNCH_CHECK();
         return AIG_OK;

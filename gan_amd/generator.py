@@ -76,8 +76,13 @@ def _plan_key(x: torch.Tensor, nd: Optional[torch.Tensor], K: int):
 
 class AIGGenerator(nn.Module):
     def __init__(self, node_in_dim: int = 2, hidden_dim: int = 128, z_dim: int = 128, candidate_k: int = 512,
-                 device: torch.device = torch.device("cpu")):
+                 device: torch.device = torch.device("cpu"), score_dtype: str = "fp32"):
         super().__init__()
+        if score_dtype not in ("fp32", "bf16"):
+            raise ValueError("score_dtype is 'fp32' (the reference's arithmetic) or 'bf16'")
+        # "bf16": the node projections behind the scores run on the bf16 matrix cores with f32 accumulation
+        # (an extension for bulk sampling; candidate windows, tie handling and assembly are unchanged)
+        self.score_dtype = score_dtype
         self.hidden_dim = hidden_dim
         self.z_dim = z_dim
         self.candidate_k = candidate_k
@@ -163,10 +168,16 @@ class AIGGenerator(nn.Module):
 
         proj = torch.empty((4, max(n, 1), 128), **f32)
         h_cond = torch.empty((max(n, 1), 128), **f32) if return_debug else None
-        ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), dev)
         w = self._weights()
-        _abi.check(_abi.timed("aig_gen_node_proj", lib.aig_gen_node_proj, n, _abi.ptr(x_in), _abi.ptr(z), C.byref(w), _abi.ptr(h_cond),
-                                         _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st), "aig_gen_node_proj")
+        if self.score_dtype == "bf16":
+            ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(1), dev)
+            _abi.check(_abi.timed("aig_gen_node_proj_bf16", lib.aig_gen_node_proj_bf16, n, 1, _abi.ptr(x_in), _abi.ptr(z),
+                                  C.byref(w), _abi.ptr(h_cond), _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st),
+                       "aig_gen_node_proj_bf16")
+        else:
+            ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), dev)
+            _abi.check(_abi.timed("aig_gen_node_proj", lib.aig_gen_node_proj, n, _abi.ptr(x_in), _abi.ptr(z), C.byref(w),
+                                  _abi.ptr(h_cond), _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st), "aig_gen_node_proj")
         logits = torch.empty((max(n, 1), K), **f32)
         if return_debug:
             logits.fill_(float("nan"))

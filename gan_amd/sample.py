@@ -102,6 +102,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--num-samples", type=int, default=1, help="extension: bulk sampling")
     ap.add_argument("--in-flight", type=int, default=4, help="extension: samples kept in flight during bulk sampling")
+    ap.add_argument("--score-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="extension: arithmetic of the node projections behind the candidate scores (bf16 = bf16 matrix "
+                         "cores with f32 accumulation, for bulk sampling; the default is the reference's f32)")
     ap.add_argument("--allow-pickle", action="store_true",
                     help="extension: also read dataset files that need a full unpickle (trusted files only)")
     return ap
@@ -122,7 +125,8 @@ def main(argv=None) -> None:
         raise RuntimeError(f"No .pt files in {args.dataset_dir}")
     tpl = dataset[min(args.template_idx, len(dataset) - 1)].to(device)
 
-    G = AIGGenerator(node_in_dim=2, hidden_dim=args.g_hidden, z_dim=args.z_dim, candidate_k=args.candidate_k).to(device)
+    G = AIGGenerator(node_in_dim=2, hidden_dim=args.g_hidden, z_dim=args.z_dim, candidate_k=args.candidate_k,
+                     score_dtype=args.score_dtype).to(device)
     G.load_state_dict(torch.load(args.gen_ckpt, map_location=device, weights_only=True))
     G.eval()
 

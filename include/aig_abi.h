@@ -94,6 +94,18 @@ size_t aig_gen_node_proj_ws_bytes(int64_t n);
 int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_weights* w_host,
                       float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream);
 
+/* The same node pipeline with the inputs of its seven 128x128 products - activations and weights - rounded to bf16
+ * (round to nearest even) and multiplied on the bf16 matrix cores with f32 accumulation; biases, activations and the
+ * stored outputs stay f32 (the reference computes in f32 throughout, models/generator.py:115-117,94-98: this is the
+ * reduced-precision option of bulk sampling, off by default).  Results differ from aig_gen_node_proj by bf16 rounding
+ * (about 2^-8 relative per product input); like it, a result depends on its own input row only, so equal rows give
+ * bit-equal outputs and candidates with equal features still tie exactly.
+ *   samples > 1: `samples` draws of z for ONE template in one call - z [samples,128], rows laid out sample after
+ *   sample (h_cond [samples*n,128], proj 4 x [samples*n,128]), x [n,2] shared; n must then be a multiple of 64. */
+size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples);
+int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w_host,
+                           float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream);
+
 /* Candidate scores - models/generator.py:84-99 (_score_candidates + edge_scorer):
  *   logits[r*K + i] = w2 . relu(projA[cand[r*K+i]] + projB[order[r]]) + b2,   i < cnt[r] */
 int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt, const int32_t* cand,

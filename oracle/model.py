@@ -157,6 +157,35 @@ def generator_forward_canonical(state: Dict[str, torch.Tensor], x: torch.Tensor,
             "fb": fb, "logits": logits, "sel": sel}
 
 
+def node_proj_bf16(state: Dict[str, torch.Tensor], x: torch.Tensor, z: torch.Tensor):
+    """The node pipeline of the bf16 scoring option (an extension of this repository, no counterpart in the
+    reference): activations and weights entering each of the seven 128x128 products rounded to bf16 (nearest
+    even), products summed exactly (float64 here; the matrix cores accumulate in f32), biases, ReLU and outputs
+    in f32.  -> (h_cond [n,128], proj [4,n,128]).  Checked to a tolerance, not bit for bit: the order in which
+    the hardware adds the sixteen products of an instruction is not documented."""
+    def bf(t):
+        return t.to(torch.bfloat16).to(torch.float64)
+
+    def lin(h, w, b):
+        return (bf(h) @ bf(w).t()).to(torch.float32) + b.float()
+
+    x, z = x.detach().cpu().float(), z.detach().cpu().float().reshape(-1)
+    st = {k: v.detach().cpu().float() for k, v in state.items()}
+    h = torch.relu(x @ st["node_enc.0.weight"].t() + st["node_enc.0.bias"])
+    h = torch.relu(lin(h, st["node_enc.2.weight"], st["node_enc.2.bias"]))
+    w0 = st["node_proj.0.weight"]
+    zb0 = (w0[:, 128:].double() @ z.double()).float() + st["node_proj.0.bias"]
+    h = torch.relu(lin(h, w0[:, :128], zb0))
+    h_cond = torch.relu(lin(h, st["node_proj.2.weight"], st["node_proj.2.bias"]))
+    outs = []
+    for name in ("edge_scorer.0", "edge_attr_pred.0"):
+        w, b = st[name + ".weight"], st[name + ".bias"]
+        zb = (w[:, 256:].double() @ z.double()).float() + b
+        outs.append(lin(h_cond, w[:, :128], torch.zeros(128)))
+        outs.append(lin(h_cond, w[:, 128:256], zb))
+    return h_cond, torch.stack(outs)
+
+
 # ------------------------------------------------------------------------------------ critic
 def gat_self_loops(edge_index: torch.Tensor, edge_attr: torch.Tensor, n: int):
     """Drop self loops, then append one per node whose attribute is the mean attribute of

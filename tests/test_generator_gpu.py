@@ -322,3 +322,107 @@ def test_bulk_sampler_matches_one_at_a_time():
         for a, b in zip(got, want):
             for k in ("x", "edge_index", "edge_attr", "node_depth"):
                 assert torch.equal(getattr(a, k), getattr(b, k)), (in_flight, k)
+
+
+# ------------------------------------------------------------------------------------------------------
+# bf16 scoring option (bulk sampling): node projections on the bf16 matrix cores.  Stated tolerance: every
+# logit within BF16_TOL of the f32 path's, relative to the largest logit of its row.
+BF16_TOL = 3e-2
+
+
+def bf16_generator(K):
+    G = AIGGenerator(candidate_k=K, score_dtype="bf16")
+    G.load_state_dict(gen_state())
+    return G.to(DEV).eval()
+
+
+@pytest.mark.parametrize("case", ["n486_dataset_k64", "n700_dataset_k256", "n486_distinct_k64", "n243_padded300_k64",
+                                  "pofirst_nodepth_k4"])
+def test_bf16_scoring_against_the_f32_path(case):
+    d = load("gen_" + case)
+    K = int(d["candidate_k"])
+    x, z = torch.from_numpy(d["x"]), torch.from_numpy(d["z"])
+    tpl = Data(x=x.to(DEV))
+    if "node_depth" in d.files:
+        tpl.node_depth = torch.from_numpy(d["node_depth"]).to(DEV)
+    out32 = golden_generator(K)(tpl, z.to(DEV), return_debug=True)
+    out16 = bf16_generator(K)(tpl, z.to(DEV), return_debug=True)
+    n = x.size(0)
+    # the plan (order, candidate windows, edge offsets) does not depend on the arithmetic: same object contents
+    p32, p16 = out32._debug["plan"], out16._debug["plan"]
+    for name in ("order", "rank", "want", "cnt", "cand", "fb", "eoff"):
+        assert torch.equal(getattr(p32, name), getattr(p16, name)), name
+    # projections against the restated bf16 pipeline (exact sums of bf16-rounded inputs)
+    h_ref, proj_ref = omodel.node_proj_bf16(gen_state(), x, z)
+    h16, proj16 = out16._debug["h_cond"].cpu()[:n], out16._debug["proj"].cpu()[:, :n]
+    scale = float(proj_ref.abs().max())
+    assert float((h16 - h_ref).abs().max()) <= 1e-2 * float(h_ref.abs().max())
+    assert float((proj16 - proj_ref).abs().max()) <= 1e-2 * scale
+    assert float((proj16 - proj_ref).abs().median()) <= 1e-5 * scale       # all but boundary roundings agree closely
+    # equal feature rows give bit-equal projections (ties between equal candidates survive)
+    _, inv = np.unique(d["x"], axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    first = {int(g): int(np.flatnonzero(inv == g)[0]) for g in np.unique(inv)}
+    rep = torch.tensor([first[int(g)] for g in inv])
+    assert torch.equal(proj16.view(torch.int32), proj16[:, rep].view(torch.int32))
+    # logits within the stated tolerance of the f32 path's; picks identical wherever f32 separates the
+    # chosen candidates from the rest (and from each other) by more than twice that
+    l32, l16 = out32._debug["logits"].cpu().numpy(), out16._debug["logits"].cpu().numpy()
+    s32, s16 = out32._debug["sel"].cpu().numpy(), out16._debug["sel"].cpu().numpy()
+    cnt, want = p32.cnt.cpu().numpy(), p32.want.cpu().numpy()
+    compared = decided = 0
+    for r in range(n):
+        c = int(cnt[r])
+        if c == 0 or want[r] == 0:
+            continue
+        a, b = l32[r, :c], l16[r, :c]
+        tol = BF16_TOL * max(float(np.abs(a).max()), 1e-6)
+        assert float(np.abs(a - b).max()) <= tol, (case, r)
+        compared += 1
+        k = min(int(want[r]), c)
+        top = np.sort(a)[::-1]
+        clear = all(top[i] - top[i + 1] > 2 * tol for i in range(min(k, c - 1)))
+        if clear:
+            assert s16[r, :k].tolist() == s32[r, :k].tolist(), (case, r)
+            decided += 1
+    assert compared > 0
+    # rows of equal candidates tie in bf16 exactly as they do in f32: equal logit bits for equal candidate features
+    cand = p32.cand.cpu().numpy()
+    for r in range(0, n, max(1, n // 50)):
+        c = int(cnt[r])
+        if c < 2:
+            continue
+        groups = inv[cand[r, :c]]
+        for gid in np.unique(groups):
+            bits = l16[r, :c][groups == gid].view(np.int32)
+            assert np.unique(bits).size == 1, (case, r)
+
+
+def test_bf16_projection_of_several_samples_in_one_call():
+    """z of several samples against one template in one launch (rows sample after sample) = the same rows as one
+    call per sample, bit for bit."""
+    import ctypes as C
+    lib = _abi.lib()
+    G = bf16_generator(64)
+    n, S = 64 * 5, 3
+    g = synth_aig(20, n - 30, 10, seed=2, window=40)
+    x = g.x.to(DEV).contiguous()
+    zs = torch.randn(S, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    w = G._weights()
+    proj = torch.empty((4, S * n, 128), device=DEV)
+    h = torch.empty((S * n, 128), device=DEV)
+    ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(S), x.device)
+    _abi.check(lib.aig_gen_node_proj_bf16(n, S, _abi.ptr(x), _abi.ptr(zs), C.byref(w), _abi.ptr(h), _abi.ptr(proj),
+                                          _abi.ptr(ws), ws.numel(), _abi.stream()))
+    for i in range(S):
+        p1 = torch.empty((4, n, 128), device=DEV)
+        h1 = torch.empty((n, 128), device=DEV)
+        ws1 = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(1), x.device)
+        _abi.check(lib.aig_gen_node_proj_bf16(n, 1, _abi.ptr(x), _abi.ptr(zs[i].contiguous()), C.byref(w), _abi.ptr(h1),
+                                              _abi.ptr(p1), _abi.ptr(ws1), ws1.numel(), _abi.stream()))
+        assert torch.equal(h[i * n:(i + 1) * n], h1)
+        assert torch.equal(proj[:, i * n:(i + 1) * n], p1)
+    # a template that is not a whole number of tiles cannot be batched
+    rc = lib.aig_gen_node_proj_bf16(n + 1, 2, _abi.ptr(x), _abi.ptr(zs), C.byref(w), None, _abi.ptr(proj), _abi.ptr(ws),
+                                    ws.numel(), _abi.stream())
+    assert rc == -1
