@@ -32,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 MFMA_F32_PEAK_TF = 157.3  # dense f32 matrix peak of MI355X
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak; ~6300 GB/s is the measured copy ceiling
 
 
@@ -206,6 +207,91 @@ def side_workload(name: str, dev, steps: int, warmup: int):
             "sample_nodes_per_sec": round(nodes / (time.perf_counter() - s0), 1)}
 
 
+def bulk_sampling(a, rank, world, dev):
+    """BASELINE.json's bulk-sampling configuration on this rank's share: samples from one c7552-sized template at
+    candidate-k 256 with the node projections on the bf16 matrix cores, no collective (ranks only meet at the
+    timing barriers).  A step = one block of --bulk-batch samples: generator (one projection launch per block),
+    repair, resync.  Rank 0 prints the JSON line."""
+    from gan_amd import _abi
+    from gan_amd.data import Data
+    from gan_amd.generator import AIGGenerator
+    from gan_amd.sample import sample_bulk
+    from gan_amd.synth import ISCAS85_SHAPES, synth_aig
+    name, n_pi, n_po, n_and = ISCAS85_SHAPES[-1]
+    g = synth_aig(n_pi, n_and, n_po, seed=0, window=max(8, n_and // 8 + n_pi), orientation="dataset")
+    tpl = Data(x=g.x.to(dev), node_depth=g.node_depth.to(dev))
+    n = int(g.x.size(0))
+    torch.manual_seed(123)
+    G = AIGGenerator(candidate_k=256, score_dtype=a.score_dtype).to(dev).eval()
+    S = a.bulk_batch
+    streams = [torch.cuda.Stream(device=dev) for _ in range(a.sample_in_flight)]
+
+    def block(step):      # z_i from the CPU generator seeded base + rank * 10^6 + i, as the configuration words it
+        zs = torch.stack([torch.randn(128, generator=torch.Generator().manual_seed(7 + rank * 10**6 + step * S + i))
+                          for i in range(S)])
+        return zs.to(dev, non_blocking=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(first, count):
+        edges = 0
+        for d in sample_bulk(G, tpl, (block(first + k) for k in range(count)), streams=streams):
+            edges += int(d.edge_index.size(1))
+        return edges
+
+    run(0, max(a.warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    edges = run(a.warmup, a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stat = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stat, op=dist.ReduceOp.MAX)
+        elapsed = float(stat.item())
+    # the projection launch of a block, bracketed with events in one extra untimed step
+    entry = "aig_gen_node_proj_bf16" if a.score_dtype == "bf16" else "aig_gen_node_proj"
+    _abi.timeline.reset()
+    _abi.timeline.only = {entry}
+    _abi.timeline.enabled = True
+    run(a.warmup + a.steps, 2)
+    barrier()
+    _abi.timeline.enabled = False
+    ms, launches = _abi.timeline.totals_ms().get(entry, (0.0, 0))
+    if rank != 0:
+        return
+    rows = S * ((n + 63) // 64 * 64) if a.score_dtype == "bf16" else n
+    out = {"metric": "AIG nodes/sec sampled (bulk, candidate-k 256)", "value": round(n * S * a.steps * world / elapsed, 1),
+           "unit": "nodes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(elapsed * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if a.score_dtype == "bf16" else "f32", "data": "synthetic",
+           "config": {"workload": f"bulk_k256: {S} samples per step per GPU from one {name}-sized template ({n} nodes: {n_pi} PI / "
+                                  f"{n_and} AND / {n_po} PO), candidate-k 256, node projections in {a.score_dtype}, generator + repair + "
+                                  "resync per sample, no collectives", "samples_per_step_per_gpu": S,
+                      "samples_per_gpu": S * a.steps, "nodes_per_sample": n, "edges_per_sample": round(edges / (S * a.steps), 1),
+                      "parallelism": f"{world} independent rank(s)"},
+           "samples_per_sec": round(S * a.steps * world / elapsed, 1)}
+    if launches:
+        us = ms * 1e3 / launches
+        flops = 7 * 2.0 * 128 * 128 * rows
+        bytes_out = rows * (8 + 4 * 512)           # x read, four 512-byte output rows written
+        peak = MFMA_BF16_PEAK_TF if a.score_dtype == "bf16" else MFMA_F32_PEAK_TF
+        out["roofline_mfma"] = {"kernel": f"node projections of one block ({entry})", "bound": "mfma",
+                                "achieved": round(flops / (us * 1e-6) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(flops / (us * 1e-6) / 1e12 / peak, 4), "launches": launches,
+                                "avg_launch_us": round(us, 2), "rows_per_launch": rows}
+        out["roofline"] = {"kernel": f"node projections of one block ({entry}): 8 B read and 2 KB of f32 output per row, which "
+                                     "bound the kernel once the products run at bf16 rate", "bound": "hbm",
+                           "achieved": round(bytes_out / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(bytes_out / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "launches": launches, "avg_launch_us": round(us, 2)}
+    print(json.dumps(out))
+
+
 def launch_ranks(n: int) -> int:
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child
     process; one rank per GPU over RCCL.  With fewer GPUs than ranks the ranks can only rehearse the
@@ -237,7 +323,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="synth100k", choices=["synth100k", "iscas85", "synth1m"])
+    ap.add_argument("--workload", default="synth100k", choices=["synth100k", "iscas85", "synth1m", "bulk_k256"])
+    ap.add_argument("--bulk-batch", type=int, default=64, help="bulk_k256: samples per step (one projection launch each)")
+    ap.add_argument("--score-dtype", default="bf16", choices=["fp32", "bf16"], help="bulk_k256: arithmetic of the node projections")
     ap.add_argument("--sample-iters", type=int, default=10)
     ap.add_argument("--sample-in-flight", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,6 +356,13 @@ def main():
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))   # (modulo: rehearsals on fewer GPUs)
     torch.cuda.set_device(dev)
     torch.manual_seed(123)
+
+    if a.workload == "bulk_k256":
+        bulk_sampling(a, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     groups, desc = workload_minibatches(a.workload, rank, a.distinct)
     batches, max_nodes, max_edges, top = device_minibatches(groups, dev)

@@ -31,6 +31,8 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
                         int off1, const float* __restrict__ w2, const float* __restrict__ b2, int ld2, int off2,
                         float* __restrict__ out) {
     int v = blockIdx.x, j = threadIdx.x;
+    z += static_cast<size_t>(blockIdx.y) * H;           // blockIdx.y: the sample (one z and four vectors each)
+    out += static_cast<size_t>(blockIdx.y) * 4 * H;
     if (v == 3) {  // a zero vector for layers without bias
         out[v * H + j] = 0.f;
         return;
@@ -520,6 +522,7 @@ struct PipeBf16 {
     int zdep[PIPE_LAYERS];           // 1: the vector depends on z - sample s uses b + s * zstride
     int zstride;
     int rows_per_sample;   // 0: one sample; else tile t belongs to sample t*64 / rows_per_sample and reads x row (row % rows_per_sample)
+    int x_rows;            // rows of x (a sample's rows past them repeat the last one)
     float* h_cond;         // [M][128] or null
     float* out[4];         // [M][128] each
 };
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(THREADS) void k_node_pipe_bf16(int M, PipeBf16 p) {
         const int row0 = tile * BM;
         const int sample = p.rows_per_sample > 0 ? row0 / p.rows_per_sample : 0;
         const int xrow0 = row0 - sample * p.rows_per_sample;
-        const int xlimit = p.rows_per_sample > 0 ? p.rows_per_sample : M;
+        const int xlimit = p.x_rows;
         const float* bias[PIPE_LAYERS];
 #pragma unroll
         for (int l = 0; l < PIPE_LAYERS; ++l) bias[l] = p.b[l] + (p.zdep[l] ? static_cast<size_t>(sample) * p.zstride : 0);
@@ -748,8 +751,6 @@ extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x
     AIG_REQUIRE(n >= 0 && samples >= 1 && n * samples < INT32_MAX, "aig_gen_node_proj_bf16: n=%lld samples=%lld out of range",
                 (long long)n, (long long)samples);
     if (n == 0) return AIG_OK;
-    AIG_REQUIRE(samples == 1 || n % BM == 0, "aig_gen_node_proj_bf16: with several samples n must be a multiple of %d "
-                "(pad the template: a tile of rows belongs to one sample)", BM);
     AIG_REQUIRE(x && z && w && proj && ws, "aig_gen_node_proj_bf16: null pointer");
     AIG_REQUIRE(w->enc0_w && w->enc0_b && w->enc2_w && w->enc2_b && w->proj0_w && w->proj0_b && w->proj2_w &&
                     w->proj2_b && w->sc0_w && w->sc0_b && w->at0_w && w->at0_b,
@@ -766,11 +767,14 @@ extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x
     Carver c(ws);
     __bf16* wpack = c.take<__bf16>(static_cast<size_t>(PIPE_LAYERS) * H * H);
     float* zb = c.take<float>(static_cast<size_t>(samples) * 4 * H);  // per sample: node_proj.0, edge_scorer.0, edge_attr_pred.0, zeros
-    const int M = static_cast<int>(n * samples);
-    for (int64_t i = 0; i < samples; ++i) {   // (a handful of launches even for a large batch would be better as one: k_zbias takes one z)
-        hipLaunchKernelGGL(k_zbias, dim3(4), dim3(H), 0, s, z + i * H, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w, w->sc0_b,
-                           3 * H, 2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb + i * 4 * H);
-    }
+    // several samples: each starts on a tile boundary (a tile of rows belongs to one sample), the rows between a
+    // sample's last node and the next boundary repeat its last row
+    const int64_t stride = samples > 1 ? (n + BM - 1) / BM * BM : n;
+    AIG_REQUIRE(stride * samples < INT32_MAX, "aig_gen_node_proj_bf16: %lld rows", (long long)(stride * samples));
+    const int M = static_cast<int>(stride * samples);
+    AIG_REQUIRE(samples <= 65535, "aig_gen_node_proj_bf16: at most 65535 samples per call");
+    hipLaunchKernelGGL(k_zbias, dim3(4, (unsigned)samples), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w,
+                       w->sc0_b, 3 * H, 2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb);
     AIG_LAUNCH_CHECK();
     PackSrc src{};
     src.w[0] = w->enc2_w;      src.ldw[0] = H;
@@ -794,7 +798,8 @@ extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x
     p.b[5] = zb + 3 * H; p.zdep[5] = 0;
     p.b[6] = zb + 2 * H; p.zdep[6] = 1;
     p.zstride = 4 * H;
-    p.rows_per_sample = samples > 1 ? static_cast<int>(n) : 0;
+    p.rows_per_sample = samples > 1 ? static_cast<int>(stride) : 0;
+    p.x_rows = static_cast<int>(n);
     p.h_cond = h_cond;
     for (int o = 0; o < 4; ++o) p.out[o] = proj + o * plane;
     const int ntiles = (M + BM - 1) / BM;

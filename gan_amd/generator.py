@@ -146,6 +146,72 @@ class AIGGenerator(nn.Module):
             template.__dict__["_gen_plan"] = plan
         return plan
 
+    @torch.no_grad()
+    def forward_many(self, template: Data, zs: torch.Tensor) -> list:
+        """``[self(template, z) for z in zs]`` for bulk sampling from ONE template (``zs`` is ``[S, z_dim]``): the
+        plan is shared, and with ``score_dtype="bf16"`` the node projections of all S samples are ONE launch
+        (the z of a sample only enters as bias vectors), which is what gives the matrix cores rows to work on
+        when the template is a few thousand nodes.  Scores, selection and assembly follow per sample; every
+        returned graph has the tensors ``forward`` returns for its z."""
+        lib = _abi.lib()
+        dev = template.x.device
+        if dev.type != "cuda":
+            raise _abi.AigAbiError("AIGGenerator.forward_many needs the template on a HIP device (no CPU path exists)")
+        zs = zs.to(dev).float().contiguous()
+        S = int(zs.size(0))
+        if self.score_dtype != "bf16" or S == 1:
+            return [self(template, zs[i]) for i in range(S)]
+        x_src = template.x
+        x_in = x_src if (x_src.dtype == torch.float32 and x_src.is_contiguous()) else x_src.float().contiguous()
+        n = int(x_in.size(0))
+        nd = getattr(template, "node_depth", None)
+        nd_dev = nd.to(dev) if nd is not None else None
+        plan = self.plan_for(template, x_in, nd_dev)
+        K, E = plan.K, plan.E
+        st = _abi.stream()
+        n64 = (n + 63) // 64 * 64
+        proj = torch.empty((4, S * n64, 128), dtype=torch.float32, device=dev)
+        ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(S), dev)
+        w = self._weights()
+        _abi.check(_abi.timed("aig_gen_node_proj_bf16", lib.aig_gen_node_proj_bf16, n, S, _abi.ptr(x_in), _abi.ptr(zs),
+                              C.byref(w), None, _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st, meta=(n, S)),
+                   "aig_gen_node_proj_bf16")
+        outs = []
+        for i in range(S):
+            rows = slice(i * n64, i * n64 + n)
+            outs.append(self._wire(plan, x_in, x_src, nd, proj[0, rows], proj[1, rows], proj[2, rows], proj[3, rows], n, K, E, dev))
+        return outs
+
+    def _wire(self, plan, x_in, x_src, nd, pa, pb, pa2, pb2, n, K, E, dev, debug=None) -> Data:
+        """Scores, tie-exact selection and edge assembly from the four projection planes (generator.py:139-209)."""
+        lib = _abi.lib()
+        st = _abi.stream()
+        logits = torch.empty((max(n, 1), K), dtype=torch.float32, device=dev)
+        if debug is not None:
+            logits.fill_(float("nan"))
+        _abi.check(_abi.timed("aig_gen_score", lib.aig_gen_score, n, K, _abi.ptr(plan.order), _abi.ptr(plan.rank), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
+                                     _abi.ptr(pa), _abi.ptr(pb), _abi.ptr(self.edge_scorer[2].weight),
+                                     _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), "aig_gen_score")
+        sel = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
+        _abi.check(_abi.timed("aig_topk_select", lib.aig_topk_select, n, K, _abi.ptr(logits), _abi.ptr(plan.cnt), _abi.ptr(plan.want),
+                                       _abi.ptr(sel), None, 0, st), "aig_topk_select")
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+        edge_attr = torch.empty((E, 1), dtype=torch.int64, device=dev)
+        x_out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        _abi.check(_abi.timed("aig_gen_emit", lib.aig_gen_emit, n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
+                                    _abi.ptr(plan.cnt), _abi.ptr(plan.cand), _abi.ptr(plan.fb), _abi.ptr(plan.eoff),
+                                    _abi.ptr(sel), _abi.ptr(pa2), _abi.ptr(pb2),
+                                    _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias),
+                                    _abi.ptr(edge_index) if E else None, _abi.ptr(edge_attr) if E else None,
+                                    _abi.ptr(x_out), st), "aig_gen_emit")
+        if x_src.dtype != torch.float32:
+            x_out = x_out.to(x_src.dtype)
+        out = Data(x=x_out, edge_index=edge_index, edge_attr=edge_attr,
+                   node_depth=(nd.clone().to(dev) if nd is not None else None))
+        if debug is not None:
+            debug.update({"logits": logits, "sel": sel})
+        return out
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, template: Data, z: torch.Tensor, return_debug: bool = False) -> Data:
@@ -178,28 +244,8 @@ class AIGGenerator(nn.Module):
             ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), dev)
             _abi.check(_abi.timed("aig_gen_node_proj", lib.aig_gen_node_proj, n, _abi.ptr(x_in), _abi.ptr(z), C.byref(w),
                                   _abi.ptr(h_cond), _abi.ptr(proj), _abi.ptr(ws), ws.numel(), st), "aig_gen_node_proj")
-        logits = torch.empty((max(n, 1), K), **f32)
+        debug = {"plan": plan, "h_cond": h_cond, "proj": proj} if return_debug else None
+        out = self._wire(plan, x_in, x_src, nd, proj[0], proj[1], proj[2], proj[3], n, K, E, dev, debug)
         if return_debug:
-            logits.fill_(float("nan"))
-        _abi.check(_abi.timed("aig_gen_score", lib.aig_gen_score, n, K, _abi.ptr(plan.order), _abi.ptr(plan.rank), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
-                                     _abi.ptr(proj[0]), _abi.ptr(proj[1]), _abi.ptr(self.edge_scorer[2].weight),
-                                     _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), "aig_gen_score")
-        sel = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
-        _abi.check(_abi.timed("aig_topk_select", lib.aig_topk_select, n, K, _abi.ptr(logits), _abi.ptr(plan.cnt), _abi.ptr(plan.want),
-                                       _abi.ptr(sel), None, 0, st), "aig_topk_select")
-        edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
-        edge_attr = torch.empty((E, 1), dtype=torch.int64, device=dev)
-        x_out = torch.empty((n, 2), **f32)
-        _abi.check(_abi.timed("aig_gen_emit", lib.aig_gen_emit, n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
-                                    _abi.ptr(plan.cnt), _abi.ptr(plan.cand), _abi.ptr(plan.fb), _abi.ptr(plan.eoff),
-                                    _abi.ptr(sel), _abi.ptr(proj[2]), _abi.ptr(proj[3]),
-                                    _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias),
-                                    _abi.ptr(edge_index) if E else None, _abi.ptr(edge_attr) if E else None,
-                                    _abi.ptr(x_out), st), "aig_gen_emit")
-        if x_src.dtype != torch.float32:
-            x_out = x_out.to(x_src.dtype)
-        out = Data(x=x_out, edge_index=edge_index, edge_attr=edge_attr,
-                   node_depth=(nd.clone().to(dev) if nd is not None else None))
-        if return_debug:
-            out._debug = {"plan": plan, "h_cond": h_cond, "logits": logits, "sel": sel, "proj": proj}
+            out._debug = debug
         return out

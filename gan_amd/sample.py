@@ -83,6 +83,50 @@ def sample_many(G: AIGGenerator, jobs: Iterable[Tuple[Data, Callable[[], torch.T
         yield finish()
 
 
+def sample_bulk(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 4,
+                streams: Optional[List[torch.cuda.Stream]] = None) -> Iterator[Data]:
+    """Bulk sampling from ONE template: every element of ``z_batches`` is a ``[S, z_dim]`` block of draws whose
+    generator passes share their node-projection launch (``AIGGenerator.forward_many``); repair and resync then
+    follow per sample with ``in_flight`` of them in the air, as in ``sample_many``.  Results come back in draw
+    order and equal ``sample_one(G, tpl, z)`` for every z."""
+    if in_flight < 1:
+        raise ValueError("in_flight must be at least 1")
+    cur = torch.cuda.current_stream()
+    if streams is None:
+        streams = [torch.cuda.Stream(device=cur.device) for _ in range(in_flight)]
+    for st in streams:
+        st.wait_stream(cur)
+    pending: deque = deque()
+
+    def finish():
+        st, handle = pending.popleft()
+        with torch.cuda.stream(st):
+            d = resync_attrs(enforce_finish(handle))
+        cur.wait_stream(st)
+        for v in d.to_dict().values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return d
+
+    k = 0
+    for zs in z_batches:
+        with torch.no_grad():
+            raws = G.forward_many(tpl, zs)        # on the caller's stream
+        for raw in raws:
+            st = streams[k % len(streams)]
+            k += 1
+            st.wait_stream(cur)
+            for v in raw.to_dict().values():      # made on the caller's stream, consumed on the sample's
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(st)
+            with torch.cuda.stream(st):
+                pending.append((st, enforce_begin(raw, want_depth=False)))
+            if len(pending) >= len(streams):
+                yield finish()
+    while pending:
+        yield finish()
+
+
 def out_path(base: str, i: int, total: int) -> str:
     if total == 1:
         return base
@@ -102,6 +146,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--num-samples", type=int, default=1, help="extension: bulk sampling")
     ap.add_argument("--in-flight", type=int, default=4, help="extension: samples kept in flight during bulk sampling")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="extension: draws per generator launch block during bulk sampling (the samples are the same for any value)")
     ap.add_argument("--score-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="extension: arithmetic of the node projections behind the candidate scores (bf16 = bf16 matrix "
                          "cores with f32 accumulation, for bulk sampling; the default is the reference's f32)")
@@ -136,7 +182,13 @@ def main(argv=None) -> None:
     def z_of(i):   # per-sample seed: the output set does not depend on the number of ranks
         return lambda: torch.randn(args.z_dim, device=device, generator=torch.Generator(device=device).manual_seed(args.seed + i))
 
-    for i, fixed in zip(mine, sample_many(G, ((tpl, z_of(i)) for i in mine), in_flight=args.in_flight)):
+    def z_blocks():     # this rank's draws in blocks whose generator passes share a launch
+        for b in range(0, len(mine), args.batch):
+            yield torch.stack([z_of(i)() for i in mine[b:b + args.batch]])
+
+    results = (sample_bulk(G, tpl, z_blocks(), in_flight=args.in_flight) if args.batch > 1
+               else sample_many(G, ((tpl, z_of(i)) for i in mine), in_flight=args.in_flight))
+    for i, fixed in zip(mine, results):
         if args.num_samples == 1:
             print("[INFO] FIX:", summarize(fixed))
         path = out_path(args.out, i, args.num_samples)

@@ -100,8 +100,10 @@ int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_w
  * reduced-precision option of bulk sampling, off by default).  Results differ from aig_gen_node_proj by bf16 rounding
  * (about 2^-8 relative per product input); like it, a result depends on its own input row only, so equal rows give
  * bit-equal outputs and candidates with equal features still tie exactly.
- *   samples > 1: `samples` draws of z for ONE template in one call - z [samples,128], rows laid out sample after
- *   sample (h_cond [samples*n,128], proj 4 x [samples*n,128]), x [n,2] shared; n must then be a multiple of 64. */
+ *   samples > 1: `samples` draws of z for ONE template in one call - z [samples,128], x [n,2] shared, rows laid out
+ *   sample after sample, each sample starting on a multiple of 64 rows: with n64 = n rounded up to a multiple of 64,
+ *   h_cond is [samples*n64,128], proj 4 x [samples*n64,128], sample s owns rows s*n64 .. s*n64+n-1 (the rows up to
+ *   the next sample repeat its last row). */
 size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples);
 int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w_host,
                            float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream);

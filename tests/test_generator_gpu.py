@@ -399,18 +399,19 @@ def test_bf16_scoring_against_the_f32_path(case):
 
 
 def test_bf16_projection_of_several_samples_in_one_call():
-    """z of several samples against one template in one launch (rows sample after sample) = the same rows as one
-    call per sample, bit for bit."""
+    """z of several samples against one template in one launch (every sample starts on a 64-row boundary) = the
+    same rows as one call per sample, bit for bit."""
     import ctypes as C
     lib = _abi.lib()
     G = bf16_generator(64)
-    n, S = 64 * 5, 3
+    n, S = 64 * 5 + 7, 3
+    n64 = (n + 63) // 64 * 64
     g = synth_aig(20, n - 30, 10, seed=2, window=40)
     x = g.x.to(DEV).contiguous()
     zs = torch.randn(S, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
     w = G._weights()
-    proj = torch.empty((4, S * n, 128), device=DEV)
-    h = torch.empty((S * n, 128), device=DEV)
+    proj = torch.empty((4, S * n64, 128), device=DEV)
+    h = torch.empty((S * n64, 128), device=DEV)
     ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(S), x.device)
     _abi.check(lib.aig_gen_node_proj_bf16(n, S, _abi.ptr(x), _abi.ptr(zs), C.byref(w), _abi.ptr(h), _abi.ptr(proj),
                                           _abi.ptr(ws), ws.numel(), _abi.stream()))
@@ -420,9 +421,22 @@ def test_bf16_projection_of_several_samples_in_one_call():
         ws1 = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(1), x.device)
         _abi.check(lib.aig_gen_node_proj_bf16(n, 1, _abi.ptr(x), _abi.ptr(zs[i].contiguous()), C.byref(w), _abi.ptr(h1),
                                               _abi.ptr(p1), _abi.ptr(ws1), ws1.numel(), _abi.stream()))
-        assert torch.equal(h[i * n:(i + 1) * n], h1)
-        assert torch.equal(proj[:, i * n:(i + 1) * n], p1)
-    # a template that is not a whole number of tiles cannot be batched
-    rc = lib.aig_gen_node_proj_bf16(n + 1, 2, _abi.ptr(x), _abi.ptr(zs), C.byref(w), None, _abi.ptr(proj), _abi.ptr(ws),
-                                    ws.numel(), _abi.stream())
-    assert rc == -1
+        assert torch.equal(h[i * n64:i * n64 + n], h1)
+        assert torch.equal(proj[:, i * n64:i * n64 + n], p1)
+
+
+def test_bulk_sampling_in_blocks_equals_one_sample_at_a_time():
+    from gan_amd.sample import sample_bulk, sample_one
+    g = synth_aig(12, 330, 9, seed=5, window=60, orientation="dataset")
+    tpl = Data(x=g.x.to(DEV), node_depth=g.node_depth.to(DEV))
+    zs = torch.randn(7, 128, generator=torch.Generator().manual_seed(8)).to(DEV)
+    for dtype in ("bf16", "fp32"):
+        G = AIGGenerator(candidate_k=32, score_dtype=dtype)
+        G.load_state_dict(gen_state())
+        G = G.to(DEV).eval()
+        bulk = list(sample_bulk(G, tpl, [zs[:4], zs[4:]], in_flight=3))
+        assert len(bulk) == 7
+        for i, d in enumerate(bulk):
+            ref = sample_one(G, tpl, zs[i])
+            for name in ("x", "edge_index", "edge_attr", "node_depth"):
+                assert torch.equal(getattr(d, name), getattr(ref, name)), (dtype, i, name)
