@@ -102,6 +102,8 @@ constexpr int SEG = 32;         // an out-edge list of at most this many edges i
 constexpr int HUB_CHUNK = 256;  // a longer list (a "hub") is cut into chunks of this many edges, one block each
 constexpr int HUB_BLOCKS = 1024;        // blocks that gather hub chunks (multiple of 8)
 constexpr int HUB_FINISH_BLOCKS = 64;   // blocks that add up the chunk rows, a hub at a time
+constexpr int BWD_DST_BLOCKS = 1024;    // grids of the two backward kernels: what is resident at once at their occupancy
+constexpr int BWD_SRC_BLOCKS = 1280;
 // upper bounds for E edges: a hub has more than SEG edges, and its chunks number fan-out / HUB_CHUNK rounded up
 inline size_t hubs_max(int64_t E) { return (size_t)(E > 0 ? E : 0) / (SEG + 1) + 1; }
 inline size_t hub_chunks_max(int64_t E) { return (size_t)(E > 0 ? E : 0) / HUB_CHUNK + hubs_max(E); }
@@ -770,12 +772,13 @@ __global__ __launch_bounds__(256) void k_reduce_cols(ColSums jobs) {
 // Grid of the node-parallel kernels: a multiple of 8 (XCD grouping), at least 8 nodes per half-wave
 // before more blocks are added, capped at 2048 (measured: finer cuts than co-residency win here).
 // AIG_GAT_GRID_CAP overrides the cap (tuning aid).
-int grid_blocks(int64_t n) {
-    static const int cap = [] {
+int grid_blocks(int64_t n, int limit = 2048) {
+    static const int env_cap = [] {
         const char* e = getenv("AIG_GAT_GRID_CAP");
         int c = e ? atoi(e) : 0;
         return c >= 8 && c <= 2048 ? c / 8 * 8 : 2048;  // the partial-sum areas hold 2048 blocks
     }();
+    const int cap = env_cap < limit ? env_cap : limit;
     int64_t g = (n + 63) / 64;
     g = (g + 7) / 8 * 8;
     if (g > cap) g = cap;
@@ -924,13 +927,15 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     float* part_das = c.take<float>(hub_chunks_max(E) * HEADS);
     float* partial = c.take<float>((size_t)4097 * 2 * H);       // source-side kernels: [gs + g][2H]
     float* partial_dst = c.take<float>((size_t)2048 * (H + HEADS));  // target-side kernel: [g][H + HEADS]
-    const int g = grid_blocks(n);
+    // the target-side kernel holds 4 waves per SIMD (104 registers): 1024 blocks are resident at once, and a grid
+    // of 1568 left the second round half empty
+    const int g = grid_blocks(n, BWD_DST_BLOCKS);
     hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
                        csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial_dst);
     AIG_LAUNCH_CHECK();
     // blocks of the by-source kernel: HUB_BLOCKS for the hubs' chunks (they leave at once when the graph
     // has none), then gs over the nodes; the finishing kernel takes a hub per block
-    const int gs = grid_blocks(n);
+    const int gs = grid_blocks(n, BWD_SRC_BLOCKS);
     const int4* tab = reinterpret_cast<const int4*>(hub_tab);
     hipLaunchKernelGGL(k_gat_bwd_src, dim3(HUB_BLOCKS + gs), dim3(THREADS), 0, s, (int)n, HUB_BLOCKS, g_pre, xw, att_src,
                        att_dst, tab, col_ptr, csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw,

@@ -334,7 +334,8 @@ constexpr int SCORE_K_TILED = 256; // wider windows take the gather kernel
 constexpr int SCORE_THREADS = 1024; // sixteen waves share one tile: the per-pair chains are latency-bound
 constexpr int SCORE_LD = H + 4;    // padded row: lanes read different rows at the same column
 
-__global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, int T, const int* __restrict__ order,
+template <int T>
+__global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, const int* __restrict__ order,
                                                      const int* __restrict__ rank, const int* __restrict__ cnt,
                                                      const int* __restrict__ cand, const float* __restrict__ A,
                                                      const float* __restrict__ B, const float* __restrict__ w2,
@@ -423,10 +424,16 @@ extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const i
     if (K <= SCORE_K_TILED) {
         const int T = K <= 128 ? SCORE_T : SCORE_T_WIDE;
         const size_t lds = (size_t)(K + T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
-        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled), lds));
         const int64_t tb = (n + T - 1) / T;
-        hipLaunchKernelGGL(k_score_tiled, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, T, order, rank, cnt, cand,
-                           projA, projB, w2, b2, logits);
+        if (K <= 128) {
+            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T>), lds));
+            hipLaunchKernelGGL(k_score_tiled<SCORE_T>, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, order,
+                               rank, cnt, cand, projA, projB, w2, b2, logits);
+        } else {
+            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T_WIDE>), lds));
+            hipLaunchKernelGGL(k_score_tiled<SCORE_T_WIDE>, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K,
+                               order, rank, cnt, cand, projA, projB, w2, b2, logits);
+        }
         AIG_LAUNCH_CHECK();
         return AIG_OK;
     }

@@ -22,7 +22,9 @@ namespace {
 constexpr int H = AIG_HIDDEN;
 constexpr int THREADS = 256;
 constexpr int HW_PER_BLOCK = THREADS / 32;
-constexpr int ROWS_PER_HW = 32;  // sorted rows walked by one half-wave
+// Sorted rows walked by one half-wave: 8 while that still leaves the walk short of a few thousand blocks (at
+// 100k nodes 32 rows made 391 blocks, six waves per CU, and the walk ran at latency, not bandwidth), 32 beyond.
+__host__ __device__ inline int rows_per_halfwave(long long n) { return n >= (1 << 19) ? 32 : 8; }
 
 // Plan header, four int32 in device memory, for a plan built without a host read of the depth vector
 // (aig_level_plan_dyn): {deepest level L, nodes with a level, flags, 0}; flag bit 0 = no node carries a valid
@@ -59,7 +61,13 @@ __global__ void k_level_scan(int n, int L_cap, const long long* __restrict__ dep
         cnt += __shfl_xor(cnt, off);
         over |= __shfl_xor(over, off);
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one set of atomics per block (every wave updating the three words itself cost 38 us at 100k nodes)
+    __shared__ int s_top[4], s_cnt[4], s_over[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_top[wave] = top; s_cnt[wave] = cnt; s_over[wave] = over; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { top = max(top, s_top[k]); cnt += s_cnt[k]; over |= s_over[k]; }
         if (top >= 0) atomicMax(meta + META_L, top);
         if (cnt) atomicAdd(meta + META_NVALID, cnt);
         if (over) atomicOr(meta + META_FLAGS, 2);
@@ -118,7 +126,7 @@ __device__ __forceinline__ float unpack_val(unsigned long long p) {
     return __uint_as_float(b);
 }
 
-__global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const int* __restrict__ meta,
+__global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, int rows_per_hw, const int* __restrict__ meta,
                                                        const float* __restrict__ h,
                                                        const int* __restrict__ perm,
                                                        const int* __restrict__ node_level,
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void k_pool_walk(int nvalid, const int* __
     // with a header the grid covers every node and half-waves past the valid rows add nothing (never more rows
     // than the launch was sized for, whatever the header says)
     if (meta) nvalid = min(nvalid, meta[META_NVALID]);
-    const int p0 = item * ROWS_PER_HW, p1 = min(nvalid, p0 + ROWS_PER_HW);
+    const int p0 = item * rows_per_hw, p1 = min(nvalid, p0 + rows_per_hw);
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
     int4 mi = make_int4(0, 0, 0, 0);
@@ -286,7 +294,7 @@ int level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_
         hipLaunchKernelGGL(k_level_meta_init, dim3(1), dim3(64), 0, s, meta);
         AIG_LAUNCH_CHECK();
         if (depth && n > 0) {
-            hipLaunchKernelGGL(k_level_scan, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, (int)n, (int)L,
+            hipLaunchKernelGGL(k_level_scan, dim3(grid_for(n, 256 * 8, 128)), dim3(256), 0, s, (int)n, (int)L,
                                reinterpret_cast<const long long*>(depth), meta);
             AIG_LAUNCH_CHECK();
         }
@@ -332,7 +340,8 @@ extern "C" int aig_level_plan_dyn(int64_t n, int64_t L_cap, const int64_t* depth
 }
 
 extern "C" size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L) {
-    size_t items = (size_t)((n > 0 ? n : 1) + ROWS_PER_HW - 1) / ROWS_PER_HW;
+    const size_t rows = (size_t)rows_per_halfwave(n);
+    size_t items = ((size_t)(n > 0 ? n : 1) + rows - 1) / rows;
     size_t blocks = (items + HW_PER_BLOCK - 1) / HW_PER_BLOCK;
     return align_up((size_t)(L + 1) * H * 8) + align_up(blocks * H * 4) + 256;
 }
@@ -354,10 +363,11 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const in
     float* partial = nullptr;
     if (nvalid > 0) {
         AIG_REQUIRE(h && perm && node_level && w, "aig_level_pool_fwd: null pointer");
-        int64_t items = (nvalid + ROWS_PER_HW - 1) / ROWS_PER_HW;
+        const int rows = rows_per_halfwave(n);
+        int64_t items = (nvalid + rows - 1) / rows;
         blocks = (int)((items + HW_PER_BLOCK - 1) / HW_PER_BLOCK);
         partial = c.take<float>((size_t)blocks * H);
-        hipLaunchKernelGGL(k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, lvl_meta, h, perm, node_level, w,
+        hipLaunchKernelGGL(k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, rows, lvl_meta, h, perm, node_level, w,
                            table, partial);
         AIG_LAUNCH_CHECK();
     }

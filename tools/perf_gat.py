@@ -16,7 +16,10 @@ fake = enforce_aig_constraints(G(Data(x=g.x.to(dev), node_depth=g.node_depth.to(
 D = AIGDiscriminator().to(dev)
 graphs = {"real": (g.edge_index.to(dev), g.edge_attr.to(dev)), "fake": (fake.edge_index, fake.edge_attr)}
 n = g.x.size(0)
+only = sys.argv[1] if len(sys.argv) > 1 else None      # "real" / "fake": one graph kind (for per-kernel profiles)
 for name, (ei, ea) in graphs.items():
+    if only and name != only:
+        continue
     csr = GraphCSR(ei, ea, n)
     x = torch.randn(n, 128, device=dev, requires_grad=True)
     for _ in range(3):
