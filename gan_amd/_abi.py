@@ -27,6 +27,15 @@ class GenWeights(C.Structure):
         "sc0_w", "sc0_b", "sc2_w", "sc2_b", "at0_w", "at0_b", "at2_w", "at2_b")]
 
 
+class GenWireSet(C.Structure):
+    """Mirror of ``aig_gen_wire_set``."""
+    _fields_ = ([(n, I64) for n in ("B", "n", "K", "ecap", "plan_shared", "x_shared")] +
+                [(n, P) for n in ("x", "order", "rank", "want", "cnt", "fb", "eoff", "cand", "proj")] +
+                [("proj_rows", I64)] +
+                [(n, P) for n in ("sc2_w", "sc2_b", "at2_w", "at2_b", "logits", "sel", "edge_index", "edge_attr",
+                                  "ecount", "x_out")])
+
+
 # name -> (restype, argtypes); every symbol of include/aig_abi.h appears here
 SIGNATURES = {
     "aig_abi_version": (INT, []),
@@ -78,6 +87,17 @@ SIGNATURES = {
     "aig_validate": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
     "aig_resync_ws_bytes": (SZ, [I64, I64]),
     "aig_resync": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
+    "aig_gen_batch_rows": (I64, [I64]),
+    "aig_gen_node_proj_batch_ws_bytes": (SZ, [I64, I64, INT]),
+    "aig_gen_node_proj_batch": (INT, [I64, I64, P, INT, P, P, INT, P, P, SZ, P]),
+    "aig_gen_wire_batch": (INT, [P, P]),
+    "aig_enforce_batch_ws_bytes": (SZ, [I64, I64, I64]),
+    "aig_enforce_batch": (INT, [I64, I64, I64, P, P, P, P, INT, P, I64, P, I64, P, P, P, P, P, SZ, P]),
+    "aig_penalties_batch_ws_bytes": (SZ, [I64, I64, I64]),
+    "aig_penalties_batch": (INT, [I64, I64, I64, P, P, P, P, P, SZ, P]),
+    "aig_resync_batch_ws_bytes": (SZ, [I64, I64, I64]),
+    "aig_resync_batch": (INT, [I64, I64, I64, P, P, P, P, P, P, SZ, P]),
+    "aig_pad_batch": (INT, [I64, I64, I64, P, P, P, I64, P, P, P]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ import torch
 
 from . import _abi
 from .data import Data
+from .graphset import GraphSet
 
 PI, PO, AND = 0, 1, 2
 
@@ -256,3 +257,85 @@ def resync_attrs(d: Data) -> Data:
     d.x[:, 1] = inv_cnt
     d.node_depth = depth
     return d
+
+
+# ------------------------------------------------------------------------------------------ sets of graphs
+def _set_depth_arg(gs: GraphSet):
+    nd = gs.node_depth
+    if nd is None or nd.numel() not in (gs.n, gs.B * gs.n):
+        return 0, None, 0
+    stride = 0 if (nd.numel() == gs.n and gs.B > 1) else gs.n
+    if nd.dtype.is_floating_point:
+        return 1, nd.to(torch.float32).contiguous(), stride
+    return 2, nd.to(torch.int64).contiguous(), stride
+
+
+def enforce_set(gs: GraphSet, want_depth: bool = True) -> GraphSet:
+    """``enforce_aig_constraints`` on every graph of the set, one call: returns a new set (``cap = 2n`` edge
+    slots per graph, counts on the device - no host read) whose graphs equal the single-graph repair's."""
+    lib = _abi.lib()
+    _need_gpu(gs.x, "enforce_set")
+    dev = gs.x.device
+    B, n = gs.B, gs.n
+    cap = 2 * n
+    kind, depth, stride = _set_depth_arg(gs)
+    out_ei = torch.empty((B, 2, cap), dtype=torch.int64, device=dev)
+    out_ea = torch.empty((B, cap), dtype=torch.int64, device=dev)
+    out_cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    node_depth = torch.empty(B * n, dtype=torch.int64, device=dev) if want_depth else None
+    x_out = torch.empty((B * n, 2), dtype=torch.float32, device=dev)
+    ws = _abi.workspace(lib.aig_enforce_batch_ws_bytes(B, n, gs.ecap), dev)
+    _abi.check(_abi.timed("aig_enforce_batch", lib.aig_enforce_batch, B, n, gs.ecap, _abi.ptr(gs.count), _abi.ptr(gs.x),
+                          _abi.ptr(gs.edge_index), _abi.ptr(gs.edge_attr), kind, _abi.ptr(depth), stride,
+                          _abi.ptr(out_ei), cap, _abi.ptr(out_ea), _abi.ptr(out_cnt), _abi.ptr(node_depth),
+                          _abi.ptr(x_out), _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_enforce_batch")
+    return GraphSet(B, n, cap, x_out, out_ei, out_ea, out_cnt, node_depth, x_dtype=gs.x_dtype)
+
+
+def penalties_set(gs: GraphSet) -> torch.Tensor:
+    """``aig_constraint_penalties`` (default weights) of every graph: float32 ``[B, 9]`` in the order of
+    ``PENALTY_KEYS`` + total, on the device."""
+    lib = _abi.lib()
+    _need_gpu(gs.x, "penalties_set")
+    dev = gs.x.device
+    out = torch.empty((gs.B, 9), dtype=torch.float32, device=dev)
+    ws = _abi.workspace(lib.aig_penalties_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
+    _abi.check(_abi.timed("aig_penalties_batch", lib.aig_penalties_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
+                          _abi.ptr(gs.x), _abi.ptr(gs.edge_index), _abi.ptr(out), _abi.ptr(ws), ws.numel(), _abi.stream()),
+               "aig_penalties_batch")
+    return out
+
+
+def resync_set(gs: GraphSet) -> GraphSet:
+    """``resync_attrs`` on every graph of the set (in place: ``x[:, 1]`` and ``node_depth``)."""
+    lib = _abi.lib()
+    _need_gpu(gs.x, "resync_set")
+    dev = gs.x.device
+    N = gs.B * gs.n
+    inv_cnt = torch.empty(N, dtype=torch.int64, device=dev)
+    depth = torch.empty(N, dtype=torch.int64, device=dev)
+    ws = _abi.workspace(lib.aig_resync_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
+    _abi.check(_abi.timed("aig_resync_batch", lib.aig_resync_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
+                          _abi.ptr(gs.edge_index), _abi.ptr(gs.edge_attr), _abi.ptr(inv_cnt), _abi.ptr(depth),
+                          _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync_batch")
+    gs.x[:, 1] = inv_cnt
+    gs.node_depth = depth
+    return gs
+
+
+def repair_and_resync_set(gs: GraphSet) -> GraphSet:
+    """``repair_and_resync`` on every graph of the set: two calls, no host read in between."""
+    return resync_set(enforce_set(gs, want_depth=False))
+
+
+def pad_set(gs: GraphSet, max_edges: int):
+    """Edge tensors of the padded minibatch made of the set's graphs - what ``pad_data`` on every graph and
+    the batch concatenation give: ``edge_index [2, B*max_edges]`` (node offsets added, ``-1`` pad columns shifted
+    like the rest) and ``edge_attr [B*max_edges, 1]``."""
+    lib = _abi.lib()
+    dev = gs.x.device
+    ei = torch.empty((2, gs.B * max_edges), dtype=torch.int64, device=dev)
+    ea = torch.empty((gs.B * max_edges, 1), dtype=torch.int64, device=dev)
+    _abi.check(lib.aig_pad_batch(gs.B, gs.n, gs.ecap, _abi.ptr(gs.count), _abi.ptr(gs.edge_index), _abi.ptr(gs.edge_attr),
+                                 int(max_edges), _abi.ptr(ei), _abi.ptr(ea), _abi.stream()), "aig_pad_batch")
+    return ei, ea

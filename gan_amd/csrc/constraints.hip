@@ -33,21 +33,54 @@ __global__ void k_type_flags(int n, const float* __restrict__ x, int* __restrict
         flags[i] = {t == PI_T, t == AND_T, t == PO_T, (t != PI_T && t != AND_T && t != PO_T)};
     }
 }
-// pos = rank in (all PI, all AND, all PO, anything else), index order inside a group
-// (constraints.py:118-132).  scan[n] holds the group totals.
-__global__ void k_pos(int n, const int* __restrict__ types, const Cnt4* __restrict__ scan, int* __restrict__ pos,
-                      int* __restrict__ small /*[3]*/) {
-    const Cnt4 tot = scan[n];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+// A set of B graphs of n nodes each, worked on as one graph of N = B n nodes: node i of graph g is union
+// node g n + i.  Edge slot e of graph g: source ei[(2g) ecap + e], target ei[(2g + 1) ecap + e], inversion
+// value ea[g ecap + e]; only the first ecount[g] slots of a graph hold edges (all ecap when ecount is null).
+// A single graph is the set B = 1, ecap = E.  Graphs never share an edge, so sorts, scans and level-by-level
+// walks over the union give every graph the result it gets alone; what is per graph by definition
+// (ranks among a graph's own nodes, counts, the cycle verdict) is taken per graph below.
+struct GraphSet {
+    int B, n, ecap;
+    const int* ecount;
+    __host__ __device__ int N() const { return B * n; }
+    __host__ __device__ int M() const { return B * ecap; }
+    // a graph without a single edge takes the early exits of the reference (constraints.py:264-269,517-522)
+    __device__ bool empty(int g) const { return ecount && ecount[g] <= 0; }
+};
+__device__ __forceinline__ Cnt4 operator-(const Cnt4& x, const Cnt4& y) { return {x.a - y.a, x.b - y.b, x.c - y.c, x.d - y.d}; }
+
+// pos = rank in (all PI, all AND, all PO, anything else) among the nodes of the node's own graph, index
+// order inside a group (constraints.py:118-132).  small[3g + p] = union id of the PI/AND node of graph g
+// at pos p < 3.
+__global__ void k_pos(GraphSet gs, const int* __restrict__ types, const Cnt4* __restrict__ scan, int* __restrict__ pos,
+                      int* __restrict__ small /*[3 B]*/) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int g = i / gs.n;
+        const Cnt4 base = scan[g * gs.n];
+        const Cnt4 tot = scan[(g + 1) * gs.n] - base;
         const int t = types[i];
-        const Cnt4 s = scan[i];
+        const Cnt4 s = scan[i] - base;
         int p = t == PI_T ? s.a : t == AND_T ? tot.a + s.b : t == PO_T ? tot.a + tot.b + s.c : tot.a + tot.b + tot.c + s.d;
         pos[i] = p;
-        if (small && p < 3 && (t == PI_T || t == AND_T)) small[p] = i;
+        if (small && p < 3 && (t == PI_T || t == AND_T)) small[3 * g + p] = i;
     }
 }
 
 __device__ __forceinline__ bool in_range(long long u, long long v, int n) { return u >= 0 && u < n && v >= 0 && v < n; }
+
+// Edge slot `e` of the set (0 <= e < B ecap): its graph and its endpoints as the input holds them (ids inside
+// the graph, whatever their value); false for a slot past its graph's edge count.
+__device__ __forceinline__ bool load_edge(const GraphSet& gs, const long long* __restrict__ ei, int e, int& g,
+                                          long long& u, long long& v) {
+    g = gs.B == 1 ? 0 : e / gs.ecap;
+    const int le = e - g * gs.ecap;
+    if (gs.ecount && le >= gs.ecount[g]) return false;
+    const size_t row = (size_t)(2 * g) * gs.ecap + le;
+    u = ei[row];
+    v = ei[row + gs.ecap];
+    return true;
+}
 
 // ------------------------------------------------------------------------------------------ sort helpers
 int bits_for(unsigned long long maxval) {
@@ -91,7 +124,8 @@ __global__ void k_segment_ptr(int n, int E, const K* __restrict__ skey, K scale,
 // Level-synchronous frontier walk by ONE workgroup over CSR (ptr, adj).
 //   MODE 0: breadth-first levels; depth[] preset to 0 on the sources and -1 elsewhere.
 //   MODE 1: Kahn peel; state[] = indegree, every node released in the round after its last
-//           predecessor, so depth = longest-path level; *popped counts released nodes.
+//           predecessor, so depth = longest-path level (-1: never released, the node sits on or behind a
+//           cycle); *popped counts released nodes.
 //           (state[] is scratch: it is counted down in place or left as it was.)
 // Every wave leaves through the same `break` (the frontier size is read between two barriers),
 // and the loop ends after at most n rounds because a node enters a queue at most once.
@@ -148,7 +182,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs)
     for (int i = tid; i < n; i += TRAV_THREADS) {
         bool start;
         if (MODE == 0) start = depth[i] == 0;
-        else { start = state[i] == 0; depth[i] = 0; }
+        else { start = state[i] == 0; depth[i] = start ? 0 : -1; }
         if (start) q0[atomicAdd(&s_cnt[0], 1)] = i;
     }
     int cur = 0;
@@ -356,7 +390,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
     for (int i = tid; i < n; i += TRAV_THREADS) {
         bool start;
         if (MODE == 0) start = depth[i] == 0;
-        else { start = state[i] == 0; depth[i] = 0; }
+        else { start = state[i] == 0; depth[i] = -1; }
         if (start) {
             if (MODE == 0) atomicOr(&t.bits[i >> 5], 1u << (i & 31));
             q_put(t, 0, atomicAdd(&s_cnt[0], 1), i);
@@ -438,11 +472,17 @@ int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* re
     return AIG_OK;
 }
 
-// adjacency in sorted order: adj[p] = other endpoint of edge sid[p]
-__global__ void k_gather_adj(int m, const int* __restrict__ sid, const long long* __restrict__ endpoint,
+// adjacency in sorted order: adj[p] = other endpoint (union id) of edge slot sid[p]; which = 1: the target
+__global__ void k_gather_adj(GraphSet gs, const int* __restrict__ sid, const long long* __restrict__ ei, int which,
                              int* __restrict__ adj) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x)
-        adj[p] = (int)endpoint[sid[p]];
+    const int m = gs.M();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
+        int g;
+        long long u = -1, v = -1;
+        const bool have = load_edge(gs, ei, sid[p], g, u, v);
+        const long long w = which ? v : u;
+        adj[p] = have && w >= 0 && w < gs.n ? g * gs.n + (int)w : 0;   // entries past the valid keys are never read
+    }
 }
 
 __global__ void k_seed_depth(int n, const int* __restrict__ types, int want_type, int* __restrict__ depth) {
@@ -452,13 +492,17 @@ __global__ void k_seed_depth(int n, const int* __restrict__ types, int want_type
 
 // ------------------------------------------------------------------------------------------ enforce
 // key of a cleaned edge = v*n + u (grouped by target, then source); dropped edges sort last
-__global__ void k_enf_keys(int n, int E, const long long* __restrict__ ei, const int* __restrict__ pos,
+__global__ void k_enf_keys(GraphSet gs, const long long* __restrict__ ei, const int* __restrict__ pos,
                            unsigned long long* __restrict__ key, unsigned* __restrict__ key_src, int* __restrict__ ids) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        long long u = ei[e], v = ei[(size_t)E + e];
-        bool ok = u != v && in_range(u, v, n) && pos[u] < pos[v];
-        key[e] = ok ? (unsigned long long)v * (unsigned long long)n + (unsigned long long)u : ~0ull;
-        key_src[e] = ok ? (unsigned)u : (unsigned)n;
+    const int M = gs.M(), N = gs.N();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M; e += gridDim.x * blockDim.x) {
+        int g;
+        long long u = -1, v = -1;
+        bool ok = load_edge(gs, ei, e, g, u, v) && u != v && in_range(u, v, gs.n);
+        const int gu = g * gs.n + (int)u, gv = g * gs.n + (int)v;
+        ok = ok && pos[gu] < pos[gv];
+        key[e] = ok ? (unsigned long long)gv * (unsigned long long)N + (unsigned long long)gu : ~0ull;
+        key_src[e] = ok ? (unsigned)gu : (unsigned)N;
         ids[e] = e;
     }
 }
@@ -484,23 +528,26 @@ struct Pick {
     int count;
 };
 
-__device__ __forceinline__ long long depth_trunc(int kind, const void* depth, int u) {
+__device__ __forceinline__ long long depth_trunc(int kind, const void* depth, size_t u) {
     if (kind == 1) return (long long)static_cast<const float*>(depth)[u];  // int(): toward zero
     if (kind == 2) return static_cast<const long long*>(depth)[u];
     return 0;
 }
 
 // one thread per target: choose the fan-ins to keep (constraints.py:558-620) and sum inversions
-__global__ void k_enf_select(int n, const int* __restrict__ types, const int* __restrict__ pos,
+// (ids are union ids here; depth holds depth_stride entries per graph - 0: one vector shared by all graphs)
+__global__ void k_enf_select(GraphSet gs, const int* __restrict__ types, const int* __restrict__ pos,
                              const int* __restrict__ small, const Cnt4* __restrict__ scan,
                              const unsigned long long* __restrict__ skey, const long long* __restrict__ minv,
                              const int* __restrict__ vptr, int depth_kind, const void* __restrict__ depth,
-                             Pick* __restrict__ picks, int* __restrict__ pick_cnt, float* __restrict__ x_out,
-                             const float* __restrict__ x) {
-    const Cnt4 tot = scan[n];
-    const int n_src_nodes = tot.a + tot.b;  // PI + AND
+                             long long depth_stride, Pick* __restrict__ picks, int* __restrict__ pick_cnt,
+                             float* __restrict__ x_out, const float* __restrict__ x) {
+    const int n = gs.N();
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += gridDim.x * blockDim.x) {
         if (v == n) { pick_cnt[n] = 0; continue; }
+        const int g = v / gs.n;
+        const Cnt4 tot = scan[(g + 1) * gs.n] - scan[g * gs.n];
+        const int n_src_nodes = tot.a + tot.b;  // PI + AND of the node's graph
         const int t = types[v];
         const int beg = vptr[v], end = vptr[v + 1];
         Pick pk{-1, -1, 0, 0, 0};
@@ -512,13 +559,13 @@ __global__ void k_enf_select(int n, const int* __restrict__ types, const int* __
             const long long iv = minv[p];
             if (iv == LLONG_MIN) continue;  // repeat of the previous pair
             inv_sum += iv;
-            const int u = (int)(skey[p] - (unsigned long long)v * (unsigned long long)n);
+            const int u = (int)(skey[p] - (unsigned long long)v * (unsigned long long)n);  // n = nodes of the union
             const int tu = types[u];
             if (!(tu == PI_T || tu == AND_T)) continue;
             ++nl;
             if (t == PO_T) {
                 const int is_and = tu == AND_T;
-                const long long dep = depth_trunc(depth_kind, depth, u);
+                const long long dep = depth_trunc(depth_kind, depth, (size_t)g * depth_stride + (u - g * gs.n));
                 bool better;
                 if (pk.s0 < 0) better = true;
                 else if (is_and != b_and) better = is_and > b_and;
@@ -531,14 +578,15 @@ __global__ void k_enf_select(int n, const int* __restrict__ types, const int* __
                 else if (pu < p2) { p2 = pu; pk.s1 = u; pk.i1 = iv; }
             }
         }
-        if (t == PO_T) pk.count = nl >= 1 ? 1 : 0;
+        if (gs.empty(g)) pk.count = 0;   // no edge at all: nothing is repaired
+        else if (t == PO_T) pk.count = nl >= 1 ? 1 : 0;
         else if (t == AND_T) {
             if (nl >= 2) pk.count = 2;
             else if (n_src_nodes - 1 >= 2) {
                 // widen with every other PI/AND node (inversion 0): the two smallest pos besides v
                 int c0 = -1, c1 = -1;
                 for (int j = 0; j < 3; ++j) {
-                    int u = j < n_src_nodes ? small[j] : -1;
+                    int u = j < n_src_nodes ? small[3 * g + j] : -1;
                     if (u < 0 || u == v) continue;
                     if (c0 < 0) c0 = u; else if (c1 < 0) c1 = u;
                 }
@@ -556,79 +604,110 @@ __global__ void k_enf_select(int n, const int* __restrict__ types, const int* __
     }
 }
 
-__global__ void k_enf_write(int n, long long cap, const Pick* __restrict__ picks, const int* __restrict__ off,
+// graph g's repaired edges go to its own slots: sources out_ei[(2g) cap + ..], targets out_ei[(2g + 1) cap + ..]
+// (ids inside the graph again), out_count[g] of them, in target order
+__global__ void k_enf_write(GraphSet gs, long long cap, const Pick* __restrict__ picks, const int* __restrict__ off,
                             long long* __restrict__ out_ei, long long* __restrict__ out_ea, int* __restrict__ out_count) {
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const int N = gs.N();
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
         const Pick pk = picks[v];
-        const int o = off[v];
-        if (pk.count >= 1) { out_ei[o] = pk.s0; out_ei[cap + o] = v; out_ea[o] = pk.i0; }
-        if (pk.count >= 2) { out_ei[o + 1] = pk.s1; out_ei[cap + o + 1] = v; out_ea[o + 1] = pk.i1; }
-        if (v == 0) *out_count = off[n];
+        const int g = v / gs.n, first = g * gs.n;
+        const int o = off[v] - off[first];
+        long long* src = out_ei + (size_t)(2 * g) * cap;
+        long long* dst = src + cap;
+        long long* ea = out_ea + (size_t)g * cap;
+        if (pk.count >= 1) { src[o] = pk.s0 - first; dst[o] = v - first; ea[o] = pk.i0; }
+        if (pk.count >= 2) { src[o + 1] = pk.s1 - first; dst[o + 1] = v - first; ea[o + 1] = pk.i1; }
+        if (v == first) out_count[g] = off[first + gs.n] - off[first];
     }
 }
 
-__global__ void k_widen_i32_i64(int n, const int* __restrict__ in, long long* __restrict__ out) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+// breadth-first levels as int64; a graph without edges reports -1 everywhere (constraints.py:517-522)
+__global__ void k_enf_depth_out(GraphSet gs, const int* __restrict__ in, long long* __restrict__ out) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        out[i] = gs.empty(i / gs.n) ? -1 : in[i];
 }
 
 // ------------------------------------------------------------------------------------------ penalties / validate
-// counters: 0 pi_in, 1 po_out, 2 backedge, 3 selfloop, 4 fanin_type
-__global__ void k_pen_edges(int n, int E, const long long* __restrict__ ei, const int* __restrict__ types,
+// counters (PEN_CTRS per graph): 0 pi_in, 1 po_out, 2 backedge, 3 selfloop, 4 fanin_type
+constexpr int PEN_CTRS = 16;
+__global__ void k_pen_edges(GraphSet gs, const long long* __restrict__ ei, const int* __restrict__ types,
                             const int* __restrict__ pos, int* __restrict__ counters, int* __restrict__ indeg,
                             unsigned long long* __restrict__ pair_key, unsigned* __restrict__ key_src,
                             unsigned* __restrict__ key_dst, int* __restrict__ ids, unsigned char* __restrict__ eflag) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        long long u = ei[e], v = ei[(size_t)E + e];
+    const int M = gs.M(), N = gs.N();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M; e += gridDim.x * blockDim.x) {
+        int g;
+        long long lu = -1, lv = -1;
+        const bool have = load_edge(gs, ei, e, g, lu, lv);
         ids[e] = e;
-        if (!in_range(u, v, n)) {  // the reference cannot index such an edge; it is left out of every count
-            pair_key[e] = ~0ull; key_src[e] = (unsigned)n; key_dst[e] = (unsigned)n;
+        if (!have || !in_range(lu, lv, gs.n)) {  // the reference cannot index such an edge; it is left out of every count
+            pair_key[e] = ~0ull; key_src[e] = (unsigned)N; key_dst[e] = (unsigned)N;
             if (eflag) eflag[e] = 0;
             continue;
         }
+        const int u = g * gs.n + (int)lu, v = g * gs.n + (int)lv;
         const int tu = types[u], tv = types[v];
         const bool self = u == v, to_pi = tv == PI_T, from_po = tu == PO_T, back = !(pos[u] < pos[v]);
         const bool bad_src = (tv == AND_T || tv == PO_T) && !(tu == PI_T || tu == AND_T);
         if (counters) {
-            if (to_pi) atomicAdd(&counters[0], 1);
-            if (from_po) atomicAdd(&counters[1], 1);
-            if (back) atomicAdd(&counters[2], 1);
-            if (self) atomicAdd(&counters[3], 1);
-            if (bad_src) atomicAdd(&counters[4], 1);
+            int* c = counters + g * PEN_CTRS;
+            if (to_pi) atomicAdd(&c[0], 1);
+            if (from_po) atomicAdd(&c[1], 1);
+            if (back) atomicAdd(&c[2], 1);
+            if (self) atomicAdd(&c[3], 1);
+            if (bad_src) atomicAdd(&c[4], 1);
         }
         if (eflag) eflag[e] = (unsigned char)((self ? 1 : 0) | (to_pi ? 4 : 0) | (from_po ? 8 : 0) | (bad_src ? 16 : 0));
         atomicAdd(&indeg[v], 1);
-        pair_key[e] = (unsigned long long)u * (unsigned long long)n + (unsigned long long)v;
+        pair_key[e] = (unsigned long long)u * (unsigned long long)N + (unsigned long long)v;
         key_src[e] = (unsigned)u;
         key_dst[e] = (unsigned)v;
     }
 }
 
 // counters[5] += repeats of an already seen (u,v); flags those edges with bit 2 (validator)
-__global__ void k_pen_dups(int E, const unsigned long long* __restrict__ skey, const int* __restrict__ sid,
+__global__ void k_pen_dups(GraphSet gs, const unsigned long long* __restrict__ skey, const int* __restrict__ sid,
                            int* __restrict__ counters, unsigned char* __restrict__ eflag) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E; p += gridDim.x * blockDim.x) {
+    const int M = gs.M();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < M; p += gridDim.x * blockDim.x) {
         if (p == 0 || skey[p] == ~0ull || skey[p] != skey[p - 1]) continue;
-        if (counters) atomicAdd(&counters[5], 1);
+        if (counters) {
+            const int g = gs.B == 1 ? 0 : (int)(skey[p] / (unsigned long long)gs.N()) / gs.n;   // the pair's source
+            atomicAdd(&counters[g * PEN_CTRS + 5], 1);
+        }
         if (eflag) eflag[sid[p]] |= 2;
     }
 }
 
 // counters[6] += |indeg - target|; counters[7] += node not (reached forward from a PI and backward from a PO)
-__global__ void k_pen_nodes(int n, const int* __restrict__ types, const int* __restrict__ indeg,
+__global__ void k_pen_nodes(GraphSet gs, const int* __restrict__ types, const int* __restrict__ indeg,
                             const int* __restrict__ fwd, const int* __restrict__ rev, int* __restrict__ counters,
                             unsigned char* __restrict__ on_path) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        int* c = counters + (i / gs.n) * PEN_CTRS;
         const int t = types[i];
         const int target = t == PO_T ? 1 : (t == AND_T ? 2 : 0);
         const int d = indeg[i] - target;
-        if (d) atomicAdd(&counters[6], d < 0 ? -d : d);
+        if (d) atomicAdd(&c[6], d < 0 ? -d : d);
         const bool ok = fwd[i] >= 0 && rev[i] >= 0;
-        if (!ok) atomicAdd(&counters[7], 1);
+        if (!ok) atomicAdd(&c[7], 1);
         if (on_path) on_path[i] = ok;
     }
 }
 
-__global__ void k_pen_finish(const int* __restrict__ c, float* __restrict__ out) {
+// one thread per graph: out[9 g ..]
+__global__ void k_pen_finish(GraphSet gs, const int* __restrict__ counters, float* __restrict__ out9) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gs.B) return;
+    const int* c = counters + g * PEN_CTRS;
+    float* out = out9 + 9 * g;
+    if (gs.empty(g)) {   // no edge: every term is zero (constraints.py:264-269)
+        for (int i = 0; i < 9; ++i) out[i] = 0.f;
+        return;
+    }
     // pi_in, po_out, backedge, selfloop, dup_fanin, indeg_mse, fanin_type, reach_violation, total
     float pi_in = (float)c[0], po_out = (float)c[1], back = (float)c[2], self = (float)c[3], ftype = (float)c[4],
           dup = (float)c[5], mse = (float)c[6], reach = (float)c[7];
@@ -667,83 +746,109 @@ __global__ void k_val_summary(int n, const int* __restrict__ popped, const int* 
 }
 
 // ------------------------------------------------------------------------------------------ resync
-__global__ void k_rs_edges(int n, int E, const long long* __restrict__ ei, const long long* __restrict__ inv,
+__global__ void k_rs_edges(GraphSet gs, const long long* __restrict__ ei, const long long* __restrict__ inv,
                            int* __restrict__ inv_cnt, int* __restrict__ indeg, unsigned* __restrict__ key_src,
                            int* __restrict__ ids) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-        long long u = ei[e], v = ei[(size_t)E + e];
+    const int M = gs.M(), N = gs.N();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M; e += gridDim.x * blockDim.x) {
+        int g;
+        long long u = -1, v = -1;
+        const bool have = load_edge(gs, ei, e, g, u, v);
         ids[e] = e;
-        const bool ok = in_range(u, v, n);
-        if (v >= 0 && v < n && inv && inv[e] == 1) atomicAdd(&inv_cnt[v], 1);
-        key_src[e] = ok ? (unsigned)u : (unsigned)n;
-        if (ok) atomicAdd(&indeg[v], 1);
+        const bool ok = have && in_range(u, v, gs.n);
+        const int gv = g * gs.n + (int)v;
+        if (have && v >= 0 && v < gs.n && inv && inv[e] == 1) atomicAdd(&inv_cnt[gv], 1);
+        key_src[e] = ok ? (unsigned)(g * gs.n + (int)u) : (unsigned)N;
+        if (ok) atomicAdd(&indeg[gv], 1);
     }
 }
-__global__ void k_rs_finish(int n, const int* __restrict__ popped, const int* __restrict__ depth,
+// cyclic[g] = 1 when the Kahn peel left a node of graph g behind
+__global__ void k_rs_cyclic(GraphSet gs, const int* __restrict__ depth, int* __restrict__ cyclic) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        if (depth[i] < 0) cyclic[i / gs.n] = 1;
+}
+__global__ void k_rs_finish(GraphSet gs, const int* __restrict__ cyclic, const int* __restrict__ depth,
                             const int* __restrict__ inv_cnt, long long* __restrict__ depth_out,
                             long long* __restrict__ inv_out) {
-    const bool cyclic = popped[0] != n;  // networkx raises on a cycle and the depth falls back to zeros
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        depth_out[i] = cyclic ? 0 : depth[i];
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        // networkx raises on a cycle and the depth of that graph falls back to zeros
+        depth_out[i] = cyclic[i / gs.n] ? 0 : depth[i];
         inv_out[i] = inv_cnt[i];
     }
 }
 
 inline int g256(int64_t items) { return grid_for(items, 256, 4096); }
 
-// types/pos for n nodes into (types, pos, scan[n+1]); `flags` and `temp` are scratch
-int run_types_pos(hipStream_t s, int n, const float* x, int* types, int* pos, int* small, Cnt4* flags, Cnt4* scan,
-                  void* temp, size_t tb) {
+// types/pos for the N nodes of the set into (types, pos, scan[N+1]); `flags` and `temp` are scratch
+int run_types_pos(hipStream_t s, const GraphSet& gs, const float* x, int* types, int* pos, int* small, Cnt4* flags,
+                  Cnt4* scan, void* temp, size_t tb) {
+    const int n = gs.N();
     hipLaunchKernelGGL(k_type_flags, dim3(g256(n + 1)), dim3(256), 0, s, n, x, types, flags);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, flags, scan, Cnt4{0, 0, 0, 0}, (size_t)(n + 1), Cnt4Plus(), s));
-    if (small) AIG_HIP_CHECK(fill_words(small, 0xFFFFFFFFu, 3 * sizeof(int), s));
-    hipLaunchKernelGGL(k_pos, dim3(g256(n)), dim3(256), 0, s, n, types, scan, pos, small);
+    if (small) AIG_HIP_CHECK(fill_words(small, 0xFFFFFFFFu, (size_t)3 * gs.B * sizeof(int), s));
+    hipLaunchKernelGGL(k_pos, dim3(g256(n)), dim3(256), 0, s, gs, types, scan, pos, small);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 
-// CSR over the edges whose key (an endpoint id) is < n: ptr[n+1], adj = the other endpoint
-int run_csr(hipStream_t s, int n, int E, int bits, unsigned* key, unsigned* skey, int* ids, int* sid,
-            const long long* other_endpoint, int* ptr, int* adj, void* temp, size_t tb) {
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, sid, (size_t)E, 0, bits, s));
-    hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(n + 1)), dim3(256), 0, s, n, E, skey, 1u, ptr);
-    hipLaunchKernelGGL(k_gather_adj, dim3(g256(E)), dim3(256), 0, s, E, sid, other_endpoint, adj);
+// CSR over the edge slots whose key (an endpoint's union id) is < N: ptr[N+1], adj = the other endpoint
+int run_csr(hipStream_t s, const GraphSet& gs, int bits, unsigned* key, unsigned* skey, int* ids, int* sid,
+            const long long* ei, int other_is_target, int* ptr, int* adj, void* temp, size_t tb) {
+    const int N = gs.N(), M = gs.M();
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, sid, (size_t)M, 0, bits, s));
+    hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey, 1u, ptr);
+    hipLaunchKernelGGL(k_gather_adj, dim3(g256(M)), dim3(256), 0, s, gs, sid, ei, other_is_target, adj);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 
-}  // namespace
-}  // namespace aig
+struct Temps {
+    int kb;       // bits of a pair key
+    int nb;       // bits of a node key (N itself marks an absent edge)
+    size_t bytes; // scratch for the widest sort / scan
+};
+Temps temps_for(int64_t N, int64_t M) {
+    Temps t;
+    const unsigned long long n = (unsigned long long)(N > 0 ? N : 1);
+    t.kb = bits_for(n * n + n);
+    t.nb = bits_for(n);
+    const size_t t64 = sort_temp<unsigned long long>(M, t.kb), t32 = sort_temp<unsigned>(M, 32), ts = scan_temp(N + 2);
+    t.bytes = t64 > t32 ? t64 : t32;
+    t.bytes = t.bytes > ts ? t.bytes : ts;
+    return t;
+}
 
-using namespace aig;
+int check_set(const char* who, int64_t B, int64_t n, int64_t ecap) {
+    AIG_REQUIRE(B >= 1 && n > 0 && ecap > 0, "%s: needs B >= 1, n > 0 and edge slots > 0 (got %lld, %lld, %lld)", who,
+                (long long)B, (long long)n, (long long)ecap);
+    AIG_REQUIRE(B * n < INT_MAX && B * ecap < INT_MAX, "%s: %lld graphs of %lld nodes / %lld edge slots exceed 2^31", who,
+                (long long)B, (long long)n, (long long)ecap);
+    return AIG_OK;
+}
 
-// ============================================================================================ enforce
-extern "C" size_t aig_enforce_ws_bytes(int64_t n, int64_t E) {
-    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
-    int kb = bits_for((unsigned long long)N * N + N);
-    size_t t64 = sort_temp<unsigned long long>(E, kb < 64 ? kb : 64), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
-    size_t tmax = t64 > t32 ? t64 : t32;
-    tmax = tmax > ts ? tmax : ts;
+size_t enforce_ws(int64_t B, int64_t n, int64_t ecap) {
+    const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
+    const Temps t = temps_for((int64_t)N, (int64_t)M);
     return 2 * align_up((N + 1) * sizeof(Cnt4)) + 6 * align_up((N + 2) * 4) + align_up(N * sizeof(Pick)) +
-           2 * align_up(M * 8) + 5 * align_up(M * 4) + align_up(M * 8) + align_up((N + 2) * 16) + align_up(tmax) + 1024;
+           2 * align_up(M * 8) + 5 * align_up(M * 4) + align_up(M * 8) + align_up((N + 2) * 16) +
+           align_up((size_t)(3 * B + 16) * 4) + align_up(t.bytes) + 1024;
 }
 
-extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
-                           int depth_kind, const void* depth, int64_t* out_edge_index, int64_t cap,
-                           int64_t* out_edge_attr, int32_t* out_count, int64_t* node_depth, float* x_out, void* ws,
-                           size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_enforce: needs n > 0 and E > 0 (got %lld, %lld)",
-                (long long)n, (long long)E);
-    AIG_REQUIRE((double)n * (double)n < 1.8e19, "aig_enforce: n too large for 64-bit pair keys");
-    AIG_REQUIRE(x && edge_index && out_edge_index && out_edge_attr && out_count && x_out && ws,
-                "aig_enforce: null pointer");
-    AIG_REQUIRE(cap >= 2 * n, "aig_enforce: output capacity %lld < 2n", (long long)cap);
-    AIG_REQUIRE(depth_kind >= 0 && depth_kind <= 2 && (depth_kind == 0 || depth), "aig_enforce: bad depth argument");
-    if (ws_bytes < aig_enforce_ws_bytes(n, E))
-        return fail(AIG_EWORKSPACE, "aig_enforce: workspace %zu < %zu", ws_bytes, aig_enforce_ws_bytes(n, E));
+int enforce(const GraphSet& gs, const float* x, const int64_t* edge_index, const int64_t* edge_attr, int depth_kind,
+            const void* depth, int64_t depth_stride, int64_t* out_edge_index, int64_t cap, int64_t* out_edge_attr,
+            int32_t* out_count, int64_t* node_depth, float* x_out, void* ws, size_t ws_bytes, void* stream,
+            const char* who) {
+    AIG_REQUIRE(x && edge_index && out_edge_index && out_edge_attr && out_count && x_out && ws, "%s: null pointer", who);
+    AIG_REQUIRE(cap >= 2 * (int64_t)gs.n, "%s: output capacity %lld < 2n", who, (long long)cap);
+    AIG_REQUIRE(depth_kind >= 0 && depth_kind <= 2 && (depth_kind == 0 || depth), "%s: bad depth argument", who);
+    AIG_REQUIRE(depth_stride == 0 || depth_stride == gs.n, "%s: depth stride is 0 (shared) or n", who);
+    if (ws_bytes < enforce_ws(gs.B, gs.n, gs.ecap))
+        return fail(AIG_EWORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, enforce_ws(gs.B, gs.n, gs.ecap));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int N = (int)n, M = (int)E;
+    const int N = gs.N(), M = gs.M();
     Carver c(ws);
     Cnt4* flags = c.take<Cnt4>(N + 1);
     Cnt4* scan = c.take<Cnt4>(N + 1);
@@ -762,72 +867,64 @@ extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* 
     int* sid = c.take<int>(M);
     int* adj = c.take<int>(M);
     long long* minv = c.take<long long>(M);
-    int* small = c.take<int>(64);
+    int* small = c.take<int>(3 * gs.B + 16);
     int4* rec = c.take<int4>(N + 2);
-    const int kb = bits_for((unsigned long long)n * (unsigned long long)n + (unsigned long long)n);
-    size_t t64 = sort_temp<unsigned long long>(E, kb), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
-    size_t tb = t64 > t32 ? t64 : t32;
-    tb = tb > ts ? tb : ts;
+    const Temps t = temps_for(N, M);
+    size_t tb = t.bytes;
     void* temp = c.take<char>(tb);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     const long long* inv = reinterpret_cast<const long long*>(edge_attr);
 
-    int rc = run_types_pos(s, N, x, types, pos, small, flags, scan, temp, tb);
+    int rc = run_types_pos(s, gs, x, types, pos, small, flags, scan, temp, tb);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_enf_keys, dim3(g256(M)), dim3(256), 0, s, N, M, ei, pos, key64, key_src, ids);
+    hipLaunchKernelGGL(k_enf_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, key64, key_src, ids);
     AIG_LAUNCH_CHECK();
     // by (target, source): runs of equal pairs are adjacent, first occurrence first (stable)
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, kb, s));
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, t.kb, s));
     hipLaunchKernelGGL(k_enf_merge, dim3(g256(M)), dim3(256), 0, s, M, skey64, sid, inv, minv);
     hipLaunchKernelGGL(k_segment_ptr<unsigned long long>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey64,
-                       (unsigned long long)n, vptr);
-    hipLaunchKernelGGL(k_enf_select, dim3(g256(N + 1)), dim3(256), 0, s, N, types, pos, small, scan, skey64, minv, vptr,
-                       depth_kind, depth, picks, pick_cnt, x_out, x);
+                       (unsigned long long)N, vptr);
+    hipLaunchKernelGGL(k_enf_select, dim3(g256(N + 1)), dim3(256), 0, s, gs, types, pos, small, scan, skey64, minv, vptr,
+                       depth_kind, depth, (long long)depth_stride, picks, pick_cnt, x_out, x);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rocprim::exclusive_scan(temp, tb, pick_cnt, pick_off, 0, (size_t)(N + 1), rocprim::plus<int>(), s));
-    hipLaunchKernelGGL(k_enf_write, dim3(g256(N)), dim3(256), 0, s, N, (long long)cap, picks, pick_off,
+    hipLaunchKernelGGL(k_enf_write, dim3(g256(N)), dim3(256), 0, s, gs, (long long)cap, picks, pick_off,
                        reinterpret_cast<long long*>(out_edge_index), reinterpret_cast<long long*>(out_edge_attr),
                        out_count);
     AIG_LAUNCH_CHECK();
     if (!node_depth) return AIG_OK;  // the caller recomputes the depths anyway (sampling: resync follows)
     // node_depth: breadth-first level from the PIs over the cleaned (pre-repair) edges
-    rc = run_csr(s, N, M, 32, key_src, skey_src, ids, sid, ei + E, sptr, adj, temp, tb);
+    rc = run_csr(s, gs, 32, key_src, skey_src, ids, sid, ei, 1, sptr, adj, temp, tb);
     if (rc) return rc;
     int* depth32 = pick_cnt;  // free again
-    int* q0 = reinterpret_cast<int*>(flags);  // (n+1)*16 bytes each: room for n ints
+    int* q0 = reinterpret_cast<int*>(flags);  // (N+1)*16 bytes each: room for N ints
     int* q1 = reinterpret_cast<int*>(scan);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, nullptr, depth32, q0, q1, nullptr};
     if ((rc = run_traverse<0>(s, N, jobs, 1, rec, nullptr))) return rc;
-    hipLaunchKernelGGL(k_widen_i32_i64, dim3(g256(N)), dim3(256), 0, s, N, depth32, reinterpret_cast<long long*>(node_depth));
+    hipLaunchKernelGGL(k_enf_depth_out, dim3(g256(N)), dim3(256), 0, s, gs, depth32, reinterpret_cast<long long*>(node_depth));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 
-// ============================================================================================ penalties / validate
-static size_t graph_checks_ws_bytes(int64_t n, int64_t E) {
-    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
-    int kb = bits_for((unsigned long long)N * N + N);
-    size_t t64 = sort_temp<unsigned long long>(E, kb < 64 ? kb : 64), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
-    size_t tmax = t64 > t32 ? t64 : t32;
-    tmax = tmax > ts ? tmax : ts;
+size_t graph_checks_ws(int64_t B, int64_t n, int64_t ecap) {
+    const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
+    const Temps t = temps_for((int64_t)N, (int64_t)M);
     return 2 * align_up((N + 1) * sizeof(Cnt4)) + 12 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
-           8 * align_up(M * 4) + 2 * align_up((N + 2) * 16) + align_up(tmax) + 2048;
+           8 * align_up(M * 4) + 2 * align_up((N + 2) * 16) + align_up((size_t)(B + 1) * PEN_CTRS * 4) +
+           align_up(t.bytes) + 2048;
 }
 
-// shared body: counters (penalties) and/or flags (validator)
-static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edge_index, float* pen_out,
-                        unsigned char* eflag, unsigned char* ncode, int* indeg_out, int* pred2,
-                        unsigned char* on_path, int* summary, void* ws, size_t ws_bytes, void* stream,
-                        const char* who) {
-    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "%s: needs n > 0 and E > 0 (got %lld, %lld)", who,
-                (long long)n, (long long)E);
-    AIG_REQUIRE((double)n * (double)n < 1.8e19, "%s: n too large for 64-bit pair keys", who);
+// shared body: counters (penalties, any B) and/or flags (validator, one graph)
+int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, float* pen_out, unsigned char* eflag,
+                 unsigned char* ncode, int* indeg_out, int* pred2, unsigned char* on_path, int* summary, void* ws,
+                 size_t ws_bytes, void* stream, const char* who) {
     AIG_REQUIRE(x && edge_index && ws, "%s: null pointer", who);
-    if (ws_bytes < graph_checks_ws_bytes(n, E)) return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
+    AIG_REQUIRE(gs.B == 1 || !ncode, "%s: the validator takes one graph at a time", who);
+    if (ws_bytes < graph_checks_ws(gs.B, gs.n, gs.ecap)) return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int N = (int)n, M = (int)E;
+    const int N = gs.N(), M = gs.M();
     Carver c(ws);
     Cnt4* flags = c.take<Cnt4>(N + 1);
     Cnt4* scan = c.take<Cnt4>(N + 1);
@@ -852,30 +949,29 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
     int* sid = c.take<int>(M);
     int* sadj = c.take<int>(M);
     int* dadj = c.take<int>(M);
-    int* q1 = qx;                                  // second queue (n entries)
-    int* counters = c.take<int>(64);               // [0..7] counts, [8] Kahn popped
+    int* q1 = qx;                                                 // second queue (N entries)
+    int* counters = c.take<int>((size_t)(gs.B + 1) * PEN_CTRS);   // PEN_CTRS per graph, then [0] Kahn popped
+    int* popped = counters + (size_t)gs.B * PEN_CTRS;
     int4* rec0 = c.take<int4>(N + 2);
     int4* rec1 = c.take<int4>(N + 2);
-    const int kb = bits_for((unsigned long long)n * (unsigned long long)n + (unsigned long long)n);
-    size_t t64 = sort_temp<unsigned long long>(E, kb), t32 = sort_temp<unsigned>(E, 32), ts = scan_temp(n + 2);
-    size_t tb = t64 > t32 ? t64 : t32;
-    tb = tb > ts ? tb : ts;
+    const Temps t = temps_for(N, M);
+    size_t tb = t.bytes;
     void* temp = c.take<char>(tb);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
 
-    int rc = run_types_pos(s, N, x, types, pos, nullptr, flags, scan, temp, tb);
+    int rc = run_types_pos(s, gs, x, types, pos, nullptr, flags, scan, temp, tb);
     if (rc) return rc;
-    AIG_HIP_CHECK(fill_words(counters, 0u, 64 * sizeof(int), s));
+    AIG_HIP_CHECK(fill_words(counters, 0u, (size_t)(gs.B + 1) * PEN_CTRS * sizeof(int), s));
     AIG_HIP_CHECK(fill_words(indeg, 0u, (size_t)(N + 2) * sizeof(int), s));
-    hipLaunchKernelGGL(k_pen_edges, dim3(g256(M)), dim3(256), 0, s, N, M, ei, types, pos, counters, indeg, key64,
-                       key_src, key_dst, ids, eflag);
+    hipLaunchKernelGGL(k_pen_edges, dim3(g256(M)), dim3(256), 0, s, gs, ei, types, pos, counters, indeg, key64, key_src,
+                       key_dst, ids, eflag);
     AIG_LAUNCH_CHECK();
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, kb, s));
-    hipLaunchKernelGGL(k_pen_dups, dim3(g256(M)), dim3(256), 0, s, M, skey64, sid, counters, eflag);
+    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, t.kb, s));
+    hipLaunchKernelGGL(k_pen_dups, dim3(g256(M)), dim3(256), 0, s, gs, skey64, sid, counters, eflag);
     AIG_LAUNCH_CHECK();
     // forward reachability from the PIs, backward from the POs
-    if ((rc = run_csr(s, N, M, 32, key_src, skey32, ids, sid, ei + E, sptr, sadj, temp, tb))) return rc;
-    if ((rc = run_csr(s, N, M, 32, key_dst, skey32, ids, sid, ei, dptr, dadj, temp, tb))) return rc;
+    if ((rc = run_csr(s, gs, 32, key_src, skey32, ids, sid, ei, 1, sptr, sadj, temp, tb))) return rc;
+    if ((rc = run_csr(s, gs, 32, key_dst, skey32, ids, sid, ei, 0, dptr, dadj, temp, tb))) return rc;
     int* q0 = reinterpret_cast<int*>(flags);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, fwd);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PO_T, rev);
@@ -883,54 +979,34 @@ static int graph_checks(int64_t n, int64_t E, const float* x, const int64_t* edg
     jobs.j[0] = TravJob{sptr, sadj, nullptr, fwd, q0, q1, nullptr};
     jobs.j[1] = TravJob{dptr, dadj, nullptr, rev, q2, q3, nullptr};
     if ((rc = run_traverse<0>(s, N, jobs, 2, rec0, rec1))) return rc;
-    hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, fwd, rev, counters, on_path);
+    hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, gs, types, indeg, fwd, rev, counters, on_path);
     AIG_LAUNCH_CHECK();
-    if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3(1), dim3(1), 0, s, counters, pen_out);
+    if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3((gs.B + 63) / 64), dim3(64), 0, s, gs, counters, pen_out);
     if (ncode) {
         hipLaunchKernelGGL(k_val_nodes, dim3(g256(N)), dim3(256), 0, s, N, types, indeg, dptr, dadj, ncode, pred2);
         AIG_HIP_CHECK(hipMemcpyAsync(kdeg, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
         if (indeg_out) AIG_HIP_CHECK(hipMemcpyAsync(indeg_out, indeg, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, s));
         TravJobs kj{};
-        kj.j[0] = TravJob{sptr, sadj, kdeg, kdepth, q0, q1, counters + 8};
+        kj.j[0] = TravJob{sptr, sadj, kdeg, kdepth, q0, q1, popped};
         if ((rc = run_traverse<1>(s, N, kj, 1, rec0, nullptr))) return rc;
-        hipLaunchKernelGGL(k_val_summary, dim3(1), dim3(1), 0, s, N, counters + 8, counters, summary);
+        hipLaunchKernelGGL(k_val_summary, dim3(1), dim3(1), 0, s, N, popped, counters, summary);
     }
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 
-extern "C" size_t aig_penalties_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws_bytes(n, E); }
-
-extern "C" int aig_penalties(int64_t n, int64_t E, const float* x, const int64_t* edge_index, float* out9, void* ws,
-                             size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(out9, "aig_penalties: null output");
-    return graph_checks(n, E, x, edge_index, out9, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
-                        stream, "aig_penalties");
+size_t resync_ws(int64_t B, int64_t n, int64_t ecap) {
+    const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
+    return 7 * align_up((N + 2) * 4) + 5 * align_up(M * 4) + align_up((N + 2) * 16) + align_up((size_t)(B + 16) * 4) +
+           align_up(sort_temp<unsigned>((int64_t)M, 32)) + 1024;
 }
 
-extern "C" size_t aig_validate_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws_bytes(n, E); }
-
-extern "C" int aig_validate(int64_t n, int64_t E, const float* x, const int64_t* edge_index, uint8_t* eflag,
-                            uint8_t* ncode, int32_t* indeg, int32_t* pred2, uint8_t* on_path, int32_t* summary,
-                            void* ws, size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(eflag && ncode && indeg && pred2 && on_path && summary, "aig_validate: null output");
-    return graph_checks(n, E, x, edge_index, nullptr, eflag, ncode, indeg, pred2, on_path, summary, ws, ws_bytes,
-                        stream, "aig_validate");
-}
-
-// ============================================================================================ resync
-extern "C" size_t aig_resync_ws_bytes(int64_t n, int64_t E) {
-    size_t N = (size_t)(n > 0 ? n : 1), M = (size_t)(E > 0 ? E : 1);
-    return 7 * align_up((N + 2) * 4) + 5 * align_up(M * 4) + align_up((N + 2) * 16) + align_up(sort_temp<unsigned>(E, 32)) + 1024;
-}
-
-extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
-                          int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_resync: needs n > 0 and E > 0");
-    AIG_REQUIRE(edge_index && inv_cnt && depth && ws, "aig_resync: null pointer");
-    if (ws_bytes < aig_resync_ws_bytes(n, E)) return fail(AIG_EWORKSPACE, "aig_resync: workspace too small");
+int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth,
+           void* ws, size_t ws_bytes, void* stream, const char* who) {
+    AIG_REQUIRE(edge_index && inv_cnt && depth && ws, "%s: null pointer", who);
+    if (ws_bytes < resync_ws(gs.B, gs.n, gs.ecap)) return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int N = (int)n, M = (int)E;
+    const int N = gs.N(), M = gs.M();
     Carver c(ws);
     int* icnt = c.take<int>(N + 2);
     int* indeg = c.take<int>(N + 2);
@@ -945,21 +1021,156 @@ extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const
     int* sid = c.take<int>(M);
     int* adj = c.take<int>(M);
     int4* rec = c.take<int4>(N + 2);
-    size_t tb = sort_temp<unsigned>(E, 32);
+    int* cyclic = c.take<int>(gs.B + 16);
+    size_t tb = sort_temp<unsigned>(M, 32);
     void* temp = c.take<char>(tb);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     AIG_HIP_CHECK(fill_words(icnt, 0u, (size_t)(N + 2) * 4, s));
     AIG_HIP_CHECK(fill_words(indeg, 0u, (size_t)(N + 2) * 4, s));
-    hipLaunchKernelGGL(k_rs_edges, dim3(g256(M)), dim3(256), 0, s, N, M, ei, reinterpret_cast<const long long*>(edge_attr),
+    AIG_HIP_CHECK(fill_words(cyclic, 0u, (size_t)(gs.B + 16) * 4, s));
+    hipLaunchKernelGGL(k_rs_edges, dim3(g256(M)), dim3(256), 0, s, gs, ei, reinterpret_cast<const long long*>(edge_attr),
                        icnt, indeg, key, ids);
     AIG_LAUNCH_CHECK();
-    int rc = run_csr(s, N, M, 32, key, skey, ids, sid, ei + E, sptr, adj, temp, tb);
+    int rc = run_csr(s, gs, 32, key, skey, ids, sid, ei, 1, sptr, adj, temp, tb);
     if (rc) return rc;
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, popped};
     if ((rc = run_traverse<1>(s, N, jobs, 1, rec, nullptr))) return rc;
-    hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, N, popped, d32, icnt,
+    hipLaunchKernelGGL(k_rs_cyclic, dim3(g256(N)), dim3(256), 0, s, gs, d32, cyclic);
+    hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, gs, cyclic, d32, icnt,
                        reinterpret_cast<long long*>(depth), reinterpret_cast<long long*>(inv_cnt));
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+// edge slots of B graphs -> the padded minibatch the critic takes (data_process.py pad_data, then the
+// concatenation with node offsets): graph g owns columns [g max_edges, (g+1) max_edges), its first
+// min(count, max_edges) edges with union ids, the rest -1 shifted like every other entry
+__global__ void k_pad_batch(GraphSet gs, const long long* __restrict__ ei, const long long* __restrict__ ea,
+                            int max_edges, long long* __restrict__ out_ei, long long* __restrict__ out_ea) {
+    const long long cols = (long long)gs.B * max_edges;
+    for (long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x; c < cols; c += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(c / max_edges), j = (int)(c - (long long)g * max_edges);
+        const int have = gs.ecount ? min(gs.ecount[g], gs.ecap) : gs.ecap;
+        long long u = -1, v = -1, a = 0;
+        if (j < have) {
+            const size_t row = (size_t)(2 * g) * gs.ecap + j;
+            u = ei[row];
+            v = ei[row + gs.ecap];
+            a = ea ? ea[(size_t)g * gs.ecap + j] : 0;
+        }
+        const long long shift = (long long)g * gs.n;
+        out_ei[c] = u + shift;
+        out_ei[cols + c] = v + shift;
+        out_ea[c] = a;
+    }
+}
+
+}  // namespace
+}  // namespace aig
+
+using namespace aig;
+
+// ============================================================================================ enforce
+extern "C" size_t aig_enforce_ws_bytes(int64_t n, int64_t E) { return enforce_ws(1, n, E); }
+
+extern "C" int aig_enforce(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
+                           int depth_kind, const void* depth, int64_t* out_edge_index, int64_t cap,
+                           int64_t* out_edge_attr, int32_t* out_count, int64_t* node_depth, float* x_out, void* ws,
+                           size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_enforce: needs n > 0 and E > 0 (got %lld, %lld)",
+                (long long)n, (long long)E);
+    const GraphSet gs{1, (int)n, (int)E, nullptr};
+    return enforce(gs, x, edge_index, edge_attr, depth_kind, depth, 0, out_edge_index, cap, out_edge_attr, out_count,
+                   node_depth, x_out, ws, ws_bytes, stream, "aig_enforce");
+}
+
+extern "C" size_t aig_enforce_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap) { return enforce_ws(B, n, ecap); }
+
+extern "C" int aig_enforce_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                                 const int64_t* edge_index, const int64_t* edge_attr, int depth_kind, const void* depth,
+                                 int64_t depth_stride, int64_t* out_edge_index, int64_t cap, int64_t* out_edge_attr,
+                                 int32_t* out_count, int64_t* node_depth, float* x_out, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    int rc = check_set("aig_enforce_batch", B, n, ecap);
+    if (rc) return rc;
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    return enforce(gs, x, edge_index, edge_attr, depth_kind, depth, depth_stride, out_edge_index, cap, out_edge_attr,
+                   out_count, node_depth, x_out, ws, ws_bytes, stream, "aig_enforce_batch");
+}
+
+// ============================================================================================ penalties / validate
+extern "C" size_t aig_penalties_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws(1, n, E); }
+
+extern "C" int aig_penalties(int64_t n, int64_t E, const float* x, const int64_t* edge_index, float* out9, void* ws,
+                             size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(out9, "aig_penalties: null output");
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_penalties: needs n > 0 and E > 0 (got %lld, %lld)",
+                (long long)n, (long long)E);
+    const GraphSet gs{1, (int)n, (int)E, nullptr};
+    return graph_checks(gs, x, edge_index, out9, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                        stream, "aig_penalties");
+}
+
+extern "C" size_t aig_penalties_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap) { return graph_checks_ws(B, n, ecap); }
+
+extern "C" int aig_penalties_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                                   const int64_t* edge_index, float* out9, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(out9, "aig_penalties_batch: null output");
+    int rc = check_set("aig_penalties_batch", B, n, ecap);
+    if (rc) return rc;
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    return graph_checks(gs, x, edge_index, out9, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                        stream, "aig_penalties_batch");
+}
+
+extern "C" size_t aig_validate_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws(1, n, E); }
+
+extern "C" int aig_validate(int64_t n, int64_t E, const float* x, const int64_t* edge_index, uint8_t* eflag,
+                            uint8_t* ncode, int32_t* indeg, int32_t* pred2, uint8_t* on_path, int32_t* summary,
+                            void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(eflag && ncode && indeg && pred2 && on_path && summary, "aig_validate: null output");
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_validate: needs n > 0 and E > 0 (got %lld, %lld)",
+                (long long)n, (long long)E);
+    const GraphSet gs{1, (int)n, (int)E, nullptr};
+    return graph_checks(gs, x, edge_index, nullptr, eflag, ncode, indeg, pred2, on_path, summary, ws, ws_bytes, stream,
+                        "aig_validate");
+}
+
+// ============================================================================================ resync
+extern "C" size_t aig_resync_ws_bytes(int64_t n, int64_t E) { return resync_ws(1, n, E); }
+
+extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
+                          int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_resync: needs n > 0 and E > 0");
+    const GraphSet gs{1, (int)n, (int)E, nullptr};
+    return resync(gs, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync");
+}
+
+extern "C" size_t aig_resync_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap) { return resync_ws(B, n, ecap); }
+
+extern "C" int aig_resync_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,
+                                const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes,
+                                void* stream) {
+    int rc = check_set("aig_resync_batch", B, n, ecap);
+    if (rc) return rc;
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    return resync(gs, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync_batch");
+}
+
+// ============================================================================================ padded minibatch
+extern "C" int aig_pad_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,
+                             const int64_t* edge_attr, int64_t max_edges, int64_t* out_edge_index,
+                             int64_t* out_edge_attr, void* stream) {
+    int rc = check_set("aig_pad_batch", B, n, ecap);
+    if (rc) return rc;
+    AIG_REQUIRE(max_edges > 0 && B * max_edges < INT_MAX, "aig_pad_batch: bad max_edges %lld", (long long)max_edges);
+    AIG_REQUIRE(edge_index && out_edge_index && out_edge_attr, "aig_pad_batch: null pointer");
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    hipLaunchKernelGGL(k_pad_batch, dim3(g256(B * max_edges)), dim3(256), 0, static_cast<hipStream_t>(stream), gs,
+                       reinterpret_cast<const long long*>(edge_index), reinterpret_cast<const long long*>(edge_attr),
+                       (int)max_edges, reinterpret_cast<long long*>(out_edge_index),
+                       reinterpret_cast<long long*>(out_edge_attr));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

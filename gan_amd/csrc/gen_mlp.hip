@@ -320,6 +320,8 @@ struct Mlp3 {
     const float* b[3];     // [128]
     int ldw[3];
     float* out;            // [M][128]
+    // several graphs of M rows (blockIdx.y): floats from one graph to the next in x, out and the z-dependent b[1]
+    long long gx, gout, gzb;
 #ifdef MLP3_TIMING
     long long* dbg;
 #endif
@@ -329,6 +331,10 @@ constexpr size_t MLP3_LDS = (3 * TILE_F + 2 * BM) * sizeof(float);
 
 __global__ __launch_bounds__(THREADS) void k_node_mlp3(int M, int rpb, Mlp3 p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // tiles t0, t1, staging tile, x of the next tile
+    {
+        const long long g = blockIdx.y;
+        p.x += g * p.gx; p.out += g * p.gout; p.b[1] += g * p.gzb;
+    }
     float* const stage = lds + 2 * TILE_F;
     float2* const xs = reinterpret_cast<float2*>(lds + 3 * TILE_F);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,12 +432,20 @@ struct Proj4 {
     const float* b[4];   // [128] (never null: a zero vector where the layer has no bias)
     int ldw[4];
     float* out[4];       // [M][128] each
+    // several graphs of M rows (blockIdx.y): floats from one graph to the next in x, every out and every b
+    long long gx, gout, gzb;
 };
 
 constexpr size_t PROJ4_LDS = 4 * TILE_F * sizeof(float);
 
 __global__ __launch_bounds__(THREADS) void k_node_proj4(int M, int rpb, Proj4 p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // input tiles x0, x1, staging tiles s0, s1
+    {
+        const long long g = blockIdx.y;
+        p.x += g * p.gx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p.out[i] += g * p.gout; p.b[i] += g * p.gzb; }
+    }
     float* const s0 = lds + 2 * TILE_F;
     float* const s1 = lds + 3 * TILE_F;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -522,7 +536,8 @@ struct PipeBf16 {
     int zdep[PIPE_LAYERS];           // 1: the vector depends on z - sample s uses b + s * zstride
     int zstride;
     int rows_per_sample;   // 0: one sample; else tile t belongs to sample t*64 / rows_per_sample and reads x row (row % rows_per_sample)
-    int x_rows;            // rows of x (a sample's rows past them repeat the last one)
+    int x_rows;            // rows of x per sample (a sample's rows past them repeat the last one)
+    int x_sample_rows;     // rows of x from one sample to the next (0: all samples read the same x)
     float* h_cond;         // [M][128] or null
     float* out[4];         // [M][128] each
 };
@@ -626,7 +641,8 @@ __global__ __launch_bounds__(THREADS) void k_node_pipe_bf16(int M, PipeBf16 p) {
 #pragma unroll
         for (int q = 0; q < BM / 8; ++q) {
             const int row = q * 8 + (tid >> 5);
-            const float2 xv = *reinterpret_cast<const float2*>(p.x + static_cast<size_t>(min(xrow0 + row, xlimit - 1)) * 2);
+            const float2 xv = *reinterpret_cast<const float2*>(
+                p.x + (static_cast<size_t>(sample) * p.x_sample_rows + min(xrow0 + row, xlimit - 1)) * 2);
             bf16x4 o;
 #pragma unroll
             for (int u = 0; u < 4; ++u) o[u] = (__bf16)fmaxf(fmaf(xv.y, e1[u], xv.x * e0[u]) + eb[u], 0.f);
@@ -672,36 +688,47 @@ int launch_linear(hipStream_t s, int M, const float* X, const Chunk& ck) {
 
 using namespace aig;
 
-extern "C" size_t aig_gen_node_proj_ws_bytes(int64_t n) {
-    if (n <= 0) return 256;
-    return align_up(static_cast<size_t>(n) * H * 4) + align_up(4 * H * 4) + 256;
-}
+namespace aig {
+namespace {
 
-extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_weights* w,
-                                 float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(n >= 0 && n < INT32_MAX, "aig_gen_node_proj: n=%lld out of range", (long long)n);
-    if (n == 0) return AIG_OK;
-    AIG_REQUIRE(x && z && w && proj && ws, "aig_gen_node_proj: null pointer");
+int check_gen_weights(const char* who, const float* x, const float* z, const aig_gen_weights* w, const float* h_cond,
+                      const float* proj, const void* ws) {
+    AIG_REQUIRE(x && z && w && proj && ws, "%s: null pointer", who);
     AIG_REQUIRE(w->enc0_w && w->enc0_b && w->enc2_w && w->enc2_b && w->proj0_w && w->proj0_b && w->proj2_w &&
                     w->proj2_b && w->sc0_w && w->sc0_b && w->at0_w && w->at0_b,
-                "aig_gen_node_proj: null weight pointer");
+                "%s: null weight pointer", who);
     // the kernels read weights, biases and rows in 16-byte pieces (x in 8-byte pieces)
     auto aligned = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
     AIG_REQUIRE(aligned(x, 8) && aligned(proj, 16) && aligned(h_cond, 16) && aligned(ws, 16) && aligned(w->enc2_w, 16) &&
                     aligned(w->enc2_b, 16) && aligned(w->proj0_w, 16) && aligned(w->proj2_w, 16) &&
                     aligned(w->proj2_b, 16) && aligned(w->sc0_w, 16) && aligned(w->at0_w, 16),
-                "aig_gen_node_proj: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned");
-    if (ws_bytes < aig_gen_node_proj_ws_bytes(n))
-        return fail(AIG_EWORKSPACE, "aig_gen_node_proj: workspace %zu < %zu", ws_bytes, aig_gen_node_proj_ws_bytes(n));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Carver c(ws);
-    float* bufA = c.take<float>(static_cast<size_t>(n) * H);  // h_cond when the caller does not want it
-    float* zb = c.take<float>(4 * H);  // [0] node_proj.0, [1] edge_scorer.0, [2] edge_attr_pred.0, [3] zeros
-    const int M = static_cast<int>(n);
+                "%s: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned", who);
+    return AIG_OK;
+}
 
-    hipLaunchKernelGGL(k_zbias, dim3(4), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w, w->sc0_b, 3 * H,
-                       2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb);
+void launch_zbias(hipStream_t s, int samples, const float* z, const aig_gen_weights* w, float* zb) {
+    // per sample: [0] node_proj.0, [1] edge_scorer.0, [2] edge_attr_pred.0, [3] zeros
+    hipLaunchKernelGGL(k_zbias, dim3(4, (unsigned)samples), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w,
+                       w->sc0_b, 3 * H, 2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb);
+}
+
+size_t proj_f32_ws(int64_t B, int64_t n) {
+    if (n <= 0) return 256;
+    return align_up(static_cast<size_t>(B) * n * H * 4) + align_up(static_cast<size_t>(B) * 4 * H * 4) + 256;
+}
+
+// B graphs of n rows: x advances by x_stride floats per graph (0: shared), the output planes hold `rows` rows per graph
+int node_proj_f32(hipStream_t s, int B, int n, const float* x, long long x_stride, const float* z,
+                  const aig_gen_weights* w, float* h_cond, float* proj, int64_t rows, void* ws) {
+    Carver c(ws);
+    float* bufA = c.take<float>(static_cast<size_t>(B) * n * H);  // h_cond when the caller does not want it
+    float* zb = c.take<float>(static_cast<size_t>(B) * 4 * H);
+    const int M = n;
+    launch_zbias(s, B, z, w, zb);
     AIG_LAUNCH_CHECK();
+    const int per_graph = 256 / B > 0 ? 256 / B : 1;   // workgroups per graph: about one per CU for the set
+    const int rpb = rows_per_block(M, per_graph);
+    const dim3 grid((M + rpb - 1) / rpb, B);
 
     // node_enc (Linear(2,128)+ReLU while staging, Linear(128,128)+ReLU) and node_proj (on cat[h, z]: the z
     // block of node_proj.0 is the bias vector zb[0]) in one pass over the rows
@@ -716,15 +743,15 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
         p.w[1] = w->proj0_w; p.b[1] = zb;         p.ldw[1] = 2 * H;
         p.w[2] = w->proj2_w; p.b[2] = w->proj2_b; p.ldw[2] = H;
         p.out = hc;
+        p.gx = x_stride; p.gout = static_cast<long long>(n) * H; p.gzb = 4 * H;
 #ifdef MLP3_TIMING
         p.dbg = reinterpret_cast<long long*>(bufA);  // timing builds are run with h_cond given
 #endif
-        const int rpb = rows_per_block(M, 256);
-        hipLaunchKernelGGL(k_node_mlp3, dim3((M + rpb - 1) / rpb), dim3(THREADS), MLP3_LDS, s, M, rpb, p);
+        hipLaunchKernelGGL(k_node_mlp3, grid, dim3(THREADS), MLP3_LDS, s, M, rpb, p);
         AIG_LAUNCH_CHECK();
     }
     // first Linear of both edge MLPs, split into source block / target block (+ z block and bias)
-    const size_t plane = static_cast<size_t>(n) * H;
+    const size_t plane = static_cast<size_t>(B) * rows * H;
     {
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_node_proj4), (size_t)(PROJ4_LDS)));
         Proj4 q{};
@@ -734,47 +761,31 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
         q.w[2] = w->at0_w;     q.b[2] = zb + 3 * H; q.out[2] = proj + 2 * plane;
         q.w[3] = w->at0_w + H; q.b[3] = zb + 2 * H; q.out[3] = proj + 3 * plane;
         for (int i = 0; i < 4; ++i) q.ldw[i] = 3 * H;
-        const int rpb = rows_per_block(M, 256);
-        hipLaunchKernelGGL(k_node_proj4, dim3((M + rpb - 1) / rpb), dim3(THREADS), PROJ4_LDS, s, M, rpb, q);
+        q.gx = static_cast<long long>(n) * H; q.gout = rows * H; q.gzb = 4 * H;
+        hipLaunchKernelGGL(k_node_proj4, grid, dim3(THREADS), PROJ4_LDS, s, M, rpb, q);
         AIG_LAUNCH_CHECK();
     }
     return AIG_OK;
 }
 
-extern "C" size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples) {
+size_t proj_bf16_ws(int64_t samples) {
     const size_t S = static_cast<size_t>(samples > 0 ? samples : 1);
     return align_up(static_cast<size_t>(PIPE_LAYERS) * H * H * sizeof(__bf16)) + align_up(S * 4 * H * 4) + 256;
 }
 
-extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w,
-                                      float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(n >= 0 && samples >= 1 && n * samples < INT32_MAX, "aig_gen_node_proj_bf16: n=%lld samples=%lld out of range",
-                (long long)n, (long long)samples);
-    if (n == 0) return AIG_OK;
-    AIG_REQUIRE(x && z && w && proj && ws, "aig_gen_node_proj_bf16: null pointer");
-    AIG_REQUIRE(w->enc0_w && w->enc0_b && w->enc2_w && w->enc2_b && w->proj0_w && w->proj0_b && w->proj2_w &&
-                    w->proj2_b && w->sc0_w && w->sc0_b && w->at0_w && w->at0_b,
-                "aig_gen_node_proj_bf16: null weight pointer");
-    auto aligned = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-    AIG_REQUIRE(aligned(x, 8) && aligned(proj, 16) && aligned(h_cond, 16) && aligned(ws, 16) && aligned(w->enc2_w, 16) &&
-                    aligned(w->enc2_b, 16) && aligned(w->proj0_w, 16) && aligned(w->proj2_w, 16) &&
-                    aligned(w->proj2_b, 16) && aligned(w->sc0_w, 16) && aligned(w->at0_w, 16),
-                "aig_gen_node_proj_bf16: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned");
-    if (ws_bytes < aig_gen_node_proj_bf16_ws_bytes(samples))
-        return fail(AIG_EWORKSPACE, "aig_gen_node_proj_bf16: workspace %zu < %zu", ws_bytes,
-                    aig_gen_node_proj_bf16_ws_bytes(samples));
-    hipStream_t s = static_cast<hipStream_t>(stream);
+// `samples` graphs of n rows; every graph starts on a tile boundary of the output planes (a tile of rows belongs
+// to one graph), the rows between a graph's last node and the next boundary repeat its last row.  x advances by
+// x_sample_rows rows per graph (0: one template, the graphs differ in z alone).
+int node_proj_bf16(hipStream_t s, int n, int samples, const float* x, int x_sample_rows, const float* z,
+                   const aig_gen_weights* w, float* h_cond, float* proj, void* ws, const char* who, bool tiled = false) {
     Carver c(ws);
     __bf16* wpack = c.take<__bf16>(static_cast<size_t>(PIPE_LAYERS) * H * H);
-    float* zb = c.take<float>(static_cast<size_t>(samples) * 4 * H);  // per sample: node_proj.0, edge_scorer.0, edge_attr_pred.0, zeros
-    // several samples: each starts on a tile boundary (a tile of rows belongs to one sample), the rows between a
-    // sample's last node and the next boundary repeat its last row
-    const int64_t stride = samples > 1 ? (n + BM - 1) / BM * BM : n;
-    AIG_REQUIRE(stride * samples < INT32_MAX, "aig_gen_node_proj_bf16: %lld rows", (long long)(stride * samples));
+    float* zb = c.take<float>(static_cast<size_t>(samples) * 4 * H);
+    const int64_t stride = (samples > 1 || tiled) ? (static_cast<int64_t>(n) + BM - 1) / BM * BM : n;
+    AIG_REQUIRE(stride * samples < INT32_MAX, "%s: %lld rows", who, (long long)(stride * samples));
     const int M = static_cast<int>(stride * samples);
-    AIG_REQUIRE(samples <= 65535, "aig_gen_node_proj_bf16: at most 65535 samples per call");
-    hipLaunchKernelGGL(k_zbias, dim3(4, (unsigned)samples), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w,
-                       w->sc0_b, 3 * H, 2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb);
+    AIG_REQUIRE(samples <= 65535, "%s: at most 65535 graphs per call", who);
+    launch_zbias(s, samples, z, w, zb);
     AIG_LAUNCH_CHECK();
     PackSrc src{};
     src.w[0] = w->enc2_w;      src.ldw[0] = H;
@@ -799,13 +810,72 @@ extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x
     p.b[6] = zb + 2 * H; p.zdep[6] = 1;
     p.zstride = 4 * H;
     p.rows_per_sample = samples > 1 ? static_cast<int>(stride) : 0;
-    p.x_rows = static_cast<int>(n);
+    p.x_rows = n;
+    p.x_sample_rows = x_sample_rows;
     p.h_cond = h_cond;
     for (int o = 0; o < 4; ++o) p.out[o] = proj + o * plane;
     const int ntiles = (M + BM - 1) / BM;
     hipLaunchKernelGGL(k_node_pipe_bf16, dim3(ntiles < 256 ? ntiles : 256), dim3(THREADS), PIPE_LDS, s, M, p);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+
+}  // namespace
+}  // namespace aig
+
+extern "C" size_t aig_gen_node_proj_ws_bytes(int64_t n) { return proj_f32_ws(1, n); }
+
+extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_weights* w,
+                                 float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT32_MAX, "aig_gen_node_proj: n=%lld out of range", (long long)n);
+    if (n == 0) return AIG_OK;
+    int rc = check_gen_weights("aig_gen_node_proj", x, z, w, h_cond, proj, ws);
+    if (rc) return rc;
+    if (ws_bytes < aig_gen_node_proj_ws_bytes(n))
+        return fail(AIG_EWORKSPACE, "aig_gen_node_proj: workspace %zu < %zu", ws_bytes, aig_gen_node_proj_ws_bytes(n));
+    return node_proj_f32(static_cast<hipStream_t>(stream), 1, static_cast<int>(n), x, 0, z, w, h_cond, proj, n, ws);
+}
+
+extern "C" size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples) { return proj_bf16_ws(samples); }
+
+extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w,
+                                      float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && samples >= 1 && n * samples < INT32_MAX, "aig_gen_node_proj_bf16: n=%lld samples=%lld out of range",
+                (long long)n, (long long)samples);
+    if (n == 0) return AIG_OK;
+    int rc = check_gen_weights("aig_gen_node_proj_bf16", x, z, w, h_cond, proj, ws);
+    if (rc) return rc;
+    if (ws_bytes < aig_gen_node_proj_bf16_ws_bytes(samples))
+        return fail(AIG_EWORKSPACE, "aig_gen_node_proj_bf16: workspace %zu < %zu", ws_bytes,
+                    aig_gen_node_proj_bf16_ws_bytes(samples));
+    return node_proj_bf16(static_cast<hipStream_t>(stream), static_cast<int>(n), static_cast<int>(samples), x, 0, z, w,
+                          h_cond, proj, ws, "aig_gen_node_proj_bf16");
+}
+
+extern "C" int64_t aig_gen_batch_rows(int64_t n) { return (n + BM - 1) / BM * BM; }
+
+extern "C" size_t aig_gen_node_proj_batch_ws_bytes(int64_t B, int64_t n, int bf16) {
+    return bf16 ? proj_bf16_ws(B) : proj_f32_ws(B, n);
+}
+
+extern "C" int aig_gen_node_proj_batch(int64_t B, int64_t n, const float* x, int x_shared, const float* z,
+                                       const aig_gen_weights* w, int bf16, float* proj, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    AIG_REQUIRE(B >= 1 && B <= 65535 && n >= 1 && B * aig_gen_batch_rows(n) < INT32_MAX,
+                "aig_gen_node_proj_batch: B=%lld n=%lld out of range", (long long)B, (long long)n);
+    int rc = check_gen_weights("aig_gen_node_proj_batch", x, z, w, nullptr, proj, ws);
+    if (rc) return rc;
+    if (ws_bytes < aig_gen_node_proj_batch_ws_bytes(B, n, bf16))
+        return fail(AIG_EWORKSPACE, "aig_gen_node_proj_batch: workspace %zu < %zu", ws_bytes,
+                    aig_gen_node_proj_batch_ws_bytes(B, n, bf16));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (bf16) {
+        // (a set of one graph still lays its rows out on the tile grid: the planes hold aig_gen_batch_rows(n) rows)
+        return node_proj_bf16(s, static_cast<int>(n), static_cast<int>(B), x, x_shared ? 0 : static_cast<int>(n), z, w,
+                              nullptr, proj, ws, "aig_gen_node_proj_batch", true);
+    }
+    return node_proj_f32(s, static_cast<int>(B), static_cast<int>(n), x, x_shared ? 0 : 2 * n, z, w, nullptr, proj,
+                         aig_gen_batch_rows(n), ws);
 }
 
 extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,

@@ -8,6 +8,17 @@ namespace {
 
 constexpr int H = AIG_HIDDEN;
 
+// Several graphs of n nodes in one launch: blockIdx.y is the graph, and every per-graph array advances by its
+// stride (in elements) from one graph to the next - 0 for an array all graphs share (the plan and the node
+// features when the graphs are samples of one template).  A single graph is a grid of height 1.
+struct GenSet {
+    long long node;     // order, rank, want, cnt, fb
+    long long eoff;     // eoff (n + 1 entries per graph)
+    long long cand;     // cand (n K entries per graph)
+    long long x;        // x (2 n floats per graph)
+    long long proj;     // rows of the projection planes per graph
+};
+
 // ------------------------------------------------------------------------------------------ scores
 // One wave per slot; lane i scores candidate i (and i+64, ... for wider windows):
 //   logit = b2 + sum_j w2[j] * relu(A[cand][j] + B[target][j]),   j ascending.
@@ -17,10 +28,15 @@ __global__ __launch_bounds__(256) void k_score(int n, int K, const int* __restri
                                                const int* __restrict__ cnt, const int* __restrict__ cand,
                                                const float* __restrict__ A, const float* __restrict__ B,
                                                const float* __restrict__ w2, const float* __restrict__ b2,
-                                               float* __restrict__ logits) {
+                                               float* __restrict__ logits, GenSet gs) {
     const int lane = threadIdx.x & 63;
     int r = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (r >= n) return;
+    {
+        const long long g = blockIdx.y;
+        order += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
+        A += g * gs.proj * H; B += g * gs.proj * H; logits += g * (long long)n * K;
+    }
     const int c = cnt[r];
     if (c <= 0) return;
     const int v = __builtin_amdgcn_readfirstlane(order[r]);
@@ -178,8 +194,13 @@ constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets
 
 __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
                                                              const int* __restrict__ cnt,
-                                                             const int* __restrict__ want, int* __restrict__ sel) {
+                                                             const int* __restrict__ want, int* __restrict__ sel,
+                                                             GenSet gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const long long g = blockIdx.y;
+        logits += g * (long long)rows * ld; cnt += g * gs.node; want += g * gs.node; sel += g * 2ll * rows;
+    }
     float* val = reinterpret_cast<float*>(smem);                                     // [cap][SEL_THREADS+1]
     unsigned char* idx = smem + (size_t)cap * (SEL_THREADS + 1) * sizeof(float);     // [cap][SEL_THREADS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,14 +303,24 @@ __device__ __forceinline__ int inv_bit(const float* __restrict__ A2, const float
     return (acc + bias) > 0.f ? 1 : 0;  // sigmoid(l) > 0.5
 }
 
+// E: slots between the source row and the target row of a graph's edge list (its edge count for a single
+// graph, the slot capacity for a set, where graph g's lists start 2 E g slots in and ecount[g] gets its count)
 __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, const int* __restrict__ order,
                        const int* __restrict__ want, const int* __restrict__ cnt, const int* __restrict__ cand,
                        const int* __restrict__ fb, const int* __restrict__ eoff, const int* __restrict__ sel,
                        const float* __restrict__ A2, const float* __restrict__ B2, const float* __restrict__ w2a,
                        const float* __restrict__ b2a, long long* __restrict__ edge_index,
-                       long long* __restrict__ edge_attr, float* __restrict__ x_out) {
+                       long long* __restrict__ edge_attr, float* __restrict__ x_out, GenSet gs,
+                       int* __restrict__ ecount) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    {
+        const long long g = blockIdx.y;
+        x += g * gs.x; order += g * gs.node; want += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
+        fb += g * gs.node; eoff += g * gs.eoff; sel += g * 2ll * n; A2 += g * gs.proj * H; B2 += g * gs.proj * H;
+        edge_index += g * 2 * E; edge_attr += g * E; x_out += g * 2ll * n;
+        if (ecount && r == 0) ecount[g] = eoff[n];
+    }
     const int v = order[r];
     const int off = eoff[r], ne = eoff[r + 1] - off;
     int invs = 0;
@@ -339,8 +370,14 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, con
                                                      const int* __restrict__ rank, const int* __restrict__ cnt,
                                                      const int* __restrict__ cand, const float* __restrict__ A,
                                                      const float* __restrict__ B, const float* __restrict__ w2,
-                                                     const float* __restrict__ b2, float* __restrict__ logits) {
+                                                     const float* __restrict__ b2, float* __restrict__ logits,
+                                                     GenSet gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const long long g = blockIdx.y;
+        order += g * gs.node; rank += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
+        A += g * gs.proj * H; B += g * gs.proj * H; logits += g * (long long)n * K;
+    }
     float* tile = reinterpret_cast<float*>(smem);                     // [K + T][SCORE_LD]
     int* ids = reinterpret_cast<int*>(tile + (size_t)(K + T) * SCORE_LD);   // [K] ascending ids of slot r0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,6 +446,42 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, con
     }
 }
 
+int launch_score(hipStream_t s, int B, int n, int K, const int* order, const int* rank, const int* cnt, const int* cand,
+                 const float* projA, const float* projB, const float* w2, const float* b2, float* logits,
+                 const GenSet& gs) {
+    if (K <= SCORE_K_TILED) {
+        const int T = K <= 128 ? SCORE_T : SCORE_T_WIDE;
+        const size_t lds = (size_t)(K + T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
+        const unsigned tb = (unsigned)((n + T - 1) / T);
+        if (K <= 128) {
+            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T>), lds));
+            hipLaunchKernelGGL(k_score_tiled<SCORE_T>, dim3(tb, B), dim3(SCORE_THREADS), lds, s, n, K, order, rank, cnt,
+                               cand, projA, projB, w2, b2, logits, gs);
+        } else {
+            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T_WIDE>), lds));
+            hipLaunchKernelGGL(k_score_tiled<SCORE_T_WIDE>, dim3(tb, B), dim3(SCORE_THREADS), lds, s, n, K, order, rank,
+                               cnt, cand, projA, projB, w2, b2, logits, gs);
+        }
+        AIG_LAUNCH_CHECK();
+        return AIG_OK;
+    }
+    const unsigned blocks = (unsigned)(((int64_t)n * 64 + 255) / 256);
+    hipLaunchKernelGGL(k_score, dim3(blocks, B), dim3(256), 0, s, n, K, order, cnt, cand, projA, projB, w2, b2, logits, gs);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, const int* cnt, const int* want, int* sel,
+                  const GenSet& gs) {
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select), (size_t)(SEL_LDS)));
+    const unsigned blocks = (unsigned)((rows + SEL_THREADS - 1) / SEL_THREADS);
+    const int cap = ld < SEL_CAP ? ld : SEL_CAP;
+    hipLaunchKernelGGL(k_topk_select, dim3(blocks, B), dim3(SEL_THREADS), sel_lds(cap), s, rows, ld, cap, logits, cnt,
+                       want, sel, gs);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
 }  // namespace
 }  // namespace aig
 
@@ -420,28 +493,8 @@ extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const i
     AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1, "aig_gen_score: bad sizes n=%lld K=%lld", (long long)n, (long long)K);
     if (n == 0) return AIG_OK;
     AIG_REQUIRE(order && rank && cnt && cand && projA && projB && w2 && b2 && logits, "aig_gen_score: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (K <= SCORE_K_TILED) {
-        const int T = K <= 128 ? SCORE_T : SCORE_T_WIDE;
-        const size_t lds = (size_t)(K + T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
-        const int64_t tb = (n + T - 1) / T;
-        if (K <= 128) {
-            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T>), lds));
-            hipLaunchKernelGGL(k_score_tiled<SCORE_T>, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K, order,
-                               rank, cnt, cand, projA, projB, w2, b2, logits);
-        } else {
-            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T_WIDE>), lds));
-            hipLaunchKernelGGL(k_score_tiled<SCORE_T_WIDE>, dim3((unsigned)tb), dim3(SCORE_THREADS), lds, s, (int)n, (int)K,
-                               order, rank, cnt, cand, projA, projB, w2, b2, logits);
-        }
-        AIG_LAUNCH_CHECK();
-        return AIG_OK;
-    }
-    int64_t blocks = (n * 64 + 255) / 256;
-    hipLaunchKernelGGL(k_score, dim3((unsigned)blocks), dim3(256), 0, s, (int)n, (int)K, order, cnt, cand, projA, projB,
-                       w2, b2, logits);
-    AIG_LAUNCH_CHECK();
-    return AIG_OK;
+    return launch_score(static_cast<hipStream_t>(stream), 1, (int)n, (int)K, order, rank, cnt, cand, projA, projB, w2, b2,
+                        logits, GenSet{});
 }
 
 extern "C" size_t aig_topk_select_ws_bytes(int64_t, int64_t) { return 256; }
@@ -452,14 +505,7 @@ extern "C" int aig_topk_select(int64_t rows, int64_t ld, const float* logits, co
                 (long long)rows, (long long)ld);
     if (rows == 0) return AIG_OK;
     AIG_REQUIRE(logits && cnt && want && sel, "aig_topk_select: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select), (size_t)(SEL_LDS)));
-    int64_t blocks = (rows + SEL_THREADS - 1) / SEL_THREADS;
-    const int cap = ld < SEL_CAP ? (int)ld : SEL_CAP;
-    hipLaunchKernelGGL(k_topk_select, dim3((unsigned)blocks), dim3(SEL_THREADS), sel_lds(cap), s, (int)rows, (int)ld, cap,
-                       logits, cnt, want, sel);
-    AIG_LAUNCH_CHECK();
-    return AIG_OK;
+    return launch_select(static_cast<hipStream_t>(stream), 1, (int)rows, (int)ld, logits, cnt, want, sel, GenSet{});
 }
 
 extern "C" int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order,
@@ -475,7 +521,38 @@ extern "C" int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, con
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int)n, (int)K, (long long)E, x,
                        order, want, cnt, cand, fb, eoff, sel, projA2, projB2, w2a, b2a,
-                       reinterpret_cast<long long*>(edge_index), reinterpret_cast<long long*>(edge_attr), x_out);
+                       reinterpret_cast<long long*>(edge_index), reinterpret_cast<long long*>(edge_attr), x_out, GenSet{},
+                       nullptr);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
+    AIG_REQUIRE(a, "aig_gen_wire_batch: null argument block");
+    AIG_REQUIRE(a->B >= 1 && a->B <= 65535 && a->n >= 1 && a->K >= 1 && a->ecap >= 1 && a->proj_rows >= a->n,
+                "aig_gen_wire_batch: bad sizes B=%lld n=%lld K=%lld ecap=%lld rows=%lld", (long long)a->B, (long long)a->n,
+                (long long)a->K, (long long)a->ecap, (long long)a->proj_rows);
+    AIG_REQUIRE(a->B * a->proj_rows < INT_MAX && a->B * a->ecap < INT_MAX && a->n * a->K < INT_MAX,
+                "aig_gen_wire_batch: set too large for 32-bit indices");
+    AIG_REQUIRE(a->x && a->order && a->rank && a->want && a->cnt && a->fb && a->eoff && a->cand && a->proj && a->sc2_w &&
+                    a->sc2_b && a->at2_w && a->at2_b && a->logits && a->sel && a->edge_index && a->edge_attr &&
+                    a->ecount && a->x_out,
+                "aig_gen_wire_batch: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = (int)a->B, n = (int)a->n, K = (int)a->K;
+    GenSet gs{};
+    if (!a->plan_shared) { gs.node = n; gs.eoff = n + 1; gs.cand = (long long)n * K; }
+    gs.x = a->x_shared ? 0 : 2ll * n;
+    gs.proj = a->proj_rows;
+    const size_t plane = (size_t)a->B * a->proj_rows * H;
+    int rc = launch_score(s, B, n, K, a->order, a->rank, a->cnt, a->cand, a->proj, a->proj + plane, a->sc2_w, a->sc2_b,
+                          a->logits, gs);
+    if (rc) return rc;
+    if ((rc = launch_select(s, B, n, K, a->logits, a->cnt, a->want, a->sel, gs))) return rc;
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, n, K, (long long)a->ecap, a->x,
+                       a->order, a->want, a->cnt, a->cand, a->fb, a->eoff, a->sel, a->proj + 2 * plane,
+                       a->proj + 3 * plane, a->at2_w, a->at2_b, reinterpret_cast<long long*>(a->edge_index),
+                       reinterpret_cast<long long*>(a->edge_attr), a->x_out, gs, a->ecount);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -182,6 +182,98 @@ class AIGGenerator(nn.Module):
             outs.append(self._wire(plan, x_in, x_src, nd, proj[0, rows], proj[1, rows], proj[2, rows], proj[3, rows], n, K, E, dev))
         return outs
 
+    # ------------------------------------------------------------------ sets of graphs
+    def _stacked_plans(self, templates, dev):
+        """Plan arrays, node features and depths of several templates of one node count, back to back.  The
+        last few stacks are kept: the two generator passes of a training step use the same templates."""
+        xs, nds, plans = [], [], []
+        for t in templates:
+            x_src = t.x
+            x_in = x_src if (x_src.dtype == torch.float32 and x_src.is_contiguous()) else x_src.float().contiguous()
+            nd = getattr(t, "node_depth", None)
+            nd_dev = nd.to(dev) if nd is not None else None
+            plans.append(self.plan_for(t, x_in, nd_dev))
+            xs.append(x_in)
+            nds.append(nd_dev)
+        key = tuple(id(p) for p in plans)
+        cache = self.__dict__.setdefault("_plan_stacks", {})
+        hit = cache.get(key)
+        if hit is not None and all(a is b for a, b in zip(hit["plans"], plans)):
+            return hit
+        n = plans[0].n
+        if any(p.n != n for p in plans):
+            raise ValueError("forward_set needs templates of one node count")
+        st = {"plans": plans, "n": n, "E": [p.E for p in plans], "x": torch.cat(xs).contiguous()}
+        for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
+            st[name] = torch.stack([getattr(p, name) for p in plans]).contiguous()
+        st["nd"] = torch.cat(nds).contiguous() if all(v is not None and v.numel() == n for v in nds) else None
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        cache[key] = st
+        return st
+
+    @torch.no_grad()
+    def forward_set(self, templates, zs: torch.Tensor):
+        """``self(template, z)`` for a whole set of graphs in five launches: ``templates`` is ONE template (the
+        graphs are samples of it that differ in z alone - bulk sampling) or a list of B templates of equal node
+        count (the graphs of a padded minibatch), ``zs`` is ``[B, z_dim]``.  Returns a ``GraphSet`` whose graph
+        ``g`` holds exactly the tensors ``self(template_g, zs[g])`` returns."""
+        from .graphset import GraphSet
+        lib = _abi.lib()
+        shared = not isinstance(templates, (list, tuple))
+        first = templates if shared else templates[0]
+        dev = first.x.device
+        if dev.type != "cuda":
+            raise _abi.AigAbiError("AIGGenerator.forward_set needs the templates on a HIP device (no CPU path exists)")
+        zs = zs.to(dev).float().contiguous()
+        B = int(zs.size(0))
+        K = int(self.candidate_k)
+        if shared:
+            x_src = first.x
+            x_all = x_src if (x_src.dtype == torch.float32 and x_src.is_contiguous()) else x_src.float().contiguous()
+            nd = getattr(first, "node_depth", None)
+            nd_all = nd.to(dev) if nd is not None else None
+            plan = self.plan_for(first, x_all, nd_all)
+            n, Es = plan.n, [plan.E] * B
+            arrays = {name: getattr(plan, name) for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand")}
+            if nd_all is not None:
+                nd_all = nd_all.clone()
+        else:
+            if len(templates) != B:
+                raise ValueError("forward_set: one z per template")
+            st = self._stacked_plans(templates, dev)
+            n, Es, x_all, arrays = st["n"], st["E"], st["x"], st
+            nd_all = None if st["nd"] is None else st["nd"].clone()
+        bf16 = 1 if self.score_dtype == "bf16" else 0
+        stream = _abi.stream()
+        rows = int(lib.aig_gen_batch_rows(n))
+        proj = torch.empty((4, B * rows, 128), dtype=torch.float32, device=dev)
+        ws = _abi.workspace(lib.aig_gen_node_proj_batch_ws_bytes(B, n, bf16), dev)
+        w = self._weights()
+        _abi.check(_abi.timed("aig_gen_node_proj_batch", lib.aig_gen_node_proj_batch, B, n, _abi.ptr(x_all), int(shared),
+                              _abi.ptr(zs), C.byref(w), bf16, _abi.ptr(proj), _abi.ptr(ws), ws.numel(), stream,
+                              meta=(n, B)), "aig_gen_node_proj_batch")
+        ecap = max(max(Es), 1)
+        a = _abi.GenWireSet()
+        a.B, a.n, a.K, a.ecap, a.plan_shared, a.x_shared = B, n, K, ecap, int(shared), int(shared)
+        a.x = _abi.ptr(x_all)
+        for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
+            setattr(a, name, _abi.ptr(arrays[name]))
+        a.proj, a.proj_rows = _abi.ptr(proj), rows
+        a.sc2_w, a.sc2_b = _abi.ptr(self.edge_scorer[2].weight), _abi.ptr(self.edge_scorer[2].bias)
+        a.at2_w, a.at2_b = _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias)
+        logits = torch.empty((B, n, K), dtype=torch.float32, device=dev)
+        sel = torch.empty((B, n, 2), dtype=torch.int32, device=dev)
+        edge_index = torch.empty((B, 2, ecap), dtype=torch.int64, device=dev)
+        edge_attr = torch.empty((B, ecap), dtype=torch.int64, device=dev)
+        ecount = torch.empty(B, dtype=torch.int32, device=dev)
+        x_out = torch.empty((B * n, 2), dtype=torch.float32, device=dev)
+        a.logits, a.sel = _abi.ptr(logits), _abi.ptr(sel)
+        a.edge_index, a.edge_attr, a.ecount, a.x_out = _abi.ptr(edge_index), _abi.ptr(edge_attr), _abi.ptr(ecount), _abi.ptr(x_out)
+        _abi.check(_abi.timed("aig_gen_wire_batch", lib.aig_gen_wire_batch, C.byref(a), stream, meta=(n, B, K)),
+                   "aig_gen_wire_batch")
+        return GraphSet(B, n, ecap, x_out, edge_index, edge_attr, ecount, nd_all, counts_host=Es, x_dtype=first.x.dtype)
+
     def _wire(self, plan, x_in, x_src, nd, pa, pb, pa2, pb2, n, K, E, dev, debug=None) -> Data:
         """Scores, tie-exact selection and edge assembly from the four projection planes (generator.py:139-209)."""
         lib = _abi.lib()

@@ -354,6 +354,76 @@ size_t aig_resync_ws_bytes(int64_t n, int64_t E);
 int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
                int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- sets of graphs -----------------------------------------------------------------------------------
+ * The reference repairs, scores and resyncs the graphs of a minibatch (train.py:242-245,287) and the samples
+ * of a bulk run (AIGgan.py:104-110) one after another.  These entry points take B graphs of n nodes each in
+ * one call, a handful of launches for the whole set: every graph gets exactly the result the single-graph
+ * entry point above gives it.
+ *   edge slots: graph g's sources at edge_index[(2g) ecap + e], targets at edge_index[(2g+1) ecap + e],
+ *   inversion values at edge_attr[g ecap + e], e < ecount[g] (ecount NULL: all ecap slots hold edges);
+ *   node arrays (x [B n, 2], node_depth / inv_cnt / depth [B n]) are the graphs' arrays back to back. */
+
+/* Node projections (aig_gen_node_proj) of B graphs in one call: x holds 2n floats per graph, or one
+ * template's when x_shared (then only z differs between the graphs); z [B][128]; bf16 != 0 takes the bf16
+ * matrix-core pipeline of aig_gen_node_proj_bf16.  proj [4][B rows][128] with rows =
+ * aig_gen_batch_rows(n) rows per graph (n rounded up to the 64-row tile; rows past n are unspecified). */
+int64_t aig_gen_batch_rows(int64_t n);
+size_t aig_gen_node_proj_batch_ws_bytes(int64_t B, int64_t n, int bf16);
+int aig_gen_node_proj_batch(int64_t B, int64_t n, const float* x, int x_shared, const float* z,
+                            const aig_gen_weights* w, int bf16, float* proj, void* ws, size_t ws_bytes, void* stream);
+
+/* Scores, tie-exact selection and edge assembly (aig_gen_score, aig_topk_select, aig_gen_emit) of B graphs:
+ * three launches for the set.  Plan arrays are [B][...] back to back, or one plan when plan_shared. */
+typedef struct aig_gen_wire_set {
+    int64_t B, n, K;
+    int64_t ecap;             /* edge slots per graph in the outputs (>= every graph's eoff[n]) */
+    int64_t plan_shared;      /* 1: order .. cand describe one template used by all graphs */
+    int64_t x_shared;         /* 1: x is one template's [n][2] */
+    const float* x;           /* [B n][2] or [n][2] */
+    const int32_t *order, *rank, *want, *cnt, *fb;   /* [B][n] or [n] */
+    const int32_t* eoff;      /* [B][n+1] or [n+1] */
+    const int32_t* cand;      /* [B][n][K] or [n][K] */
+    const float* proj;        /* [4][B proj_rows][128] from aig_gen_node_proj_batch */
+    int64_t proj_rows;
+    const float *sc2_w, *sc2_b, *at2_w, *at2_b;      /* edge_scorer.2 / edge_attr_pred.2 */
+    float* logits;            /* scratch [B][n][K] */
+    int32_t* sel;             /* scratch [B][n][2] */
+    int64_t* edge_index;      /* out [B][2][ecap] */
+    int64_t* edge_attr;       /* out [B][ecap] */
+    int32_t* ecount;          /* out [B] */
+    float* x_out;             /* out [B n][2] */
+} aig_gen_wire_set;
+int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream);
+
+/* aig_enforce on B graphs.  depth holds depth_stride entries per graph: n, or 0 when all graphs share one
+ * depth vector (samples of one template).  Outputs in the same slot layout with `cap` (>= 2n) slots per
+ * graph and out_count[B]. */
+size_t aig_enforce_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
+int aig_enforce_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                      const int64_t* edge_index, const int64_t* edge_attr, int depth_kind, const void* depth,
+                      int64_t depth_stride, int64_t* out_edge_index, int64_t cap, int64_t* out_edge_attr,
+                      int32_t* out_count, int64_t* node_depth, float* x_out, void* ws, size_t ws_bytes, void* stream);
+
+/* aig_penalties on B graphs: out9 [B][9]. */
+size_t aig_penalties_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
+int aig_penalties_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                        const int64_t* edge_index, float* out9, void* ws, size_t ws_bytes, void* stream);
+
+/* aig_resync on B graphs (a graph with a cycle gets zeros, the others their levels). */
+size_t aig_resync_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
+int aig_resync_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,
+                     const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* Edge slots of B graphs -> the edge tensors of the padded minibatch the critic takes: pad_data
+ * (utilities/data_process.py:30-68) on every graph, then PyG's concatenation with node offsets
+ * (train.py:243-245).  out_edge_index [2][B max_edges]: graph g owns columns [g max_edges, (g+1) max_edges),
+ * its first min(ecount[g], max_edges) edges with g n added to both endpoints, then -1 + g n (the loader
+ * shifts the pad value like any other entry); out_edge_attr [B max_edges] with 0 on pad columns. */
+int aig_pad_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,
+                  const int64_t* edge_attr, int64_t max_edges, int64_t* out_edge_index, int64_t* out_edge_attr,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,189 @@
+"""Sets of graphs through one call (``gan_amd.graphset``, the ``*_batch`` entry points): every graph of a set must
+come out exactly as the single-graph function - itself held to the reference's outputs in
+test_constraints_gpu.py - returns it.  Integers, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from gan_amd.constraints import (aig_constraint_penalties, enforce_aig_constraints, enforce_set, pad_set,
+                                 penalties_set, repair_and_resync, repair_and_resync_set, resync_attrs, resync_set)
+from gan_amd.data import Batch, Data
+from gan_amd.dataset import pad_data
+from gan_amd.graphset import GraphSet
+from gan_amd.synth import synth_aig
+from oracle import cpu as ocpu
+from test_constraints_gpu import PEN_KEYS, assert_same_graph, junk_graph, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def mixed_graphs(n, depth_mode, seed):
+    """Graphs of n nodes: random junk with different edge counts (cycles, repeats, self loops), valid forward
+    AIGs (acyclic: the resync reports levels), one graph with a single edge and one without any."""
+    gs = [junk_graph(n, e, seed + i, depth_mode) for i, e in enumerate((3 * n, n // 2, 7 * n, 5))]
+    for i in range(2):
+        n_pi, n_po = max(2, n // 20), max(1, n // 25)
+        a = synth_aig(n_pi, n - n_pi - n_po, n_po, seed=seed + 10 + i, window=64)
+        a.edge_attr = a.edge_attr.long()
+        if depth_mode == "float":
+            a.node_depth = a.node_depth.float()
+        elif depth_mode is None:
+            a.node_depth = None
+        else:
+            a.node_depth = a.node_depth.long()
+        gs.append(a)
+    empty = junk_graph(n, 10, seed + 99, depth_mode)
+    empty.edge_index = torch.zeros((2, 0), dtype=torch.long)
+    empty.edge_attr = torch.zeros((0, 1), dtype=torch.long)
+    gs.insert(2, empty)
+    return gs
+
+
+@pytest.mark.parametrize("n,depth_mode", [(60, "long"), (700, "float"), (3000, None), (20000, "long")])
+def test_every_graph_of_a_set_matches_its_single_graph_result(n, depth_mode):
+    graphs = mixed_graphs(n, depth_mode, seed=n)
+    on_dev = [to_dev(g) for g in graphs]
+    gset = GraphSet.from_data_list(on_dev)
+    assert gset.B == len(graphs) and gset.edge_index.shape == (gset.B, 2, gset.ecap)
+    # penalties
+    pen = penalties_set(gset).cpu().numpy()
+    for g, d in enumerate(on_dev):
+        ref = aig_constraint_penalties(d.clone())
+        for i, k in enumerate(PEN_KEYS):
+            assert float(pen[g, i]) == float(ref[k]), (g, k)
+    # repair (with its breadth-first depths), then attributes of the repaired graphs
+    fixed = enforce_set(gset)
+    singles = [enforce_aig_constraints(d.clone()) for d in on_dev]
+    for g, ref in enumerate(singles):
+        assert_same_graph(fixed.graph(g), ref)
+    assert fixed.counts() == [int(r.edge_index.size(1)) for r in singles]
+    pen_fixed = penalties_set(fixed).cpu().numpy()
+    for g, ref in enumerate(singles):
+        assert float(pen_fixed[g, 8]) == float(aig_constraint_penalties(ref.clone())["total"])
+    # resync of the raw graphs (cycles: zeros; the valid AIGs: their levels) and the fused sampling tail
+    rs = resync_set(GraphSet.from_data_list([to_dev(g) for g in graphs]))
+    deep = 0
+    for g, d in enumerate(graphs):
+        ref = resync_attrs(to_dev(d))
+        assert_same_graph(rs.graph(g), ref)
+        deep = max(deep, int(ref.node_depth.max()))
+    assert deep > 3
+    tail = repair_and_resync_set(GraphSet.from_data_list([to_dev(g) for g in graphs]))
+    for g, d in enumerate(graphs):
+        assert_same_graph(tail.graph(g), repair_and_resync(to_dev(d)))
+    # against the CPU checker directly for two of the graphs
+    for g in (0, 4):
+        assert_same_graph(fixed.graph(g), ocpu.enforce_aig_constraints(graphs[g].clone()))
+
+
+@pytest.mark.parametrize("max_edges", [40, 5000])
+def test_padded_minibatch_of_a_set(max_edges):
+    n = 300
+    graphs = mixed_graphs(n, "long", seed=5)
+    fixed = enforce_set(GraphSet.from_data_list([to_dev(g) for g in graphs]))
+    ei, ea = pad_set(fixed, max_edges)
+    ref = Batch.from_data_list([pad_data(d, n, max_edges) for d in fixed.graphs()])
+    assert torch.equal(ei, ref.edge_index) and torch.equal(ea, ref.edge_attr)
+    assert torch.equal(fixed.x, ref.x) and torch.equal(fixed.node_depth, ref.node_depth)
+
+
+def test_shared_depth_vector_and_single_graph_sets():
+    """Samples of one template share its depth vector (stride 0); a set of one graph is the plain call."""
+    n = 500
+    base = junk_graph(n, 4 * n, 3, "float")
+    variants = []
+    for i in range(5):
+        v = junk_graph(n, 3 * n + 50 * i, 40 + i, "float")
+        v.x = base.x.clone()                      # same node types, different edges
+        v.node_depth = base.node_depth.clone()
+        variants.append(v)
+    gset = GraphSet.from_data_list([to_dev(v) for v in variants])
+    gset.node_depth = base.node_depth.to(DEV)     # one vector for all
+    assert gset.depth_shared
+    fixed = enforce_set(gset)
+    for g, v in enumerate(variants):
+        ref = enforce_aig_constraints(to_dev(v))
+        got = fixed.graph(g)
+        assert_same_graph(got, ref)
+    one = enforce_set(GraphSet.from_data_list([to_dev(variants[0])]))
+    assert_same_graph(one.graph(0), enforce_aig_constraints(to_dev(variants[0])))
+
+
+def test_large_set_runs_in_the_global_memory_regimes():
+    """64 graphs of 20,000 nodes: 1.28M union nodes, beyond what the LDS-resident walks hold."""
+    n = 20000
+    graphs = [junk_graph(n, 2 * n + 100 * i, 900 + i, "long") for i in range(62)]
+    for i in range(2):
+        a = synth_aig(200, n - 400, 200, seed=i, window=512)
+        a.edge_attr = a.edge_attr.long()
+        a.node_depth = a.node_depth.long()
+        graphs.append(a)
+    gset = GraphSet.from_data_list([to_dev(g) for g in graphs])
+    tail = repair_and_resync_set(gset)
+    pen = penalties_set(gset).cpu().numpy()
+    for g in (0, 17, 61, 62, 63):
+        assert_same_graph(tail.graph(g), repair_and_resync(to_dev(graphs[g])))
+        ref = aig_constraint_penalties(to_dev(graphs[g]))
+        for i, k in enumerate(PEN_KEYS):
+            assert float(pen[g, i]) == float(ref[k]), (g, k)
+
+
+# ------------------------------------------------------------------------------------------ generator
+def _templates(n_list_seed, n_pi, n_and, n_po, count, orientation="dataset"):
+    out = []
+    for i in range(count):
+        g = synth_aig(n_pi + i, n_and - i, n_po, seed=n_list_seed + i, window=48 + 16 * i, orientation=orientation)
+        out.append(Data(x=g.x.to(DEV), node_depth=g.node_depth.to(DEV)))
+    return out
+
+
+@pytest.mark.parametrize("K", [16, 64, 200, 300])
+@pytest.mark.parametrize("score_dtype", ["fp32", "bf16"])
+def test_generator_on_a_set_equals_one_graph_at_a_time(K, score_dtype):
+    from gan_amd.generator import AIGGenerator
+    from util_golden import gen_state
+    G = AIGGenerator(candidate_k=K, score_dtype=score_dtype).to(DEV)
+    G.load_state_dict(gen_state())
+    gen = torch.Generator().manual_seed(K)
+    # (a) the graphs of a padded minibatch: different templates of one node count
+    tpls = _templates(70, 20, 900, 12, 5)
+    zs = torch.randn(5, 128, generator=gen).to(DEV)
+    gset = G.forward_set(tpls, zs)
+    assert gset.B == 5 and gset.n == tpls[0].x.size(0)
+    for g, t in enumerate(tpls):
+        assert_same_graph(gset.graph(g), G(t, zs[g]))
+    assert gset.counts() == [int(c) for c in gset.count.tolist()]
+    again = G.forward_set(tpls, zs)                     # the stacked plans come from the cache now
+    for g in range(5):                                  # (slots behind a graph's count are unspecified)
+        assert_same_graph(again.graph(g), gset.graph(g))
+    # (b) samples of one template
+    zs = torch.randn(7, 128, generator=gen).to(DEV)
+    sset = G.forward_set(tpls[2], zs)
+    for g in range(7):
+        assert_same_graph(sset.graph(g), G(tpls[2], zs[g]))
+    # ... and straight through repair + resync, against the one-at-a-time sampling tail
+    tail = repair_and_resync_set(sset)
+    for g in range(7):
+        assert_same_graph(tail.graph(g), repair_and_resync(G(tpls[2], zs[g])))
+
+
+def test_generator_set_of_one_and_templates_without_targets():
+    from gan_amd.generator import AIGGenerator
+    from util_golden import gen_state
+    G = AIGGenerator(candidate_k=32).to(DEV)
+    G.load_state_dict(gen_state())
+    tpl = _templates(5, 6, 130, 4, 1)[0]
+    z = torch.randn(1, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+    assert_same_graph(G.forward_set([tpl], z).graph(0), G(tpl, z[0]))
+    assert_same_graph(G.forward_set(tpl, z).graph(0), G(tpl, z[0]))
+    # only PIs: no edge is emitted, the repair and the penalties take their early exits
+    bare = Data(x=torch.zeros((40, 2), device=DEV), node_depth=torch.zeros(40, device=DEV))
+    zs = torch.randn(3, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+    gset = G.forward_set(bare, zs)
+    assert gset.counts() == [0, 0, 0]
+    ref = enforce_aig_constraints(G(bare, zs[0]))
+    fixed = enforce_set(gset)
+    for g in range(3):
+        assert_same_graph(fixed.graph(g), ref)
+    assert float(penalties_set(gset).abs().sum()) == 0.0
