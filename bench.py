@@ -10,8 +10,9 @@ penalties.  Every rank holds its own minibatch (weak scaling); for N > 1 the cri
 all-reduced over RCCL after each critic backward.  Rank 0 prints ONE JSON line:
 
   value            train edges/s = (real + fake non-sentinel edges of all ranks' minibatches) / step time
-  sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job, with
-                   several independent samples in flight (bulk sampling); ..._one_at_a_time is the plain loop
+  sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job, in
+                   blocks of draws that go through the kernels as one set of graphs (bulk sampling);
+                   ..._streams keeps single samples in flight on several streams, ..._one_at_a_time is the plain loop
   roofline         the dominant kernel (fused GAT aggregate, aig_gat_fwd): algorithmic bytes of its
                    launches inside the timed region / their duration from stream events
   cpu_baseline     the CPU checker's training step on a bounded sample, timed on this host (rank 0, N=1)
@@ -210,8 +211,8 @@ def side_workload(name: str, dev, steps: int, warmup: int):
 def bulk_sampling(a, rank, world, dev):
     """BASELINE.json's bulk-sampling configuration on this rank's share: samples from one c7552-sized template at
     candidate-k 256 with the node projections on the bf16 matrix cores, no collective (ranks only meet at the
-    timing barriers).  A step = one block of --bulk-batch samples: generator (one projection launch per block),
-    repair, resync.  Rank 0 prints the JSON line."""
+    timing barriers).  A step = one block of --bulk-batch samples that goes through generator, repair and resync
+    as one set of graphs (gan_amd.sample.sample_sets).  Rank 0 prints the JSON line."""
     from gan_amd import _abi
     from gan_amd.data import Data
     from gan_amd.generator import AIGGenerator
@@ -224,7 +225,6 @@ def bulk_sampling(a, rank, world, dev):
     torch.manual_seed(123)
     G = AIGGenerator(candidate_k=256, score_dtype=a.score_dtype).to(dev).eval()
     S = a.bulk_batch
-    streams = [torch.cuda.Stream(device=dev) for _ in range(a.sample_in_flight)]
 
     def block(step):      # z_i from the CPU generator seeded base + rank * 10^6 + i, as the configuration words it
         zs = torch.stack([torch.randn(128, generator=torch.Generator().manual_seed(7 + rank * 10**6 + step * S + i))
@@ -239,7 +239,7 @@ def bulk_sampling(a, rank, world, dev):
 
     def run(first, count):
         edges = 0
-        for d in sample_bulk(G, tpl, (block(first + k) for k in range(count)), streams=streams):
+        for d in sample_bulk(G, tpl, (block(first + k) for k in range(count))):
             edges += int(d.edge_index.size(1))
         return edges
 
@@ -254,7 +254,7 @@ def bulk_sampling(a, rank, world, dev):
         dist.all_reduce(stat, op=dist.ReduceOp.MAX)
         elapsed = float(stat.item())
     # the projection launch of a block, bracketed with events in one extra untimed step
-    entry = "aig_gen_node_proj_bf16" if a.score_dtype == "bf16" else "aig_gen_node_proj"
+    entry = "aig_gen_node_proj_batch"
     _abi.timeline.reset()
     _abi.timeline.only = {entry}
     _abi.timeline.enabled = True
@@ -264,14 +264,14 @@ def bulk_sampling(a, rank, world, dev):
     ms, launches = _abi.timeline.totals_ms().get(entry, (0.0, 0))
     if rank != 0:
         return
-    rows = S * ((n + 63) // 64 * 64) if a.score_dtype == "bf16" else n
+    rows = S * ((n + 63) // 64 * 64)
     out = {"metric": "AIG nodes/sec sampled (bulk, candidate-k 256)", "value": round(n * S * a.steps * world / elapsed, 1),
            "unit": "nodes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(elapsed * 1e3 / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16" if a.score_dtype == "bf16" else "f32", "data": "synthetic",
            "config": {"workload": f"bulk_k256: {S} samples per step per GPU from one {name}-sized template ({n} nodes: {n_pi} PI / "
                                   f"{n_and} AND / {n_po} PO), candidate-k 256, node projections in {a.score_dtype}, generator + repair + "
-                                  "resync per sample, no collectives", "samples_per_step_per_gpu": S,
+                                  "resync of a block as one set of graphs, no collectives", "samples_per_step_per_gpu": S,
                       "samples_per_gpu": S * a.steps, "nodes_per_sample": n, "edges_per_sample": round(edges / (S * a.steps), 1),
                       "parallelism": f"{world} independent rank(s)"},
            "samples_per_sec": round(S * a.steps * world / elapsed, 1)}
@@ -440,7 +440,7 @@ def main():
     draw_z = lambda: torch.randn(128, device=dev, generator=gen)   # noqa: E731
     nodes_per_iter = sum(int(t.x.size(0)) for t in templates)
 
-    def sample_rate(run):
+    def sample_rate(run, per_iter=1):
         run(1)
         barrier()
         s0 = time.perf_counter()
@@ -449,7 +449,7 @@ def main():
         s_stat = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(s_stat, op=dist.ReduceOp.MAX)
-        return nodes_per_iter * a.sample_iters * world / float(s_stat.item())
+        return nodes_per_iter * per_iter * a.sample_iters * world / float(s_stat.item())
 
     def one_at_a_time(iters):
         for _ in range(iters):
@@ -462,6 +462,14 @@ def main():
         for _ in sample_many(trainer.G, ((t, draw_z) for _ in range(iters) for t in templates), streams=sample_streams):
             pass
 
+    from gan_amd.sample import block_size, sample_sets
+    S_set = min(block_size(int(t.x.size(0)), 64) for t in templates)
+
+    def as_sets(iters):     # bulk sampling of small templates as gan_amd.sample does it: blocks of draws as one set of graphs
+        for t in templates:
+            for _ in sample_sets(trainer.G, t, (torch.stack([draw_z() for _ in range(S_set)]) for _ in range(iters))):
+                pass
+
     # the matrix-core roofline is read here, where nothing else shares the GPU with the projection
     # kernel (inside a training step the generator pass runs next to the replayed critic term)
     _abi.timeline.reset()
@@ -470,7 +478,10 @@ def main():
     sample_nodes_per_sec_single = sample_rate(one_at_a_time)
     _abi.timeline.enabled = False
     tl_proj = _abi.timeline.totals_ms()
-    sample_nodes_per_sec = sample_rate(in_flight)
+    sample_nodes_per_sec_streams = sample_rate(in_flight)
+    # gan_amd.sample takes blocks of draws as sets of graphs while a block stays small enough for the LDS-resident
+    # walks, and single samples on several streams beyond (a 100k-node template)
+    sample_nodes_per_sec = sample_rate(as_sets, S_set) if S_set > 1 else sample_nodes_per_sec_streams
 
     if rank == 0:
         ms_fwd, launches = tl.get("aig_gat_fwd", (0.0, 0))
@@ -514,11 +525,14 @@ def main():
                        "edges_per_step_per_gpu": round(edges_rank / a.steps, 1),
                        "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
             "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
+            "sample_nodes_per_sec_streams": round(sample_nodes_per_sec_streams, 1),
             "sample_nodes_per_sec_one_at_a_time": round(sample_nodes_per_sec_single, 1),
             "sample_note": f"G.forward + enforce + resync per sample (gan_amd.constraints.repair_and_resync: same tensors as "
                            "the two calls in a row, without the repair's own depth walk that the resync overwrites); "
-                           f"bulk rate with {a.sample_in_flight} independent "
-                           "samples in flight on as many streams, and the rate of strictly one sample after another",
+                           f"bulk rate as gan_amd.sample runs it (blocks of {S_set} draws per template as one set of graphs; "
+                           "1 = templates too large for that, then the streams rate), "
+                           f"the rate with {a.sample_in_flight} independent samples in flight "
+                           "on as many streams, and the rate of strictly one sample after another",
             "roofline": roof,
             "roofline_mfma": mfma,
             "timeline_ms_per_step": {k: round(v[0] / inst_steps, 3) for k, v in sorted(tl_all.items())},

@@ -632,38 +632,50 @@ __global__ void k_enf_depth_out(GraphSet gs, const int* __restrict__ in, long lo
 // ------------------------------------------------------------------------------------------ penalties / validate
 // counters (PEN_CTRS per graph): 0 pi_in, 1 po_out, 2 backedge, 3 selfloop, 4 fanin_type
 constexpr int PEN_CTRS = 16;
+
+// counters[g][idx] += amount, one atomic per wave for the lanes that share the first lane's graph (neighbouring
+// lanes hold neighbouring edges / nodes, so that is all of them except where a wave straddles two graphs):
+// a per-lane atomic on a handful of addresses is served one lane at a time.  Every lane of the wave must call.
+__device__ __forceinline__ void wave_count(int* __restrict__ counters, int g, int idx, int amount) {
+    const int g0 = __builtin_amdgcn_readfirstlane(g);
+    int mine = g == g0 ? amount : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&counters[g0 * PEN_CTRS + idx], mine);
+    if (g != g0 && amount) atomicAdd(&counters[g * PEN_CTRS + idx], amount);
+}
 __global__ void k_pen_edges(GraphSet gs, const long long* __restrict__ ei, const int* __restrict__ types,
                             const int* __restrict__ pos, int* __restrict__ counters, int* __restrict__ indeg,
                             unsigned long long* __restrict__ pair_key, unsigned* __restrict__ key_src,
                             unsigned* __restrict__ key_dst, int* __restrict__ ids, unsigned char* __restrict__ eflag) {
     const int M = gs.M(), N = gs.N();
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M; e += gridDim.x * blockDim.x) {
-        int g;
+    // whole waves stay in the loop (a lane past the end carries an absent edge): the counts are summed per wave
+    for (int base = blockIdx.x * blockDim.x; base < M; base += gridDim.x * blockDim.x) {
+        const int e = base + threadIdx.x;
+        int g = 0;
         long long lu = -1, lv = -1;
-        const bool have = load_edge(gs, ei, e, g, lu, lv);
-        ids[e] = e;
-        if (!have || !in_range(lu, lv, gs.n)) {  // the reference cannot index such an edge; it is left out of every count
-            pair_key[e] = ~0ull; key_src[e] = (unsigned)N; key_dst[e] = (unsigned)N;
-            if (eflag) eflag[e] = 0;
-            continue;
-        }
-        const int u = g * gs.n + (int)lu, v = g * gs.n + (int)lv;
+        const bool have = e < M && load_edge(gs, ei, e, g, lu, lv);
+        const bool ok = have && in_range(lu, lv, gs.n);
+        const int u = ok ? g * gs.n + (int)lu : 0, v = ok ? g * gs.n + (int)lv : 0;
         const int tu = types[u], tv = types[v];
-        const bool self = u == v, to_pi = tv == PI_T, from_po = tu == PO_T, back = !(pos[u] < pos[v]);
-        const bool bad_src = (tv == AND_T || tv == PO_T) && !(tu == PI_T || tu == AND_T);
+        const bool self = ok && u == v, to_pi = ok && tv == PI_T, from_po = ok && tu == PO_T;
+        const bool back = ok && !(pos[u] < pos[v]);
+        const bool bad_src = ok && (tv == AND_T || tv == PO_T) && !(tu == PI_T || tu == AND_T);
         if (counters) {
-            int* c = counters + g * PEN_CTRS;
-            if (to_pi) atomicAdd(&c[0], 1);
-            if (from_po) atomicAdd(&c[1], 1);
-            if (back) atomicAdd(&c[2], 1);
-            if (self) atomicAdd(&c[3], 1);
-            if (bad_src) atomicAdd(&c[4], 1);
+            wave_count(counters, g, 0, to_pi);
+            wave_count(counters, g, 1, from_po);
+            wave_count(counters, g, 2, back);
+            wave_count(counters, g, 3, self);
+            wave_count(counters, g, 4, bad_src);
         }
+        if (e >= M) continue;
+        ids[e] = e;
+        // (the reference cannot index an edge with an endpoint out of range; it is left out of every count)
         if (eflag) eflag[e] = (unsigned char)((self ? 1 : 0) | (to_pi ? 4 : 0) | (from_po ? 8 : 0) | (bad_src ? 16 : 0));
-        atomicAdd(&indeg[v], 1);
-        pair_key[e] = (unsigned long long)u * (unsigned long long)N + (unsigned long long)v;
-        key_src[e] = (unsigned)u;
-        key_dst[e] = (unsigned)v;
+        if (ok) atomicAdd(&indeg[v], 1);
+        pair_key[e] = ok ? (unsigned long long)u * (unsigned long long)N + (unsigned long long)v : ~0ull;
+        key_src[e] = ok ? (unsigned)u : (unsigned)N;
+        key_dst[e] = ok ? (unsigned)v : (unsigned)N;
     }
 }
 
@@ -686,15 +698,18 @@ __global__ void k_pen_nodes(GraphSet gs, const int* __restrict__ types, const in
                             const int* __restrict__ fwd, const int* __restrict__ rev, int* __restrict__ counters,
                             unsigned char* __restrict__ on_path) {
     const int N = gs.N();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        int* c = counters + (i / gs.n) * PEN_CTRS;
-        const int t = types[i];
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {   // whole waves: see k_pen_edges
+        const int i = base + threadIdx.x;
+        const bool live = i < N;
+        const int j = live ? i : 0;
+        const int t = types[j];
         const int target = t == PO_T ? 1 : (t == AND_T ? 2 : 0);
-        const int d = indeg[i] - target;
-        if (d) atomicAdd(&c[6], d < 0 ? -d : d);
-        const bool ok = fwd[i] >= 0 && rev[i] >= 0;
-        if (!ok) atomicAdd(&c[7], 1);
-        if (on_path) on_path[i] = ok;
+        const int d = indeg[j] - target;
+        const bool ok = fwd[j] >= 0 && rev[j] >= 0;
+        const int g = j / gs.n;
+        wave_count(counters, g, 6, live ? (d < 0 ? -d : d) : 0);
+        wave_count(counters, g, 7, live && !ok);
+        if (live && on_path) on_path[i] = ok;
     }
 }
 

@@ -155,6 +155,19 @@ class Batch(Data):
         out._num_graphs = len(data_list)
         return out
 
+    @classmethod
+    def from_uniform(cls, num_graphs: int, nodes: int, edge_cols: int, **tensors) -> "Batch":
+        """A batch whose concatenated tensors already exist: ``num_graphs`` graphs of ``nodes`` nodes and
+        ``edge_cols`` edge columns each (``edge_index`` with the node offsets added), e.g. straight from a
+        kernel that pads a whole set of graphs."""
+        out = cls(**tensors)
+        out._node_counts = [int(nodes)] * int(num_graphs)
+        out._offsets = [g * int(nodes) for g in range(int(num_graphs) + 1)]
+        out._slices = {k: [g * (int(edge_cols) if k in ("edge_index", "edge_attr") else int(nodes))
+                           for g in range(int(num_graphs) + 1)] for k, v in tensors.items() if torch.is_tensor(v)}
+        out._num_graphs = int(num_graphs)
+        return out
+
     @property
     def num_graphs(self) -> int:
         return int(self._num_graphs)

@@ -45,21 +45,32 @@ class GraphSet:
         return self.node_depth is not None and self.B > 1 and self.node_depth.numel() == self.n
 
     # ------------------------------------------------------------------ per-graph views
-    def graph(self, g: int) -> Data:
-        """Graph ``g`` as the ``Data`` the single-graph functions return (own tensors, not views)."""
+    def graph(self, g: int, copy: bool = True) -> Data:
+        """Graph ``g`` as the ``Data`` the single-graph functions return.  ``copy=False`` hands out views of
+        the set's tensors instead of tensors of its own (``edge_index`` is then a strided ``[2, E]`` view)."""
         m = self.counts()[g]
         n = self.n
-        x = self.x[g * n:(g + 1) * n].clone()
+        x = self.x[g * n:(g + 1) * n]
+        nd = self.node_depth
+        if nd is not None and nd.numel() != n:
+            nd = nd[g * n:(g + 1) * n]
+        ei, ea = self.edge_index[g, :, :m], self.edge_attr[g, :m].reshape(-1, 1)
+        if copy:
+            x, ei, ea = x.clone(), ei.contiguous(), ea.clone()
+            nd = None if nd is None else nd.clone()
         if x.dtype != self.x_dtype:
             x = x.to(self.x_dtype)
-        nd = self.node_depth
-        if nd is not None:
-            nd = nd.clone() if nd.numel() == n else nd[g * n:(g + 1) * n].clone()
-        return Data(x=x, edge_index=self.edge_index[g, :, :m].contiguous(),
-                    edge_attr=self.edge_attr[g, :m].reshape(-1, 1).contiguous(), node_depth=nd)
+        return Data(x=x, edge_index=ei, edge_attr=ea, node_depth=nd)
 
-    def graphs(self) -> List[Data]:
-        return [self.graph(g) for g in range(self.B)]
+    def graphs(self, copy: bool = True) -> List[Data]:
+        return [self.graph(g, copy) for g in range(self.B)]
+
+    def cpu(self) -> "GraphSet":
+        """The set on the host (a few large copies; its graphs are then cut out there)."""
+        counts = self.counts()
+        return GraphSet(self.B, self.n, self.ecap, self.x.cpu(), self.edge_index.cpu(), self.edge_attr.cpu(), None,
+                        None if self.node_depth is None else self.node_depth.cpu(), counts_host=counts,
+                        x_dtype=self.x_dtype)
 
     # ------------------------------------------------------------------ from separate graphs
     @staticmethod

@@ -5,8 +5,10 @@ build the generator and load its weights, draw ``z`` on the device, one forward 
 gradients, ``enforce_aig_constraints``, ``resync_attrs``, save.  Extensions: ``--num-samples`` for
 bulk sampling (sample i draws z from a device generator seeded ``seed + i``, so sample 0 is the
 reference's draw and the set of samples does not depend on how many ranks produce it), and
-under torchrun the samples are dealt to the ranks with no collective at all.  Bulk sampling keeps
-``--in-flight`` samples in the air on as many streams (``sample_many``).
+under torchrun the samples are dealt to the ranks with no collective at all.  Bulk sampling takes the
+draws in blocks of ``--batch``: a block goes through generator, repair and resync as one set of graphs
+(``sample_sets``); ``--batch 1`` keeps ``--in-flight`` single samples in the air on as many streams
+(``sample_many``).
 """
 from __future__ import annotations
 
@@ -19,10 +21,11 @@ import torch
 
 from . import parallel
 from .constraints import (enforce_aig_constraints, enforce_begin, enforce_finish, repair_and_resync,
-                          resync_attrs)
+                          repair_and_resync_set, resync_attrs)
 from .data import Data
 from .dataset import load_pt_dataset
 from .generator import AIGGenerator
+from .graphset import GraphSet
 
 PI, PO, AND = 0, 1, 2
 
@@ -83,48 +86,53 @@ def sample_many(G: AIGGenerator, jobs: Iterable[Tuple[Data, Callable[[], torch.T
         yield finish()
 
 
-def sample_bulk(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 4,
-                streams: Optional[List[torch.cuda.Stream]] = None) -> Iterator[Data]:
-    """Bulk sampling from ONE template: every element of ``z_batches`` is a ``[S, z_dim]`` block of draws whose
-    generator passes share their node-projection launch (``AIGGenerator.forward_many``); repair and resync then
-    follow per sample with ``in_flight`` of them in the air, as in ``sample_many``.  Results come back in draw
-    order and equal ``sample_one(G, tpl, z)`` for every z."""
+# The level-by-level walks of repair and resync take a set of graphs as one graph; up to this many nodes
+# they keep their per-node counters in LDS.  Larger sets still work, but single samples on several streams
+# (``sample_many``) are then the faster way to keep the GPU busy.
+SET_NODES = 131072
+
+
+def block_size(n: int, batch: int) -> int:
+    """Draws per block for templates of ``n`` nodes: ``batch``, capped so that a block stays within SET_NODES."""
+    return max(1, min(int(batch), SET_NODES // max(int(n), 1)))
+
+
+def sample_sets(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 2) -> Iterator[GraphSet]:
+    """Bulk sampling from ONE template: every element of ``z_batches`` is a ``[S, z_dim]`` block of draws that
+    goes through generator, repair and resync as one set of graphs (``AIGGenerator.forward_set``,
+    ``repair_and_resync_set``): about forty launches per block whatever its size, and one host read (the
+    repaired edge counts) that is only awaited once ``in_flight - 1`` younger blocks have been enqueued.
+    Yields one ``GraphSet`` per block; its graph ``i`` equals ``sample_one(G, tpl, zs[i])``."""
     if in_flight < 1:
         raise ValueError("in_flight must be at least 1")
-    cur = torch.cuda.current_stream()
-    if streams is None:
-        streams = [torch.cuda.Stream(device=cur.device) for _ in range(in_flight)]
-    for st in streams:
-        st.wait_stream(cur)
     pending: deque = deque()
 
-    def finish():
-        st, handle = pending.popleft()
-        with torch.cuda.stream(st):
-            d = resync_attrs(enforce_finish(handle))
-        cur.wait_stream(st)
-        for v in d.to_dict().values():
-            if torch.is_tensor(v) and v.is_cuda:
-                v.record_stream(cur)
-        return d
+    def finish() -> GraphSet:
+        gset, counts_host, ready = pending.popleft()
+        ready.synchronize()
+        gset._counts_host = [int(c) for c in counts_host.tolist()]
+        return gset
 
-    k = 0
     for zs in z_batches:
         with torch.no_grad():
-            raws = G.forward_many(tpl, zs)        # on the caller's stream
-        for raw in raws:
-            st = streams[k % len(streams)]
-            k += 1
-            st.wait_stream(cur)
-            for v in raw.to_dict().values():      # made on the caller's stream, consumed on the sample's
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(st)
-            with torch.cuda.stream(st):
-                pending.append((st, enforce_begin(raw, want_depth=False)))
-            if len(pending) >= len(streams):
-                yield finish()
+            gset = repair_and_resync_set(G.forward_set(tpl, zs))
+        counts_host = torch.empty(gset.B, dtype=torch.int32, pin_memory=True)
+        counts_host.copy_(gset.count, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        pending.append((gset, counts_host, ready))
+        if len(pending) >= in_flight:
+            yield finish()
     while pending:
         yield finish()
+
+
+def sample_bulk(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 2) -> Iterator[Data]:
+    """``sample_sets`` handed out graph by graph, in draw order: the same tensors ``sample_one(G, tpl, z)``
+    returns for every z, as views of the block's tensors."""
+    for gset in sample_sets(G, tpl, z_batches, in_flight):
+        for g in range(gset.B):
+            yield gset.graph(g, copy=False)
 
 
 def out_path(base: str, i: int, total: int) -> str:
@@ -145,9 +153,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--template-idx", type=int, default=0)
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--num-samples", type=int, default=1, help="extension: bulk sampling")
-    ap.add_argument("--in-flight", type=int, default=4, help="extension: samples kept in flight during bulk sampling")
+    ap.add_argument("--in-flight", type=int, default=4, help="extension: samples kept in flight with --batch 1")
     ap.add_argument("--batch", type=int, default=64,
-                    help="extension: draws per generator launch block during bulk sampling (the samples are the same for any value)")
+                    help="extension: draws per block during bulk sampling - a block is one set of graphs for every kernel "
+                         "(the samples are the same for any value)")
     ap.add_argument("--score-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="extension: arithmetic of the node projections behind the candidate scores (bf16 = bf16 matrix "
                          "cores with f32 accumulation, for bulk sampling; the default is the reference's f32)")
@@ -182,12 +191,19 @@ def main(argv=None) -> None:
     def z_of(i):   # per-sample seed: the output set does not depend on the number of ranks
         return lambda: torch.randn(args.z_dim, device=device, generator=torch.Generator(device=device).manual_seed(args.seed + i))
 
-    def z_blocks():     # this rank's draws in blocks whose generator passes share a launch
-        for b in range(0, len(mine), args.batch):
-            yield torch.stack([z_of(i)() for i in mine[b:b + args.batch]])
+    block = block_size(tpl.x.size(0), args.batch)
 
-    results = (sample_bulk(G, tpl, z_blocks(), in_flight=args.in_flight) if args.batch > 1
-               else sample_many(G, ((tpl, z_of(i)) for i in mine), in_flight=args.in_flight))
+    def z_blocks():     # this rank's draws in blocks that go through the kernels as one set of graphs
+        for b in range(0, len(mine), block):
+            yield torch.stack([z_of(i)() for i in mine[b:b + block]])
+
+    def bulk():     # a block's tensors cross to the host in a few large copies; its graphs are cut out there
+        for gset in sample_sets(G, tpl, z_blocks()):
+            host = gset.cpu()
+            for g in range(host.B):
+                yield host.graph(g)
+
+    results = bulk() if block > 1 else sample_many(G, ((tpl, z_of(i)) for i in mine), in_flight=args.in_flight)
     for i, fixed in zip(mine, results):
         if args.num_samples == 1:
             print("[INFO] FIX:", summarize(fixed))

@@ -18,8 +18,13 @@ What differs, on purpose:
   and replayed (``CapturedCriticTerms``; ``--no-graph-capture`` keeps the eager path); the critic's
   fakes are generated and repaired on a second stream underneath the first replay of the
   real-side term (``--no-overlap`` keeps one stream);
+* the graphs of a minibatch all carry the padded node count, so the generator pass, the repair, the
+  penalties and the padding of the fakes take the minibatch as ONE set of graphs (``gan_amd/graphset.py``):
+  a dozen launches and no host read per pass instead of that per graph (``--no-sets`` keeps the
+  graph-by-graph calls; ``--unpad-templates`` implies them);
 * extension flags: ``--seed``, ``--unpad-templates`` (the reference's templates stay padded,
-  see gan_amd/dataset.py), ``--no-progress``, ``--no-graph-capture``, ``--autograd-gp``, ``--no-overlap``;
+  see gan_amd/dataset.py), ``--no-progress``, ``--no-graph-capture``, ``--autograd-gp``, ``--no-overlap``,
+  ``--no-sets``;
 * the gradient penalty and its parameter gradient come from a closed form
   (``AIGDiscriminator.gradient_penalty_closed_form``) unless ``--autograd-gp`` is given.
 """
@@ -37,8 +42,9 @@ import torch
 
 from . import parallel
 from .constraints import (aig_constraint_penalties, enforce_aig_constraints, enforce_begin, enforce_finish,
-                          validate_strict_aig)
+                          enforce_set, pad_set, penalties_set, validate_strict_aig)
 from .data import Batch, Data, GraphLoader
+from .graphset import GraphSet
 from .dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
 from .discriminator import AIGDiscriminator, DynLevelPlan, GraphCSR
 from .generator import AIGGenerator
@@ -359,6 +365,7 @@ class Trainer:
         # ... and so do the critic's fakes (generator pass and repair), underneath the recorded
         # real-side term of the first critic iteration
         self.overlap_fakes = not bool(getattr(args, "no_overlap", False))
+        self.use_sets = not bool(getattr(args, "no_sets", False))
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
 
     def _mark(self, label: str) -> None:
@@ -421,6 +428,23 @@ class Trainer:
     def _pad_batch(self, graphs: List[Data]) -> Batch:
         return Batch.from_data_list([pad_data(g, self.max_nodes, self.max_edges) for g in graphs]).to(self.device)
 
+    def _pad_set(self, gset: GraphSet) -> Batch:
+        """``_pad_batch(gset.graphs())`` in one launch (the graphs already have ``max_nodes`` nodes each)."""
+        ei, ea = pad_set(gset, self.max_edges)
+        nd = gset.node_depth
+        if nd is None:
+            nd = torch.zeros(gset.B * gset.n, dtype=torch.long, device=self.device)    # pad_data: depth 0 when absent
+        elif nd.numel() == gset.n and gset.B > 1:
+            nd = nd.repeat(gset.B)
+        x = gset.x if gset.x.dtype == gset.x_dtype else gset.x.to(gset.x_dtype)
+        return Batch.from_uniform(gset.B, gset.n, self.max_edges, x=x, edge_index=ei, edge_attr=ea,
+                                  node_depth=nd.to(torch.long))
+
+    def _as_set(self, templates: List[Data]) -> bool:
+        """The graphs of the minibatch go through the generator and the constraint kernels as one set when
+        they all have the padded node count (the reference's default: templates keep their padding)."""
+        return self.use_sets and all(int(t.x.size(0)) == self.max_nodes for t in templates)
+
     def step(self, real_padded: Batch, epoch: int = 0, save_dir: Optional[str] = None) -> Dict[str, float]:
         a, dev, G, D = self.args, self.device, self.G, self.D
         real_padded = real_padded.to(dev)
@@ -445,13 +469,18 @@ class Trainer:
             if fakes_stream is not main_stream:
                 terms.replay_real()       # the first iteration's real-side term: one launch, then the
                 real_replayed = True      # host goes on to enqueue the fakes next to it
+            as_set = self._as_set(templates)
             with torch.cuda.stream(fakes_stream):
                 zs_once = [self.draw_z() for _ in templates]
-                raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
-                # every repair is enqueued before the first edge count is awaited: one wait per minibatch
-                repairs = [enforce_begin(r) for r in raw_fakes_once]
-                corr_fakes_once = [enforce_finish(h) for h in repairs]
-                fake_padded = self._pad_batch(corr_fakes_once)
+                if as_set:
+                    # generator, repair and padding for the whole minibatch: a dozen launches, no host read
+                    fake_padded = self._pad_set(enforce_set(G.forward_set(templates, torch.stack(zs_once))))
+                else:
+                    raw_fakes_once = [G(t, z) for t, z in zip(templates, zs_once)]
+                    # every repair is enqueued before the first edge count is awaited: one wait per minibatch
+                    repairs = [enforce_begin(r) for r in raw_fakes_once]
+                    corr_fakes_once = [enforce_finish(h) for h in repairs]
+                    fake_padded = self._pad_batch(corr_fakes_once)
                 fake_for_D = fake_padded
                 edges_fake = count_edges(fake_padded.edge_index)
             main_stream.wait_stream(fakes_stream)
@@ -508,12 +537,19 @@ class Trainer:
         self._mark("critic done")
         self.opt_G.zero_grad()
         zs = [self.draw_z() for _ in templates]
-        raw_gen = [G(t, z) for t, z in zip(templates, zs)]
+        if as_set:
+            raw_set = G.forward_set(templates, torch.stack(zs))
+            raw_gen = None        # the separate graphs are only made when a save step asks for them
+        else:
+            raw_gen = [G(t, z) for t, z in zip(templates, zs)]
         self.side_stream.wait_stream(main_stream)
         with torch.cuda.stream(self.side_stream):
-            pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
-            loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
-        raw_batch_for_D = self._pad_batch(raw_gen)
+            if as_set:
+                loss_pen = penalties_set(raw_set)[:, 8].mean()
+            else:
+                pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
+                loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
+        raw_batch_for_D = self._pad_set(raw_set) if as_set else self._pad_batch(raw_gen)
         if terms is not None:
             # the generator hands the template's depths through unchanged (generator.py:211-217) and the templates
             # are the real minibatch's graphs, so the padded depth vector of the raw batch is the real batch's:
@@ -523,6 +559,8 @@ class Trainer:
         main_stream.wait_stream(self.side_stream)
         loss_pen.record_stream(main_stream)
         if (self.global_step % a.save_every) == 0:
+            if raw_gen is None:
+                raw_gen = raw_set.graphs()
             scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
             loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
         loss_G = loss_G_adv + a.lambda_cons * loss_pen
@@ -532,7 +570,7 @@ class Trainer:
         self._mark("generator done")
 
         if save_dir is not None and (self.global_step % a.save_every) == 0:
-            self._save_samples(raw_gen, epoch, save_dir)
+            self._save_samples(raw_gen if raw_gen is not None else raw_set.graphs(), epoch, save_dir)
         self.global_step += 1
         return self.last
 
@@ -646,6 +684,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="compute the gradient penalty by double backward (autograd) instead of its closed form")
     p.add_argument("--no-overlap", dest="no_overlap", action="store_true",
                    help="generate the critic's fakes on the main stream instead of underneath the real-side term")
+    p.add_argument("--no-sets", dest="no_sets", action="store_true",
+                   help="run generator, repair and penalties graph by graph instead of once per minibatch")
     p.add_argument("--no-graph-capture", dest="graph_capture", action="store_false",
                    help="evaluate the real-side critic term and the gradient penalty eagerly instead of replaying a HIP graph")
     return p

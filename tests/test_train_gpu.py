@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from gan_amd.graphset import GraphSet
 from gan_amd.data import Batch, Data
 from gan_amd.dataset import pad_data, unpad_data
 from gan_amd.synth import synth_aig
@@ -167,7 +168,18 @@ def test_training_follows_reference_run(name, mode):
     tr.draw_z = lambda: next(zi).to(DEV)
     tr.draw_alpha = lambda: next(ai).to(DEV)
     feed = []
-    tr.G = lambda template, z: feed.pop(0)      # the recorded run's raw graphs stand in for the generator pass
+
+    class RecordedGenerator:
+        """The recorded run's raw graphs stand in for the generator pass (graph by graph, or as the set of a
+        minibatch the way the trainer asks for them)."""
+
+        def __call__(self, template, z):
+            return feed.pop(0)
+
+        def forward_set(self, templates, zs):
+            return GraphSet.from_data_list([feed.pop(0) for _ in templates])
+
+    tr.G = RecordedGenerator()
     last_epoch = 0
 
     def check_epoch(e):

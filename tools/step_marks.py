@@ -10,7 +10,7 @@ dev = torch.device("cuda")
 g = synth_aig(1000, 98000, 1000, seed=0, window=4096, orientation="dataset")
 n = g.x.size(0)
 real = Batch.from_data_list([pad_data(g, n, 2 * n)]).to(dev); real.sample_ids = [0]
-for extra in ([], ["--no-overlap"]):
+for extra in ([], ["--no-sets"], ["--no-overlap"]):
     args = build_parser().parse_args(["--dataset-dir", "x", "--out-dir", "/tmp/o", "--candidate-k", "64", "--save-every", "1000000000"] + extra)
     tr = Trainer(args, n, 2 * n, dev)
     for _ in range(4): tr.step(real)
