@@ -219,7 +219,8 @@ class CapturedCriticTerms:
     one floating-point addition per parameter."""
 
     def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], example: Batch, level_cap: int,
-                 gp_lambda: float, device: torch.device, closed_form_gp: bool = True):
+                 gp_lambda: float, device: torch.device, closed_form_gp: bool = True, fake_side: bool = False,
+                 fake_level_cap: int = 0):
         n = int(example.x.size(0))
         e_cols = 0 if example.edge_index is None else int(example.edge_index.size(1))
         self.n, self.e_cols, self.level_cap = n, e_cols, int(level_cap)
@@ -239,6 +240,18 @@ class CapturedCriticTerms:
         self._params = params
         self.load(example)
         self.x_fake.copy_(self.x_real)
+        # the generated side: score of a generated minibatch (the critic's repaired fakes, the generator step's
+        # raw graphs - same shapes as the real minibatch) and its gradient, over buffers of its own
+        self.fake_side = bool(fake_side)
+        self.fake_cap = max(int(fake_level_cap), self.level_cap)
+        if self.fake_side:
+            self.ei_f = torch.full((2, e_cols), -1, dtype=torch.int64, device=device)
+            self.ea_f = torch.zeros((e_cols, 1), **f32)
+            self.depth_f = torch.full((n,), -1, dtype=torch.int64, device=device)
+            self.plan_f = DynLevelPlan(n, self.fake_cap, device)
+            self.csr_f = None
+            self.fake_for_D = Data(x=self.x_fake, edge_index=self.ei_f, edge_attr=self.ea_f, node_depth=self.depth_f)
+            self.load_generated(example, check=False)
 
         def compute_real():
             d_real = mean_score(D, self.real_for_D)
@@ -254,6 +267,10 @@ class CapturedCriticTerms:
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha, plan=self.plan)
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
+        def compute_fake():
+            d_fake = mean_score(D, self.fake_for_D)
+            return d_fake.detach(), torch.autograd.grad(d_fake, params, allow_unused=True)
+
         self._compute_gp = compute_gp
         cur = torch.cuda.current_stream(device)
         side = torch.cuda.Stream(device=device)
@@ -262,6 +279,8 @@ class CapturedCriticTerms:
             for _ in range(2):
                 compute_real()
                 compute_gp()
+                if self.fake_side:
+                    compute_fake()
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
         # thread-local capture: a communicator's watchdog thread may query events while we record
@@ -275,6 +294,12 @@ class CapturedCriticTerms:
             with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
                 self.gp, self.grad_norm, grads_gp = compute_gp()
             self._grads_gp = self._present(grads_gp)
+        self.graph_fake = None
+        if self.fake_side:
+            self.graph_fake = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fake, capture_error_mode="thread_local"):
+                self.d_fake, grads_fake = compute_fake()
+            self._grads_fake = self._present(grads_fake)
 
     def _present(self, grads):
         """(parameters, gradients) of the parameters a term reaches."""
@@ -309,11 +334,47 @@ class CapturedCriticTerms:
             count = batch._edge_count = count_edges(batch.edge_index)
         self.edges_real = count
 
+    def load_generated(self, batch: Batch, check: bool = True) -> bool:
+        """Make ``batch`` (same shapes as the real minibatch) the input of the following ``replay_fake``: four
+        copies, its edge lists and level plan rebuilt in place.  With ``check``, one host read tells whether its
+        deepest level fits the recording (the same read the eager path spends on sizing its level plan); on
+        False the caller evaluates this minibatch eagerly."""
+        self.x_fake.copy_(batch.x)
+        if not self.fake_side:
+            return False
+        if self.e_cols:
+            self.ei_f.copy_(batch.edge_index)
+            ea = getattr(batch, "edge_attr", None)
+            if ea is not None and ea.numel() == self.e_cols:
+                self.ea_f.copy_(ea.reshape(-1, 1))
+            else:
+                self.ea_f.zero_()
+            if self.csr_f is None:
+                self.csr_f = GraphCSR(self.ei_f, self.ea_f, self.n)
+                self.fake_for_D._csr = self.csr_f
+            else:
+                self.csr_f.rebuild(self.ei_f, self.ea_f)
+        nd = getattr(batch, "node_depth", None)
+        if nd is not None:
+            self.depth_f.copy_(nd)
+        else:
+            self.depth_f.zero_()
+        self.plan_f.rebuild(self.depth_f)
+        self.fake_for_D._plan = self.plan_f
+        return not (check and self.plan_f.overflowed())
+
     def replay_real(self) -> None:
         self.graph_real.replay()
 
-    def replay_gp(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
-        self.x_fake.copy_(x_fake)
+    def replay_fake(self) -> None:
+        self.graph_fake.replay()
+
+    def add_fake_gradients(self, sign: float = 1.0) -> None:
+        ps, gs = self._grads_fake
+        torch._foreach_add_([p.grad for p in ps], gs, alpha=sign)
+
+    def replay_gp(self, alpha: torch.Tensor) -> None:
+        """The penalty term between the real minibatch and the generated one of the last ``load_generated``."""
         self.alpha.copy_(alpha.reshape(1, 1))
         if self.graph_gp is not None:
             self.graph_gp.replay()
@@ -322,8 +383,9 @@ class CapturedCriticTerms:
             self._grads_gp = self._present(grads_gp)
 
     def replay(self, x_fake: torch.Tensor, alpha: torch.Tensor) -> None:
+        self.x_fake.copy_(x_fake)
         self.replay_real()
-        self.replay_gp(x_fake, alpha)
+        self.replay_gp(alpha)
 
     def add_gradients(self) -> None:
         for ps, gs in (self._grads_real, self._grads_gp):
@@ -366,6 +428,8 @@ class Trainer:
         # real-side term of the first critic iteration
         self.overlap_fakes = not bool(getattr(args, "no_overlap", False))
         self.use_sets = not bool(getattr(args, "no_sets", False))
+        self.capture_fake = str(getattr(args, "capture_fake", "auto"))
+        self._fake_caps: Dict[tuple, int] = {}   # by minibatch shape: level cap the generated side was found to need
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
 
     def _mark(self, label: str) -> None:
@@ -412,8 +476,12 @@ class Trainer:
         top = max(depth_top(real_padded), 0)
         cap = max(self.level_cap, 2 * top, 64)
         self._captured.pop(key, None)
+        # the generated side is recorded as well when the minibatch is small enough for the step to be bound by
+        # launch rate (an eager critic pass over it costs the host more than the GPU)
+        fake_side = self.capture_fake == "on" or (self.capture_fake == "auto" and key[0] <= 65536)
         terms = CapturedCriticTerms(self.D, self._d_params, real_padded, cap, self.args.gp_lambda, self.device,
-                                    closed_form_gp=self.closed_form_gp)
+                                    closed_form_gp=self.closed_form_gp, fake_side=fake_side,
+                                    fake_level_cap=self._fake_caps.get(key, 0))
         self.captures += 1
         self._captured[key] = terms
         if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
@@ -486,6 +554,17 @@ class Trainer:
             main_stream.wait_stream(fakes_stream)
             self._mark("fakes ready")
             self._edges_last = edges_fake + edges_real
+            fake_recorded = False
+            if terms is not None:
+                fake_recorded = terms.load_generated(fake_padded)
+                if terms.fake_side and not fake_recorded:
+                    # deeper than the recording holds: this step scores its fakes eagerly, the next one records anew
+                    key = (terms.n, terms.e_cols)
+                    self._fake_caps[key] = 2 * int(fake_padded.node_depth.max().item())
+                    self._captured.pop(key, None)
+                for p_ in self._d_params:      # the recorded gradients are added into the .grad tensors
+                    if p_.grad is None:
+                        p_.grad = torch.zeros_like(p_)
         except Exception as e:
             if self.world == 1:
                 raise
@@ -493,13 +572,23 @@ class Trainer:
         for it in range(a.n_critic):
             if failed is None:
                 try:
-                    self.opt_D.zero_grad()
+                    self.opt_D.zero_grad(set_to_none=terms is None)
                     if terms is not None:
+                        if fake_recorded:     # the three recorded terms are independent: the generated side
+                            self.side_stream.wait_stream(main_stream)          # runs next to the other two
+                            with torch.cuda.stream(self.side_stream):
+                                terms.replay_fake()
                         if not (it == 0 and real_replayed):
                             terms.replay_real()
-                        terms.replay_gp(fake_padded.x, self.draw_alpha())
-                        D_fake_mean = mean_score(D, fake_for_D)
-                        D_fake_mean.backward()
+                        terms.replay_gp(self.draw_alpha())
+                        if fake_recorded:
+                            main_stream.wait_stream(self.side_stream)
+                            if it == a.n_critic - 1:      # (the buffer is written again by the generator step)
+                                D_fake_mean = terms.d_fake.clone()
+                            terms.add_fake_gradients()
+                        else:
+                            D_fake_mean = mean_score(D, fake_for_D)
+                            D_fake_mean.backward()
                         terms.add_gradients()
                         if it == a.n_critic - 1:   # the logged scalars are those of the last iteration (train.py:263-272)
                             D_real_mean, gp_term, grad_norm = terms.d_real.clone(), terms.gp.clone(), terms.grad_norm.clone()
@@ -550,12 +639,18 @@ class Trainer:
                 pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
                 loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
         raw_batch_for_D = self._pad_set(raw_set) if as_set else self._pad_batch(raw_gen)
-        if terms is not None:
-            # the generator hands the template's depths through unchanged (generator.py:211-217) and the templates
-            # are the real minibatch's graphs, so the padded depth vector of the raw batch is the real batch's:
-            # the critic reuses the level plan that the recorded terms rebuilt for this step
-            raw_batch_for_D._plan = terms.plan
-        loss_G_adv = -mean_score(D, raw_batch_for_D)
+        # the generator hands the template's depths through unchanged (generator.py:211-217) and the templates
+        # are the real minibatch's graphs, so the padded depth vector of the raw batch is the real batch's: no
+        # deeper than the recordings hold, and the eager pass can reuse the level plan rebuilt for this step
+        raw_recorded = terms is not None and terms.fake_side and terms is self._captured.get((terms.n, terms.e_cols))
+        if raw_recorded:
+            terms.load_generated(raw_batch_for_D, check=False)
+            terms.replay_fake()
+            loss_G_adv = -terms.d_fake.clone()
+        else:
+            if terms is not None:
+                raw_batch_for_D._plan = terms.plan
+            loss_G_adv = -mean_score(D, raw_batch_for_D)
         main_stream.wait_stream(self.side_stream)
         loss_pen.record_stream(main_stream)
         if (self.global_step % a.save_every) == 0:
@@ -564,7 +659,12 @@ class Trainer:
             scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
             loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
         loss_G = loss_G_adv + a.lambda_cons * loss_pen
-        loss_G.backward()
+        if raw_recorded:
+            # loss_G.backward(): the generator's outputs carry no gradient, so only the critic's parameters
+            # receive one (train.py:297-299) - the recorded gradient of D(raw), negated
+            terms.add_fake_gradients(sign=-1.0)
+        else:
+            loss_G.backward()
         self.opt_G.step()
         self.last.update(loss_G=loss_G.detach(), pen=loss_pen.detach())
         self._mark("generator done")
@@ -684,6 +784,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="compute the gradient penalty by double backward (autograd) instead of its closed form")
     p.add_argument("--no-overlap", dest="no_overlap", action="store_true",
                    help="generate the critic's fakes on the main stream instead of underneath the real-side term")
+    p.add_argument("--capture-fake", choices=["auto", "on", "off"], default="auto",
+                   help="also record the critic's pass over generated minibatches (fakes, raw graphs) as a HIP graph: "
+                        "auto = for minibatches of up to 65536 nodes, where the step is bound by launch rate")
     p.add_argument("--no-sets", dest="no_sets", action="store_true",
                    help="run generator, repair and penalties graph by graph instead of once per minibatch")
     p.add_argument("--no-graph-capture", dest="graph_capture", action="store_false",

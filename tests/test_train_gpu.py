@@ -149,8 +149,49 @@ def test_recording_outgrown_by_a_deeper_minibatch_is_replaced():
         assert tr.captures == (1 if step == 0 else 2)
 
 
+def test_generated_side_deeper_than_its_recording_is_scored_eagerly_then_recorded_anew():
+    """A generated minibatch with more levels than its recording was sized for (forced here by shrinking the
+    recording's level capacity) is scored eagerly in that step - correct numbers - and the next step records
+    the generated side anew with room for it."""
+    graph = synth_aig(8, 220, 4, seed=3, window=120, orientation="forward")
+    mn, me = graph.x.size(0), graph.edge_index.size(1)
+    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "2", "--save-every", "1000",
+                                      "--capture-fake", "on"])
+    tr = Trainer(args, mn, me, DEV)
+    tr.global_step = 1
+    gs, dparams = gen_state(), omodel.init_discriminator_params(3)
+    tr.G.load_state_dict(gs)
+    tr.D.load_state_dict(dparams)
+    cpu_tr = CpuTrainer(gs, dparams, 2, mn, me)
+    g = torch.Generator().manual_seed(2)
+    key = (mn, me)
+    for step in range(4):
+        zs = [torch.randn(128, generator=g) for _ in range(2)]
+        alphas = [torch.rand(1, 1, generator=g) for _ in range(3)]
+        zi, ai = iter(zs), iter(alphas)
+        tr.draw_z = lambda: next(zi).to(DEV)
+        tr.draw_alpha = lambda: next(ai).to(DEV)
+        if step == 1:
+            tr._captured[key].plan_f.L = 5            # the fakes of this template are about 15 levels deep
+        real = Batch.from_data_list([pad_data(graph, mn, me)])
+        got = {k: float(v) for k, v in tr.step(Batch.from_data_list([pad_data(graph, mn, me)]).to(DEV)).items()}
+        ref = cpu_tr.step(real, [unpad_data(d) for d in real.to_data_list()], zs[:1], zs[1:], alphas, validate=False)
+        for k in ("D_real", "D_fake", "gp", "loss_D", "loss_G"):
+            assert rel(got[k], ref[k]) <= 1e-4, (step, k, got[k], ref[k])
+        if step == 0:
+            assert tr.captures == 1 and tr._captured[key].fake_side and not tr._fake_caps
+        elif step == 1:
+            assert tr.captures == 1 and key not in tr._captured and tr._fake_caps[key] > 10
+        else:
+            assert tr.captures == 2 and tr._captured[key].fake_cap >= tr._fake_caps[key]
+            assert not tr._captured[key].plan_f.overflowed()
+    for k, v in tr.D.state_dict().items():
+        a, b_ = v.cpu().numpy(), cpu_tr.dp[k].detach().numpy()
+        assert np.abs(a - b_).max() <= 1e-4 * max(np.abs(b_).max(), 1e-3) + 0.1 * args.lr * 12, k
+
+
 @pytest.mark.parametrize("name", ["bs1", "bs3"])
-@pytest.mark.parametrize("mode", ["hip_graph", "eager", "autograd_gp"])
+@pytest.mark.parametrize("mode", ["hip_graph", "hip_graph_eager_fakes", "eager", "autograd_gp"])
 def test_training_follows_reference_run(name, mode):
     """A whole ``train(args)`` run recorded from the reference's own train.py (tests/golden/make_golden_critic.py;
     its attention layer is the restated one): the same dataset, initial critic, draws and raw generator outputs
@@ -159,7 +200,8 @@ def test_training_follows_reference_run(name, mode):
     mn = max(g.x.size(0) for g in run.graphs)
     me = max(g.edge_index.size(1) for g in run.graphs)
     padded = [pad_data(g, mn, me) for g in run.graphs]
-    extra = {"hip_graph": [], "eager": ["--no-graph-capture"], "autograd_gp": ["--autograd-gp"]}[mode]
+    extra = {"hip_graph": [], "hip_graph_eager_fakes": ["--capture-fake", "off"], "eager": ["--no-graph-capture"],
+             "autograd_gp": ["--autograd-gp"]}[mode]
     args = build_parser().parse_args(["--dataset-dir", "unused"] + run.argv + extra)
     tr = Trainer(args, mn, me, DEV)
     tr.G.load_state_dict(gen_state())

@@ -7,7 +7,7 @@ from gan_amd.data import Batch
 from gan_amd.dataset import pad_data
 
 dev = torch.device("cuda")
-graphs, desc = bench.workload_graphs("iscas85", 0)
+graphs = bench.workload_minibatches("iscas85", 0, 1)[0][0]
 mn = max(g.x.size(0) for g in graphs); me = max(g.edge_index.size(1) for g in graphs)
 real = Batch.from_data_list([pad_data(g, mn, me) for g in graphs]).to(dev); real.sample_ids = list(range(len(graphs)))
 args = build_parser().parse_args(["--dataset-dir", "x", "--out-dir", "/tmp/o", "--candidate-k", "64", "--save-every", "1000000000"])
