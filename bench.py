@@ -173,7 +173,7 @@ def cpu_baseline(seconds_budget: float = 25.0):
 def side_workload(name: str, dev, steps: int, warmup: int):
     """A short measurement of another BASELINE.json configuration on the same GPU (rank 0, N=1 only):
     training step time, edges/s and bulk sampling rate, reported next to the main line."""
-    from gan_amd.sample import sample_many
+    from gan_amd.sample import block_size, sample_many, sample_sets
     from gan_amd.train import Trainer, build_parser
     distinct = 8
     groups, desc = workload_minibatches(name, 0, distinct)
@@ -194,17 +194,28 @@ def side_workload(name: str, dev, steps: int, warmup: int):
     dt = (time.perf_counter() - t0) / steps
     batch = batches[0]
     templates = tr.templates_of(batch)
-    draw = lambda: torch.randn(128, device=dev)   # noqa: E731
-    list(sample_many(tr.G, ((t, draw) for t in templates)))
+    # bulk sampling as gan_amd.sample runs it: per template, blocks of draws as one set of graphs each
+    S = min(block_size(int(t.x.size(0)), 64) for t in templates)
+    blocks = lambda k: (torch.randn(S, 128, device=dev) for _ in range(k))   # noqa: E731
+
+    def sample_all(k):
+        for t in templates:
+            if S > 1:
+                for _ in sample_sets(tr.G, t, blocks(k)):
+                    pass
+            else:
+                for _ in sample_many(tr.G, ((t, lambda: torch.randn(128, device=dev)) for _ in range(k))):
+                    pass
+
+    sample_all(1)
     torch.cuda.synchronize()
     s0 = time.perf_counter()
-    for _ in sample_many(tr.G, ((t, draw) for _ in range(steps) for t in templates)):
-        pass
+    sample_all(2)
     torch.cuda.synchronize()
-    nodes = sum(int(t.x.size(0)) for t in templates) * steps
+    nodes = sum(int(t.x.size(0)) for t in templates) * S * 2
     return {"workload": f"{name}: {desc}; {distinct} different minibatches in rotation", "steps": steps,
             "ms_per_step": round(dt * 1e3, 3), "edges_per_sec": round(int(edges.item()) / steps / dt, 1),
-            "recordings": tr.captures,
+            "recordings": tr.captures, "sample_block": S,
             "sample_nodes_per_sec": round(nodes / (time.perf_counter() - s0), 1)}
 
 

@@ -162,16 +162,19 @@ struct TravJobs {
     TravJob j[2];
 };
 
+// A set of graphs is walked by one block per graph (blockIdx.y; no edge leaves a graph): block (job, g)
+// owns the n nodes from g n on, ids in queues and adjacency lists stay ids of the whole set.
 template <int MODE>
 __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs) {
     const TravJob jb = jobs.j[blockIdx.x];
+    const int base = blockIdx.y * n;
     const int* __restrict__ ptr = jb.ptr;
     const int* __restrict__ adj = jb.adj;
     int* __restrict__ state = jb.state;
     int* __restrict__ depth = jb.depth;
-    int* __restrict__ q0 = jb.q0;
-    int* __restrict__ q1 = jb.q1;
-    int* __restrict__ popped = jb.popped;
+    int* __restrict__ q0 = jb.q0 + base;
+    int* __restrict__ q1 = jb.q1 + base;
+    int* __restrict__ popped = gridDim.y == 1 ? jb.popped : nullptr;
     __shared__ int s_cnt[2];
     __shared__ int s_total;
     __shared__ int s_nheavy;
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs)
     const int tid = threadIdx.x;
     if (tid == 0) { s_cnt[0] = s_cnt[1] = 0; s_total = 0; s_nheavy = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += TRAV_THREADS) {
+    for (int l = tid; l < n; l += TRAV_THREADS) {
+        const int i = base + l;
         bool start;
         if (MODE == 0) start = depth[i] == 0;
         else { start = state[i] == 0; depth[i] = start ? 0 : -1; }
@@ -250,6 +254,7 @@ __global__ void k_node_rec(int n, const int* __restrict__ ptr, const int* __rest
 }
 
 struct TravLds {
+    int base;        // first node of the block's graph: bitmap and LDS counters are indexed by v - base
     unsigned* bits;  // MODE 0: visited bitmap; MODE 1: in-degree counters, one byte per node (see lds_cnt)
     bool lds_cnt;    // MODE 1: the counters live in LDS (every in-degree <= 255 and n small enough)
     unsigned* dummy; // 64 scratch words
@@ -278,13 +283,14 @@ __device__ __forceinline__ int q_get_spill(const TravLds& t, int which, int idx)
 // cycles per level); depth[] is written by a wave of its own, see k_traverse_lds.
 template <int MODE>
 __device__ __forceinline__ void visit_lds(int v, const TravLds& t, int nx, int ncnt, int* __restrict__ state) {
+    const int l = v - t.base;
     if (MODE == 0) {
-        const unsigned m = 1u << (v & 31);
-        if (t.bits[v >> 5] & m) return;  // peek: a popular node is claimed once and then only read
-        if (atomicOr(&t.bits[v >> 5], m) & m) return;
+        const unsigned m = 1u << (l & 31);
+        if (t.bits[l >> 5] & m) return;  // peek: a popular node is claimed once and then only read
+        if (atomicOr(&t.bits[l >> 5], m) & m) return;
     } else if (t.lds_cnt) {
-        const int sh = 8 * (v & 3);
-        if (((atomicSub(&t.bits[v >> 2], 1u << sh) >> sh) & 255u) != 1u) return;
+        const int sh = 8 * (l & 3);
+        if (((atomicSub(&t.bits[l >> 2], 1u << sh) >> sh) & 255u) != 1u) return;
     } else {
         if (atomicSub(&state[v], 1) != 1) return;
     }
@@ -298,13 +304,14 @@ template <int MODE>
 __device__ __forceinline__ void visit2_lds(int self, int v0, bool on0, int v1, bool on1, const TravLds& t, int nx,
                                            int ncnt, int* __restrict__ state) {
     bool c0, c1;
+    const int l0 = v0 - t.base, l1 = v1 - t.base;
     if (MODE == 0) {
         // (an absent neighbour aims at a per-lane dummy word: same-address atomics are served one
         //  lane at a time, a shared dummy would serialise the idle lanes of every wave)
         unsigned* const dummy = t.dummy + (threadIdx.x & 63);
-        unsigned* const q0 = on0 ? &t.bits[v0 >> 5] : dummy;
-        unsigned* const q1 = on1 ? &t.bits[v1 >> 5] : dummy;
-        const unsigned m0 = on0 ? 1u << (v0 & 31) : 0u, m1 = on1 && v1 != v0 ? 1u << (v1 & 31) : 0u;
+        unsigned* const q0 = on0 ? &t.bits[l0 >> 5] : dummy;
+        unsigned* const q1 = on1 ? &t.bits[l1 >> 5] : dummy;
+        const unsigned m0 = on0 ? 1u << (l0 & 31) : 0u, m1 = on1 && v1 != v0 ? 1u << (l1 & 31) : 0u;
         const unsigned p0 = *q0, p1 = *q1;
         const unsigned a0 = m0 & ~p0, a1 = m1 & ~p1;  // still unclaimed at the peek
         const unsigned o0 = atomicOr(q0, a0), o1 = atomicOr(q1, a1);
@@ -314,9 +321,9 @@ __device__ __forceinline__ void visit2_lds(int self, int v0, bool on0, int v1, b
         // byte counters in LDS: the decrement of byte b of a word is a subtraction of 1 << 8b (a
         // counter never goes below zero, so no borrow reaches its neighbour)
         unsigned* const dummy = t.dummy + (threadIdx.x & 63);
-        const int s0 = 8 * (v0 & 3), s1 = 8 * (v1 & 3);
-        const unsigned o0 = atomicSub(on0 ? &t.bits[v0 >> 2] : dummy, on0 ? 1u << s0 : 0u);
-        const unsigned o1 = atomicSub(on1 ? &t.bits[v1 >> 2] : dummy, on1 ? 1u << s1 : 0u);
+        const int s0 = 8 * (l0 & 3), s1 = 8 * (l1 & 3);
+        const unsigned o0 = atomicSub(on0 ? &t.bits[l0 >> 2] : dummy, on0 ? 1u << s0 : 0u);
+        const unsigned o1 = atomicSub(on1 ? &t.bits[l1 >> 2] : dummy, on1 ? 1u << s1 : 0u);
         c0 = on0 && ((o0 >> s0) & 255u) == 1u;
         c1 = on1 && ((o1 >> s1) & 255u) == 1u;
     } else {
@@ -345,6 +352,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
                                                                const int4* __restrict__ rec1) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const TravJob jb = jobs.j[blockIdx.x];
+    const int base = blockIdx.y * n;   // one block per graph of a set, see k_traverse
     const int4* __restrict__ rec = blockIdx.x ? rec1 : rec0;
     const int* __restrict__ adj = jb.adj;
     int* __restrict__ state = jb.state;
@@ -358,12 +366,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
     __shared__ int s_wide;
     const int nwords = MODE == 0 ? (n + 31) >> 5 : (n <= TRAV_KAHN_LDS_MAX_N ? (n + 3) >> 2 : 0);
     TravLds t;
+    t.base = base;
     t.bits = reinterpret_cast<unsigned*>(smem);
     t.lds_cnt = false;
     t.dummy = s_dummy;
     t.lq = smem + nwords;
-    t.gq0 = jb.q0;
-    t.gq1 = jb.q1;
+    t.gq0 = jb.q0 + base;
+    t.gq1 = jb.q1 + base;
     t.cnt = s_cnt;
     if (tid == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; s_total = 0; s_nbig[0] = s_nbig[1] = 0; s_nheavy[0] = s_nheavy[1] = 0; s_wide = 0; }
     if (MODE == 0) {
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int i = 4 * w + b;
-                const int d = i < n ? state[i] : 0;
+                const int d = i < n ? state[base + i] : 0;
                 wide |= d > 255 || d < 0;
                 word |= ((unsigned)d & 255u) << (8 * b);
             }
@@ -387,12 +396,13 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
     }
     __syncthreads();
     if (MODE == 1) t.lds_cnt = nwords > 0 && s_wide == 0;
-    for (int i = tid; i < n; i += TRAV_THREADS) {
+    for (int l = tid; l < n; l += TRAV_THREADS) {
+        const int i = base + l;
         bool start;
         if (MODE == 0) start = depth[i] == 0;
         else { start = state[i] == 0; depth[i] = -1; }
         if (start) {
-            if (MODE == 0) atomicOr(&t.bits[i >> 5], 1u << (i & 31));
+            if (MODE == 0) atomicOr(&t.bits[l >> 5], 1u << (l & 31));
             q_put(t, 0, atomicAdd(&s_cnt[0], 1), i);
         }
     }
@@ -450,24 +460,27 @@ __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs j
         }
     }
     __syncthreads();
-    if (tid == 0 && jb.popped) *jb.popped = s_total;
+    if (tid == 0 && jb.popped && gridDim.y == 1) *jb.popped = s_total;
 }
 
-// rec0 / rec1: one 16-byte record per node for job 0 / job 1 (workspace of n entries each)
+// rec0 / rec1: one 16-byte record per node for job 0 / job 1 (workspace of N entries each).  The N nodes are
+// `parts` graphs of N / parts nodes: one block per job and graph (the LDS regimes go by a graph's node count).
 template <int MODE>
-int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* rec0, int4* rec1) {
+int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* rec0, int4* rec1, int parts = 1) {
+    const int total = N;
+    N = total / parts;
     if (N > TRAV_LDS_MAX_N) {
-        hipLaunchKernelGGL(k_traverse<MODE>, dim3(njobs), dim3(TRAV_THREADS), 0, s, N, jobs);
+        hipLaunchKernelGGL(k_traverse<MODE>, dim3(njobs, parts), dim3(TRAV_THREADS), 0, s, N, jobs);
         AIG_LAUNCH_CHECK();
         return AIG_OK;
     }
     AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_traverse_lds<MODE>), (size_t)((TRAV_LDS_MAX_N / 8) + 2 * TRAV_QCAP * 4)));
-    const int g = (N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096;
-    hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[0].ptr, jobs.j[0].adj, rec0);
-    if (njobs > 1) hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, N, jobs.j[1].ptr, jobs.j[1].adj, rec1);
+    const int g = (total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096;
+    hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, total, jobs.j[0].ptr, jobs.j[0].adj, rec0);
+    if (njobs > 1) hipLaunchKernelGGL(k_node_rec, dim3(g), dim3(256), 0, s, total, jobs.j[1].ptr, jobs.j[1].adj, rec1);
     const size_t lds = (MODE == 0 ? (size_t)((N + 31) >> 5) * 4 : (N <= TRAV_KAHN_LDS_MAX_N ? (size_t)((N + 3) >> 2) * 4 : 0)) +
                        (size_t)2 * TRAV_QCAP * 4;
-    hipLaunchKernelGGL(k_traverse_lds<MODE>, dim3(njobs), dim3(TRAV_THREADS), lds, s, N, jobs, rec0, rec1);
+    hipLaunchKernelGGL(k_traverse_lds<MODE>, dim3(njobs, parts), dim3(TRAV_THREADS), lds, s, N, jobs, rec0, rec1);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -917,7 +930,7 @@ int enforce(const GraphSet& gs, const float* x, const int64_t* edge_index, const
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, nullptr, depth32, q0, q1, nullptr};
-    if ((rc = run_traverse<0>(s, N, jobs, 1, rec, nullptr))) return rc;
+    if ((rc = run_traverse<0>(s, N, jobs, 1, rec, nullptr, gs.B))) return rc;
     hipLaunchKernelGGL(k_enf_depth_out, dim3(g256(N)), dim3(256), 0, s, gs, depth32, reinterpret_cast<long long*>(node_depth));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -993,7 +1006,7 @@ int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, 
     TravJobs jobs{};  // the two reachability walks are independent: one launch, one block each
     jobs.j[0] = TravJob{sptr, sadj, nullptr, fwd, q0, q1, nullptr};
     jobs.j[1] = TravJob{dptr, dadj, nullptr, rev, q2, q3, nullptr};
-    if ((rc = run_traverse<0>(s, N, jobs, 2, rec0, rec1))) return rc;
+    if ((rc = run_traverse<0>(s, N, jobs, 2, rec0, rec1, gs.B))) return rc;
     hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, gs, types, indeg, fwd, rev, counters, on_path);
     AIG_LAUNCH_CHECK();
     if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3((gs.B + 63) / 64), dim3(64), 0, s, gs, counters, pen_out);
@@ -1049,8 +1062,8 @@ int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_at
     int rc = run_csr(s, gs, 32, key, skey, ids, sid, ei, 1, sptr, adj, temp, tb);
     if (rc) return rc;
     TravJobs jobs{};
-    jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, popped};
-    if ((rc = run_traverse<1>(s, N, jobs, 1, rec, nullptr))) return rc;
+    jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, nullptr};
+    if ((rc = run_traverse<1>(s, N, jobs, 1, rec, nullptr, gs.B))) return rc;
     hipLaunchKernelGGL(k_rs_cyclic, dim3(g256(N)), dim3(256), 0, s, gs, d32, cyclic);
     hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, gs, cyclic, d32, icnt,
                        reinterpret_cast<long long*>(depth), reinterpret_cast<long long*>(inv_cnt));
