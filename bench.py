@@ -490,8 +490,6 @@ def main():
     _abi.timeline.enabled = False
     tl_proj = _abi.timeline.totals_ms()
     sample_nodes_per_sec_streams = sample_rate(in_flight)
-    # gan_amd.sample takes blocks of draws as sets of graphs while a block stays small enough for the LDS-resident
-    # walks, and single samples on several streams beyond (a 100k-node template)
     sample_nodes_per_sec = sample_rate(as_sets, S_set) if S_set > 1 else sample_nodes_per_sec_streams
 
     if rank == 0:
@@ -540,8 +538,7 @@ def main():
             "sample_nodes_per_sec_one_at_a_time": round(sample_nodes_per_sec_single, 1),
             "sample_note": f"G.forward + enforce + resync per sample (gan_amd.constraints.repair_and_resync: same tensors as "
                            "the two calls in a row, without the repair's own depth walk that the resync overwrites); "
-                           f"bulk rate as gan_amd.sample runs it (blocks of {S_set} draws per template as one set of graphs; "
-                           "1 = templates too large for that, then the streams rate), "
+                           f"bulk rate as gan_amd.sample runs it (blocks of {S_set} draws per template as one set of graphs), "
                            f"the rate with {a.sample_in_flight} independent samples in flight "
                            "on as many streams, and the rate of strictly one sample after another",
             "roofline": roof,

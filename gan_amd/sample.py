@@ -86,14 +86,13 @@ def sample_many(G: AIGGenerator, jobs: Iterable[Tuple[Data, Callable[[], torch.T
         yield finish()
 
 
-# The level-by-level walks of repair and resync take a set of graphs as one graph; up to this many nodes
-# they keep their per-node counters in LDS.  Larger sets still work, but single samples on several streams
-# (``sample_many``) are then the faster way to keep the GPU busy.
-SET_NODES = 131072
+# Scratch of a block of draws grows with draws x nodes: 2 KB of projections per node and the score matrix
+# (candidates x 4 bytes per node).  A block is capped at about a million nodes - a few gigabytes.
+SET_NODES = 1 << 20
 
 
 def block_size(n: int, batch: int) -> int:
-    """Draws per block for templates of ``n`` nodes: ``batch``, capped so that a block stays within SET_NODES."""
+    """Draws per block for templates of ``n`` nodes: ``batch``, capped by the scratch a block needs."""
     return max(1, min(int(batch), SET_NODES // max(int(n), 1)))
 
 
