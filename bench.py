@@ -13,8 +13,10 @@ all-reduced over RCCL after each critic backward.  Rank 0 prints ONE JSON line:
   sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job, in
                    blocks of draws that go through the kernels as one set of graphs (bulk sampling);
                    ..._streams keeps single samples in flight on several streams, ..._one_at_a_time is the plain loop
-  roofline         the dominant kernel (fused GAT aggregate, aig_gat_fwd): algorithmic bytes of its
-                   launches inside the timed region / their duration from stream events
+  roofline         the memory-bound kernel with the largest share of the step (the target-side pass of the GAT
+                   backward, k_gat_bwd_dst): algorithmic bytes of its eager launches inside the timed region / their
+                   duration from events the library records around the kernel itself on its launch stream;
+                   roofline_kernels lists all four memory-bound critic kernels, per graph kind (real / fake)
   cpu_baseline     the CPU checker's training step on a bounded sample, timed on this host (rank 0, N=1)
 
 Inputs are resident in HBM before the timed region starts.
@@ -81,15 +83,73 @@ def measured_peaks():
         return {}
 
 
-def pmc_traffic(workload: str):
-    """HBM bytes per launch of k_gat_aggregate on this workload from the committed PMC passes
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see profiles/pmc_traffic.json); None when not collected."""
+def pmc_traffic(workload: str, kernel: str, kind: str):
+    """Bytes per launch that left the L2 towards memory for ``kernel`` on this workload's ``kind`` of graph
+    ("real" / "fake"), from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see
+    profiles/pmc_traffic.json); None when not collected."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)[workload]["k_gat_aggregate"]["traffic_bytes_per_launch"]
+            return json.load(f)[workload]["by_kind"][kind][kernel]["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def rocprof_shares():
+    """Share of GPU time per kernel (percent) from the committed rocprofv3 summary of this bench command."""
+    import csv
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_bench_synth100k_kernel_stats.csv")
+    out = {}
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = re.sub(r"[(<].*", "", re.sub(r"^(void )?(aig::\(anonymous namespace\)::)?", "", r["Name"]))
+                out[name] = round(out.get(name, 0.0) + float(r["Percentage"]), 2)
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
+# kernels the library can time itself (aig_kernel_timing): index = its kernel id
+TIMED_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_linear128", "k_wgrad128"]
+HBM_KERNELS = TIMED_KERNELS[:4]
+# the memory-bound kernel with the largest share of the step's GPU time (profiles/r02_bench_synth100k_kernel_stats.csv):
+# the one whose launches carry events inside the timed region
+ROOFLINE_KERNEL = "k_gat_bwd_dst"
+
+
+def kernel_bytes(kernel: str, n: int, e: int, levels: int) -> int:
+    """Algorithmic bytes of one launch on a graph of n nodes, e edges (E' = e + n list entries with the self
+    loops), `levels` depth levels; every gathered row counts, whether a cache serves it or not.
+      k_gat_bwd_dst  rows g_out, out read and g_pre written (3 x 512 B per node), one gathered source row per list
+                     entry (512 B), a_s per entry and a_d per node (16 B), row pointers, source id + attribute per
+                     edge (8 B), self-loop attribute (4 B), alpha read and d_raw written per entry (16 B each),
+                     d_a_d written per node (16 B)
+      k_gat_bwd_src  one gathered g_pre row per list entry, the node's own xw row read and d_xw row written, alpha
+                     and d_raw read per entry (16 B each), d_a_d per node, column pointers, position + target per edge
+      k_pool_walk    512 B row + 12 B of plan per node, 1 KB of level table per level"""
+    ep = e + n
+    if kernel == "k_gat_aggregate":
+        return gat_fwd_bytes(n, e)
+    if kernel == "k_gat_bwd_dst":
+        return 1536 * n + 512 * ep + 16 * ep + 16 * n + 4 * (n + 1) + 8 * e + 4 * n + 32 * ep + 16 * n
+    if kernel == "k_gat_bwd_src":
+        return 512 * ep + 1024 * n + 32 * ep + 16 * n + 4 * (n + 1) + 8 * e
+    if kernel == "k_pool_walk":
+        return 524 * n + 1024 * levels
+    raise KeyError(kernel)
+
+
+def read_kernel_times(lib):
+    """{kernel: (total ms, launches)} recorded by the library's kernel timer since it was switched on."""
+    import ctypes as C
+    out = {}
+    for k, name in enumerate(TIMED_KERNELS):
+        ms, cnt = C.c_double(), C.c_int64()
+        if lib.aig_kernel_timing_read(k, C.byref(ms), C.byref(cnt)) == 0 and cnt.value:
+            out[name] = (ms.value, cnt.value)
+    return out
 
 
 def gat_fwd_bytes(n: int, e: int) -> int:
@@ -339,6 +399,8 @@ def main():
     ap.add_argument("--score-dtype", default="bf16", choices=["fp32", "bf16"], help="bulk_k256: arithmetic of the node projections")
     ap.add_argument("--sample-iters", type=int, default=10)
     ap.add_argument("--sample-in-flight", type=int, default=4)
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="leave the event brackets around the critic's memory-bound kernels out of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true",
                     help="skip the short ISCAS85-sized measurement reported next to the main line at N=1")
@@ -400,23 +462,34 @@ def main():
     # train.py keeps per dataset sample (the template and its generator plan) and the one recording of the critic
     # terms for this minibatch shape.  Then the W warm-up steps, then the K timed steps, all in rotation.
     run_steps(nb)
+    # what exists now lives as long as the run (dataset, templates, plans, recordings): taken out of the cyclic
+    # collector's sight, as gan_amd.train.train does after its first epoch's set-up - a full collection over these
+    # ~270k objects is a 100 ms stall in the middle of some step otherwise
+    import gc
+    gc.collect()
+    gc.freeze()
     run_steps(a.warmup, start=nb)
     barrier()
     _abi.timeline.reset()
-    # Only the kernel the roofline reports on is bracketed with events inside the timed region: an
-    # event pair costs queue time, and bracketing every entry point slowed the step by 10-50 %.
-    _abi.timeline.only = {"aig_gat_fwd"}
-    _abi.timeline.enabled = True
+    # Inside the timed region only the memory-bound kernels of the critic are bracketed with events - by the
+    # library itself, around the kernel alone (aig_kernel_timing) - and the sizes of the aggregate's launches are
+    # noted: bracketing every entry point slowed the step by 10-50 %.  The launches that carry events are the
+    # eager ones (the critic on the generated graphs); the replayed recordings carry none.
+    lib = _abi.lib()
+    _abi.timeline.sizes_of = {"aig_gat_fwd"}
+    lib.aig_kernel_timing((1 << TIMED_KERNELS.index(ROOFLINE_KERNEL)) if not a.no_kernel_timing else 0)
     t0 = time.perf_counter()
     edges_dev = run_steps(a.steps, start=nb + a.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
-    _abi.timeline.enabled = False
-    tl = _abi.timeline.totals_ms()
+    kt_fake = read_kernel_times(lib)
+    lib.aig_kernel_timing(0)
+    _abi.timeline.sizes_of = None
     tl_meta = dict(_abi.timeline.meta)
     recordings = trainer.captures
     # the same step count on ONE minibatch over and over (every per-object cache hot): the figure a loop that
     # never changes its input would report, kept beside the rotating one
+    run_steps(3, only=batches[0])      # (the allocator settles into the new pattern of requests first)
     barrier()
     r0 = time.perf_counter()
     run_steps(a.steps, only=batches[0])
@@ -427,8 +500,11 @@ def main():
     _abi.timeline.reset()
     _abi.timeline.only = None
     _abi.timeline.enabled = True
+    lib.aig_kernel_timing(0 if a.no_kernel_timing else 0xF)       # here all four memory-bound kernels carry events
     run_steps(inst_steps)
     barrier()
+    kt_fake_all = read_kernel_times(lib)
+    lib.aig_kernel_timing(0)
     _abi.timeline.enabled = False
     tl_all = _abi.timeline.totals_ms()
     batch = batches[0]
@@ -492,23 +568,58 @@ def main():
     sample_nodes_per_sec_streams = sample_rate(in_flight)
     sample_nodes_per_sec = sample_rate(as_sets, S_set) if S_set > 1 else sample_nodes_per_sec_streams
 
+    # the same kernels on the REAL graphs (inside the step they only run as part of the replayed recording, which
+    # carries no events): a few eager critic passes over the first minibatch, outside the timed region
+    kt_real = {}
+    if rank == 0 and not a.no_kernel_timing:
+        real0 = trainer._captured_terms(batches[0])
+        if real0 is not None:
+            real0.load(batches[0])
+            lib.aig_kernel_timing(0xF)
+            for _ in range(5):
+                trainer.D.zero_grad()
+                trainer.D(real0.real_for_D).sum().backward()
+            torch.cuda.synchronize()
+            kt_real = read_kernel_times(lib)
+            lib.aig_kernel_timing(0)
+            trainer.D.zero_grad()
+
     if rank == 0:
-        ms_fwd, launches = tl.get("aig_gat_fwd", (0.0, 0))
-        total_bytes = sum(gat_fwd_bytes(n, e) for (n, e) in tl_meta.get("aig_gat_fwd", []))
-        roof = None
-        if launches:
-            achieved = total_bytes / (ms_fwd * 1e-3) / 1e9
-            roof = {"kernel": "k_gat_aggregate (entry point aig_gat_fwd)", "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload),
-                    "launches": launches, "avg_launch_us": round(ms_fwd * 1e3 / launches, 2),
-                    "algorithmic_bytes_per_launch_avg": int(total_bytes / launches)}
-            peaks = measured_peaks()
-            if roof["traffic"] and peaks.get("hbm_read_GBs"):
-                # HBM-side view: bytes that actually crossed the memory interface (PMC) per second of kernel time,
-                # against the read bandwidth a plain streaming kernel reaches on this GPU (tools/peaks.hip)
-                hbm_side = roof["traffic"] / (ms_fwd * 1e-3 / launches) / 1e9
-                roof.update({"traffic_GBs": round(hbm_side, 1), "peak_measured": peaks["hbm_read_GBs"],
-                             "traffic_frac_of_measured": round(hbm_side / peaks["hbm_read_GBs"], 4)})
+        sizes = tl_meta.get("aig_gat_fwd", [])
+        n_avg = sum(n for n, _ in sizes) / max(len(sizes), 1)
+        e_avg = sum(e for _, e in sizes) / max(len(sizes), 1)
+        peaks = measured_peaks()
+        shares = rocprof_shares()
+
+        def kernel_line(kernel, kind, times, where):
+            ms, launches = times[kernel]
+            us = ms * 1e3 / launches
+            bytes_alg = kernel_bytes(kernel, int(n_avg), int(e_avg), top + 1)
+            achieved = bytes_alg / (us * 1e-6) / 1e9
+            line = {"kernel": kernel, "graph_kind": kind, "measured": where, "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic(a.workload, kernel, kind), "launches": launches, "avg_launch_us": round(us, 2),
+                    "algorithmic_bytes_per_launch": bytes_alg, "rocprof_share_of_gpu_time_pct": shares.get(kernel)}
+            if line["traffic"] and peaks.get("hbm_read_GBs"):
+                # memory-side view: bytes that left the L2 (counters) per second of kernel time, against the read
+                # bandwidth a plain streaming kernel reaches on this GPU (tools/peaks.hip)
+                side = line["traffic"] / (us * 1e-6) / 1e9
+                line.update({"traffic_GBs": round(side, 1), "peak_measured": peaks["hbm_read_GBs"],
+                             "traffic_frac_of_measured": round(side / peaks["hbm_read_GBs"], 4)})
+            return line
+
+        roof_all = []
+        if sizes:
+            roof_all += [kernel_line(k, "fake", kt_fake, "events around the kernel, eager launches inside the timed region")
+                         for k in HBM_KERNELS if k in kt_fake]
+            roof_all += [kernel_line(k, "fake", kt_fake_all, f"events around the kernel, eager launches of {inst_steps} extra "
+                                     "instrumented steps outside the timed region")
+                         for k in HBM_KERNELS if k in kt_fake_all and k not in kt_fake]
+            roof_all += [kernel_line(k, "real", kt_real, "events around the kernel, 5 eager critic passes outside the timed region")
+                         for k in HBM_KERNELS if k in kt_real]
+        # the headline entry: the memory-bound kernel with the largest share of the step's GPU time
+        in_region = [r for r in roof_all if r["graph_kind"] == "fake" and r["kernel"] == ROOFLINE_KERNEL and r["kernel"] in kt_fake]
+        roof = in_region[0] if in_region else None
         # the dense contraction of the path: node projections of the generator (7 products of
         # [n,128]x[128,128] per sample) on the f32 matrix cores, flops executed / event time
         mfma = None
@@ -542,6 +653,10 @@ def main():
                            f"the rate with {a.sample_in_flight} independent samples in flight "
                            "on as many streams, and the rate of strictly one sample after another",
             "roofline": roof,
+            "roofline_kernels": roof_all,
+            "roofline_note": "bytes of the gathers count once per list entry in `achieved` (algorithmic), so a graph whose edges "
+                             "hang on a few sources - what the untrained generator wires, kind 'fake' - is served by the caches and "
+                             "can exceed what the memory delivers; `traffic` is what left the L2 (counter passes, per kind)",
             "roofline_mfma": mfma,
             "timeline_ms_per_step": {k: round(v[0] / inst_steps, 3) for k, v in sorted(tl_all.items())},
             "timeline_note": f"GPU ms per step by entry point, from {inst_steps} extra instrumented steps outside the timed region "

@@ -87,6 +87,9 @@ SIGNATURES = {
     "aig_validate": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
     "aig_resync_ws_bytes": (SZ, [I64, I64]),
     "aig_resync": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
+    "aig_kernel_timing": (INT, [C.c_uint]),
+    "aig_kernel_timing_read": (INT, [INT, P, P]),
+    "aig_kernel_timing_name": (C.c_char_p, [INT]),
     "aig_gen_batch_rows": (I64, [I64]),
     "aig_gen_node_proj_batch_ws_bytes": (SZ, [I64, I64, INT]),
     "aig_gen_node_proj_batch": (INT, [I64, I64, P, INT, P, P, INT, P, P, SZ, P]),
@@ -130,6 +133,7 @@ class _Timeline:
         self.events = {}
         self.meta = {}
         self.only = None
+        self.sizes_of = None     # names whose problem sizes (``meta``) are noted without any event
 
     def reset(self):
         self.events = {}
@@ -148,6 +152,9 @@ def timed(name: str, fn, *args, meta=None):
     (the stream the kernels are enqueued on) and remember ``meta`` (problem sizes) per launch.
     ``timeline.only`` (a set of names, or None) restricts the bracketing: an event pair costs tens
     of microseconds of queue time, so a timed run keeps only the entry point it reports on."""
+    if timeline.sizes_of is not None and name in timeline.sizes_of and meta is not None:
+        timeline.meta.setdefault(name, []).append(meta)
+        return fn(*args)
     if not timeline.enabled or (timeline.only is not None and name not in timeline.only):
         return fn(*args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -62,6 +62,20 @@ hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s);
 // (a kernel attribute belongs to the device's copy of the code object); safe to call from several threads.
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
+// Per-kernel GPU time for the benchmark (aig_kernel_timing in the header): while switched on, a launch wrapped
+// in a KernelTimed is bracketed by two events on its stream (not while that stream is being recorded into a
+// graph).  Off, the wrapper is one load and a branch.
+struct KernelTimed {
+    KernelTimed(int kernel, hipStream_t s);
+    ~KernelTimed();
+    KernelTimed(const KernelTimed&) = delete;
+    KernelTimed& operator=(const KernelTimed&) = delete;
+
+private:
+    hipStream_t stream_;
+    hipEvent_t stop_ = nullptr;
+};
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not

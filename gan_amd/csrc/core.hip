@@ -56,8 +56,77 @@ hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- per-kernel timing (benchmark aid)
+namespace {
+struct TimedLaunch { hipEvent_t start, stop; };
+std::mutex g_kt_mutex;
+volatile unsigned g_kt_mask = 0u;   // bit k: kernel k is being timed
+std::vector<TimedLaunch> g_kt[AIG_KT_COUNT];
+const char* const g_kt_names[AIG_KT_COUNT] = {"k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk",
+                                              "k_linear128", "k_wgrad128"};
+
+std::vector<hipEvent_t> g_kt_free;   // events of forgotten records, handed out again
+
+void kt_clear() {
+    for (auto& v : g_kt) {
+        for (TimedLaunch& t : v) { g_kt_free.push_back(t.start); g_kt_free.push_back(t.stop); }
+        v.clear();
+    }
+}
+
+bool kt_event(hipEvent_t* e) {   // under g_kt_mutex
+    if (!g_kt_free.empty()) { *e = g_kt_free.back(); g_kt_free.pop_back(); return true; }
+    return hipEventCreate(e) == hipSuccess;
+}
+}  // namespace
+
+KernelTimed::KernelTimed(int kernel, hipStream_t s) : stream_(s) {
+    if (kernel < 0 || kernel >= AIG_KT_COUNT || !(g_kt_mask >> kernel & 1u)) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    TimedLaunch t{};
+    {
+        std::lock_guard<std::mutex> lock(g_kt_mutex);
+        if (!kt_event(&t.start)) return;
+        if (!kt_event(&t.stop)) { g_kt_free.push_back(t.start); return; }
+        g_kt[kernel].push_back(t);
+    }
+    (void)hipEventRecord(t.start, s);
+    stop_ = t.stop;
+}
+
+KernelTimed::~KernelTimed() {
+    if (stop_) (void)hipEventRecord(stop_, stream_);
+}
+
 }  // namespace aig
 
-extern "C" int aig_abi_version(void) { return 2; }
+extern "C" int aig_kernel_timing(unsigned kernel_mask) {
+    std::lock_guard<std::mutex> lock(aig::g_kt_mutex);
+    if (kernel_mask && !aig::g_kt_mask) aig::kt_clear();
+    aig::g_kt_mask = kernel_mask;
+    return AIG_OK;
+}
+
+extern "C" const char* aig_kernel_timing_name(int kernel) {
+    return kernel >= 0 && kernel < AIG_KT_COUNT ? aig::g_kt_names[kernel] : nullptr;
+}
+
+extern "C" int aig_kernel_timing_read(int kernel, double* total_ms, int64_t* launches) {
+    AIG_REQUIRE(kernel >= 0 && kernel < AIG_KT_COUNT && total_ms && launches, "aig_kernel_timing_read: bad argument");
+    std::lock_guard<std::mutex> lock(aig::g_kt_mutex);
+    double ms = 0.0;
+    for (aig::TimedLaunch& t : aig::g_kt[kernel]) {
+        AIG_HIP_CHECK(hipEventSynchronize(t.stop));
+        float one = 0.f;
+        AIG_HIP_CHECK(hipEventElapsedTime(&one, t.start, t.stop));
+        ms += one;
+    }
+    *total_ms = ms;
+    *launches = (int64_t)aig::g_kt[kernel].size();
+    return AIG_OK;
+}
+
+extern "C" int aig_abi_version(void) { return 3; }
 
 extern "C" const char* aig_last_error(void) { return aig::err_buf(); }

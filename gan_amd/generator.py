@@ -203,6 +203,12 @@ class AIGGenerator(nn.Module):
         n = plans[0].n
         if any(p.n != n for p in plans):
             raise ValueError("forward_set needs templates of one node count")
+        if len(plans) == 1:     # nothing to stack: the plan's own tensors
+            st = {"plans": plans, "n": n, "E": [plans[0].E], "x": xs[0]}
+            for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
+                st[name] = getattr(plans[0], name)
+            st["nd"] = nds[0] if nds[0] is not None and nds[0].numel() == n else None
+            return st
         st = {"plans": plans, "n": n, "E": [p.E for p in plans], "x": torch.cat(xs).contiguous()}
         for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
             st[name] = torch.stack([getattr(p, name) for p in plans]).contiguous()

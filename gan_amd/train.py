@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import argparse
 import csv
+import gc
 import os
 import time
 import traceback
@@ -749,6 +750,13 @@ def train(args) -> None:
             logger.flush_csv()
             logger.plot_all()
             print(f"[INFO] saved checkpoints & metrics epoch {epoch}")
+        if epoch == 0:
+            # Everything alive after the first epoch lives as long as the run: the dataset, the per-sample
+            # templates and generator plans, the recorded critic terms.  They are taken out of the cyclic collector's
+            # sight; otherwise a full collection walks a few hundred thousand objects - a stall of ~100 ms in
+            # the middle of a step - whenever enough short-lived containers have come and gone.
+            gc.collect()
+            gc.freeze()
     if rank == 0:
         print("[INFO] training finished")
 

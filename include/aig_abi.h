@@ -354,6 +354,26 @@ size_t aig_resync_ws_bytes(int64_t n, int64_t E);
 int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
                int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- per-kernel GPU time (a measurement aid; no counterpart in the reference) --------------------------
+ * aig_kernel_timing(mask) selects the kernels to time (bit k = kernel k of the list below, 0 = none, the
+ * initial state); going from none to some forgets earlier records.  Every launch of a selected kernel is
+ * bracketed by two HIP events on the stream it is launched on (launches that are being recorded into a HIP
+ * graph are left alone).  aig_kernel_timing_read waits for the recorded launches of one kernel and returns
+ * their summed duration and their number.  Two event records per launch: for benchmarks, not for
+ * production runs. */
+enum {
+    AIG_KT_GAT_AGGREGATE = 0, /* aig_gat_fwd */
+    AIG_KT_GAT_BWD_DST,       /* aig_gat_bwd: target-side pass */
+    AIG_KT_GAT_BWD_SRC,       /* aig_gat_bwd: source-side pass */
+    AIG_KT_POOL_WALK,         /* aig_level_pool_fwd: the walk over the nodes */
+    AIG_KT_LINEAR128,         /* aig_linear128 */
+    AIG_KT_WGRAD128,          /* aig_wgrad with 128 input columns */
+    AIG_KT_COUNT
+};
+int aig_kernel_timing(unsigned kernel_mask);
+int aig_kernel_timing_read(int kernel, double* total_ms, int64_t* launches);
+const char* aig_kernel_timing_name(int kernel);
+
 /* ---- sets of graphs -----------------------------------------------------------------------------------
  * The reference repairs, scores and resyncs the graphs of a minibatch (train.py:242-245,287) and the samples
  * of a bulk run (AIGgan.py:104-110) one after another.  These entry points take B graphs of n nodes each in
