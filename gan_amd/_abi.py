@@ -96,6 +96,7 @@ SIGNATURES = {
     "aig_gen_wire_batch": (INT, [P, P]),
     "aig_enforce_batch_ws_bytes": (SZ, [I64, I64, I64]),
     "aig_enforce_batch": (INT, [I64, I64, I64, P, P, P, P, INT, P, I64, P, I64, P, P, P, P, P, SZ, P]),
+    "aig_clean_depth_batch": (INT, [I64, I64, I64, P, P, P, P, P, SZ, P]),
     "aig_penalties_batch_ws_bytes": (SZ, [I64, I64, I64]),
     "aig_penalties_batch": (INT, [I64, I64, I64, P, P, P, P, P, SZ, P]),
     "aig_resync_batch_ws_bytes": (SZ, [I64, I64, I64]),

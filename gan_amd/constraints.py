@@ -292,6 +292,20 @@ def enforce_set(gs: GraphSet, want_depth: bool = True) -> GraphSet:
     return GraphSet(B, n, cap, x_out, out_ei, out_ea, out_cnt, node_depth, x_dtype=gs.x_dtype)
 
 
+def clean_depth_set(gs: GraphSet) -> torch.Tensor:
+    """The ``node_depth`` that ``enforce_set(gs)`` reports, by itself: for a caller that repairs with
+    ``want_depth=False``, hands the repaired edges on at once and fills the levels in afterwards."""
+    lib = _abi.lib()
+    _need_gpu(gs.x, "clean_depth_set")
+    dev = gs.x.device
+    depth = torch.empty(gs.B * gs.n, dtype=torch.int64, device=dev)
+    ws = _abi.workspace(lib.aig_enforce_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
+    _abi.check(_abi.timed("aig_clean_depth_batch", lib.aig_clean_depth_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
+                          _abi.ptr(gs.x), _abi.ptr(gs.edge_index), _abi.ptr(depth), _abi.ptr(ws), ws.numel(), _abi.stream()),
+               "aig_clean_depth_batch")
+    return depth
+
+
 def penalties_set(gs: GraphSet) -> torch.Tensor:
     """``aig_constraint_penalties`` (default weights) of every graph: float32 ``[B, 9]`` in the order of
     ``PENALTY_KEYS`` + total, on the device."""

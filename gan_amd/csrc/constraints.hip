@@ -936,6 +936,49 @@ int enforce(const GraphSet& gs, const float* x, const int64_t* edge_index, const
     return AIG_OK;
 }
 
+// The repair's breadth-first levels alone (the walk the repair ends with, for callers that take the repaired
+// edges first and the levels later): levels from the PIs over the cleaned edges of the INPUT graph.
+int clean_depth(const GraphSet& gs, const float* x, const int64_t* edge_index, int64_t* node_depth, void* ws,
+                size_t ws_bytes, void* stream, const char* who) {
+    AIG_REQUIRE(x && edge_index && node_depth && ws, "%s: null pointer", who);
+    if (ws_bytes < enforce_ws(gs.B, gs.n, gs.ecap))
+        return fail(AIG_EWORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, enforce_ws(gs.B, gs.n, gs.ecap));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N = gs.N(), M = gs.M();
+    Carver c(ws);
+    Cnt4* flags = c.take<Cnt4>(N + 1);
+    Cnt4* scan = c.take<Cnt4>(N + 1);
+    int* types = c.take<int>(N + 2);
+    int* pos = c.take<int>(N + 2);
+    int* sptr = c.take<int>(N + 2);
+    int* depth32 = c.take<int>(N + 2);
+    unsigned long long* key64 = c.take<unsigned long long>(M);
+    unsigned* key_src = c.take<unsigned>(M);
+    unsigned* skey_src = c.take<unsigned>(M);
+    int* ids = c.take<int>(M);
+    int* sid = c.take<int>(M);
+    int* adj = c.take<int>(M);
+    int4* rec = c.take<int4>(N + 2);
+    const Temps t = temps_for(N, M);
+    size_t tb = t.bytes;
+    void* temp = c.take<char>(tb);
+    const long long* ei = reinterpret_cast<const long long*>(edge_index);
+    int rc = run_types_pos(s, gs, x, types, pos, nullptr, flags, scan, temp, tb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_enf_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, key64, key_src, ids);
+    AIG_LAUNCH_CHECK();
+    if ((rc = run_csr(s, gs, 32, key_src, skey_src, ids, sid, ei, 1, sptr, adj, temp, tb))) return rc;
+    int* q0 = reinterpret_cast<int*>(flags);  // (N+1)*16 bytes each: room for N ints
+    int* q1 = reinterpret_cast<int*>(scan);
+    hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
+    TravJobs jobs{};
+    jobs.j[0] = TravJob{sptr, adj, nullptr, depth32, q0, q1, nullptr};
+    if ((rc = run_traverse<0>(s, N, jobs, 1, rec, nullptr, gs.B))) return rc;
+    hipLaunchKernelGGL(k_enf_depth_out, dim3(g256(N)), dim3(256), 0, s, gs, depth32, reinterpret_cast<long long*>(node_depth));
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
 size_t graph_checks_ws(int64_t B, int64_t n, int64_t ecap) {
     const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
     const Temps t = temps_for((int64_t)N, (int64_t)M);
@@ -1125,6 +1168,15 @@ extern "C" int aig_enforce_batch(int64_t B, int64_t n, int64_t ecap, const int32
     const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
     return enforce(gs, x, edge_index, edge_attr, depth_kind, depth, depth_stride, out_edge_index, cap, out_edge_attr,
                    out_count, node_depth, x_out, ws, ws_bytes, stream, "aig_enforce_batch");
+}
+
+extern "C" int aig_clean_depth_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                                     const int64_t* edge_index, int64_t* node_depth, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    int rc = check_set("aig_clean_depth_batch", B, n, ecap);
+    if (rc) return rc;
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    return clean_depth(gs, x, edge_index, node_depth, ws, ws_bytes, stream, "aig_clean_depth_batch");
 }
 
 // ============================================================================================ penalties / validate

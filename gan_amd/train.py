@@ -42,8 +42,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import parallel
-from .constraints import (aig_constraint_penalties, enforce_aig_constraints, enforce_begin, enforce_finish,
-                          enforce_set, pad_set, penalties_set, validate_strict_aig)
+from .constraints import (aig_constraint_penalties, clean_depth_set, enforce_aig_constraints, enforce_begin,
+                          enforce_finish, enforce_set, pad_set, penalties_set, validate_strict_aig)
 from .data import Batch, Data, GraphLoader
 from .graphset import GraphSet
 from .dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
@@ -539,9 +539,22 @@ class Trainer:
                 terms.replay_real()       # the first iteration's real-side term: one launch, then the
                 real_replayed = True      # host goes on to enqueue the fakes next to it
             as_set = self._as_set(templates)
+            # The penalty term needs the fakes' node features, the critic's pass over the fakes their edges and
+            # levels.  The levels come out of a level-by-level walk (one workgroup per graph, most of a millisecond
+            # on a large graph): when the fakes are made on their own stream, the repair hands over features and
+            # edges first and the walk follows, so that the main stream can go on to the penalty term meanwhile.
+            split = as_set and fakes_stream is not main_stream and not terms.fake_side
+            deferred_wait = False
             with torch.cuda.stream(fakes_stream):
                 zs_once = [self.draw_z() for _ in templates]
-                if as_set:
+                if split:
+                    raw_fakes_set = G.forward_set(templates, torch.stack(zs_once))
+                    corr_set = enforce_set(raw_fakes_set, want_depth=False)
+                    features_ready = torch.cuda.Event()
+                    features_ready.record()
+                    corr_set.node_depth = clean_depth_set(raw_fakes_set)
+                    fake_padded = self._pad_set(corr_set)
+                elif as_set:
                     # generator, repair and padding for the whole minibatch: a dozen launches, no host read
                     fake_padded = self._pad_set(enforce_set(G.forward_set(templates, torch.stack(zs_once))))
                 else:
@@ -552,12 +565,17 @@ class Trainer:
                     fake_padded = self._pad_batch(corr_fakes_once)
                 fake_for_D = fake_padded
                 edges_fake = count_edges(fake_padded.edge_index)
-            main_stream.wait_stream(fakes_stream)
-            self._mark("fakes ready")
-            self._edges_last = edges_fake + edges_real
             fake_recorded = False
+            if split:
+                main_stream.wait_event(features_ready)
+                terms.x_fake.copy_(corr_set.x)      # all the penalty term reads of the fakes
+                deferred_wait = True                # the rest is awaited right before the critic's pass over them
+            else:
+                main_stream.wait_stream(fakes_stream)
+                self._mark("fakes ready")
             if terms is not None:
-                fake_recorded = terms.load_generated(fake_padded)
+                if not split:
+                    fake_recorded = terms.load_generated(fake_padded)
                 if terms.fake_side and not fake_recorded:
                     # deeper than the recording holds: this step scores its fakes eagerly, the next one records anew
                     key = (terms.n, terms.e_cols)
@@ -582,6 +600,10 @@ class Trainer:
                         if not (it == 0 and real_replayed):
                             terms.replay_real()
                         terms.replay_gp(self.draw_alpha())
+                        if deferred_wait:
+                            main_stream.wait_stream(fakes_stream)
+                            deferred_wait = False
+                            self._mark("fakes ready")
                         if fake_recorded:
                             main_stream.wait_stream(self.side_stream)
                             if it == a.n_critic - 1:      # (the buffer is written again by the generator step)
@@ -622,6 +644,7 @@ class Trainer:
                 self.opt_D.step()
         if failed is not None:
             raise failed
+        self._edges_last = edges_fake + edges_real
 
         # ---- generator (train.py:275-299); its output carries no gradient, so backward only touches D
         self._mark("critic done")
@@ -652,6 +675,10 @@ class Trainer:
             if terms is not None:
                 raw_batch_for_D._plan = terms.plan
             loss_G_adv = -mean_score(D, raw_batch_for_D)
+            # loss_G.backward() before the penalties are awaited: they carry no gradient (the generator's outputs
+            # are integers and copies), so the gradient of loss_G is the gradient of its adversarial term, and
+            # the penalties' level walks run underneath the backward pass as well
+            loss_G_adv.backward()
         main_stream.wait_stream(self.side_stream)
         loss_pen.record_stream(main_stream)
         if (self.global_step % a.save_every) == 0:
@@ -659,13 +686,11 @@ class Trainer:
                 raw_gen = raw_set.graphs()
             scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
             loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
-        loss_G = loss_G_adv + a.lambda_cons * loss_pen
+        loss_G = loss_G_adv.detach() + a.lambda_cons * loss_pen
         if raw_recorded:
-            # loss_G.backward(): the generator's outputs carry no gradient, so only the critic's parameters
-            # receive one (train.py:297-299) - the recorded gradient of D(raw), negated
+            # loss_G.backward(): only the critic's parameters receive a gradient (train.py:297-299) - the
+            # recorded gradient of D(raw), negated
             terms.add_fake_gradients(sign=-1.0)
-        else:
-            loss_G.backward()
         self.opt_G.step()
         self.last.update(loss_G=loss_G.detach(), pen=loss_pen.detach())
         self._mark("generator done")

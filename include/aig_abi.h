@@ -424,6 +424,12 @@ int aig_enforce_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount,
                       int64_t depth_stride, int64_t* out_edge_index, int64_t cap, int64_t* out_edge_attr,
                       int32_t* out_count, int64_t* node_depth, float* x_out, void* ws, size_t ws_bytes, void* stream);
 
+/* The node_depth output of aig_enforce_batch alone (breadth-first levels from the PIs over the cleaned edges of
+ * the INPUT graphs, constraints.py:88-112,640-642), for callers that pass node_depth = NULL to the repair, use the
+ * repaired edges at once and need the levels later.  Workspace: aig_enforce_batch_ws_bytes(B, n, ecap). */
+int aig_clean_depth_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                          const int64_t* edge_index, int64_t* node_depth, void* ws, size_t ws_bytes, void* stream);
+
 /* aig_penalties on B graphs: out9 [B][9]. */
 size_t aig_penalties_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
 int aig_penalties_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,

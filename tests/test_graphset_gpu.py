@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from gan_amd.constraints import (aig_constraint_penalties, enforce_aig_constraints, enforce_set, pad_set,
+from gan_amd.constraints import (aig_constraint_penalties, clean_depth_set, enforce_aig_constraints, enforce_set, pad_set,
                                  penalties_set, repair_and_resync, repair_and_resync_set, resync_attrs, resync_set)
 from gan_amd.data import Batch, Data
 from gan_amd.dataset import pad_data
@@ -58,6 +58,10 @@ def test_every_graph_of_a_set_matches_its_single_graph_result(n, depth_mode):
     for g, ref in enumerate(singles):
         assert_same_graph(fixed.graph(g), ref)
     assert fixed.counts() == [int(r.edge_index.size(1)) for r in singles]
+    # the repair without its level walk, and the walk by itself afterwards (how the training step hands fakes over)
+    late = enforce_set(gset, want_depth=False)
+    assert late.node_depth is None and torch.equal(late.x, fixed.x) and late.counts() == fixed.counts()
+    assert torch.equal(clean_depth_set(gset), fixed.node_depth)
     pen_fixed = penalties_set(fixed).cpu().numpy()
     for g, ref in enumerate(singles):
         assert float(pen_fixed[g, 8]) == float(aig_constraint_penalties(ref.clone())["total"])
