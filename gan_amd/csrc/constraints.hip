@@ -843,8 +843,10 @@ Temps temps_for(int64_t N, int64_t M) {
     const unsigned long long n = (unsigned long long)(N > 0 ? N : 1);
     t.kb = bits_for(n * n + n);
     t.nb = bits_for(n);
-    const size_t t64 = sort_temp<unsigned long long>(M, t.kb), t32 = sort_temp<unsigned>(M, 32), ts = scan_temp(N + 2);
+    const size_t t64 = sort_temp<unsigned long long>(M, t.kb), t32 = sort_temp<unsigned>(M, 32),
+                 tnb = sort_temp<unsigned>(M, t.nb), ts = scan_temp(N + 2);
     t.bytes = t64 > t32 ? t64 : t32;
+    t.bytes = t.bytes > tnb ? t.bytes : tnb;
     t.bytes = t.bytes > ts ? t.bytes : ts;
     return t;
 }
@@ -922,7 +924,7 @@ int enforce(const GraphSet& gs, const float* x, const int64_t* edge_index, const
     AIG_LAUNCH_CHECK();
     if (!node_depth) return AIG_OK;  // the caller recomputes the depths anyway (sampling: resync follows)
     // node_depth: breadth-first level from the PIs over the cleaned (pre-repair) edges
-    rc = run_csr(s, gs, 32, key_src, skey_src, ids, sid, ei, 1, sptr, adj, temp, tb);
+    rc = run_csr(s, gs, t.nb, key_src, skey_src, ids, sid, ei, 1, sptr, adj, temp, tb);
     if (rc) return rc;
     int* depth32 = pick_cnt;  // free again
     int* q0 = reinterpret_cast<int*>(flags);  // (N+1)*16 bytes each: room for N ints
@@ -967,7 +969,7 @@ int clean_depth(const GraphSet& gs, const float* x, const int64_t* edge_index, i
     if (rc) return rc;
     hipLaunchKernelGGL(k_enf_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, key64, key_src, ids);
     AIG_LAUNCH_CHECK();
-    if ((rc = run_csr(s, gs, 32, key_src, skey_src, ids, sid, ei, 1, sptr, adj, temp, tb))) return rc;
+    if ((rc = run_csr(s, gs, t.nb, key_src, skey_src, ids, sid, ei, 1, sptr, adj, temp, tb))) return rc;
     int* q0 = reinterpret_cast<int*>(flags);  // (N+1)*16 bytes each: room for N ints
     int* q1 = reinterpret_cast<int*>(scan);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, depth32);
@@ -1041,8 +1043,8 @@ int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, 
     hipLaunchKernelGGL(k_pen_dups, dim3(g256(M)), dim3(256), 0, s, gs, skey64, sid, counters, eflag);
     AIG_LAUNCH_CHECK();
     // forward reachability from the PIs, backward from the POs
-    if ((rc = run_csr(s, gs, 32, key_src, skey32, ids, sid, ei, 1, sptr, sadj, temp, tb))) return rc;
-    if ((rc = run_csr(s, gs, 32, key_dst, skey32, ids, sid, ei, 0, dptr, dadj, temp, tb))) return rc;
+    if ((rc = run_csr(s, gs, t.nb, key_src, skey32, ids, sid, ei, 1, sptr, sadj, temp, tb))) return rc;
+    if ((rc = run_csr(s, gs, t.nb, key_dst, skey32, ids, sid, ei, 0, dptr, dadj, temp, tb))) return rc;
     int* q0 = reinterpret_cast<int*>(flags);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, fwd);
     hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PO_T, rev);
@@ -1068,8 +1070,9 @@ int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, 
 
 size_t resync_ws(int64_t B, int64_t n, int64_t ecap) {
     const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
+    const size_t t32 = sort_temp<unsigned>((int64_t)M, 32), tnb = sort_temp<unsigned>((int64_t)M, bits_for(N));
     return 7 * align_up((N + 2) * 4) + 5 * align_up(M * 4) + align_up((N + 2) * 16) + align_up((size_t)(B + 16) * 4) +
-           align_up(sort_temp<unsigned>((int64_t)M, 32)) + 1024;
+           align_up(t32 > tnb ? t32 : tnb) + 1024;
 }
 
 int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth,
@@ -1094,6 +1097,10 @@ int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_at
     int4* rec = c.take<int4>(N + 2);
     int* cyclic = c.take<int>(gs.B + 16);
     size_t tb = sort_temp<unsigned>(M, 32);
+    {
+        const size_t tnb = sort_temp<unsigned>(M, bits_for((unsigned long long)N));
+        if (tnb > tb) tb = tnb;
+    }
     void* temp = c.take<char>(tb);
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     AIG_HIP_CHECK(fill_words(icnt, 0u, (size_t)(N + 2) * 4, s));
@@ -1102,7 +1109,7 @@ int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_at
     hipLaunchKernelGGL(k_rs_edges, dim3(g256(M)), dim3(256), 0, s, gs, ei, reinterpret_cast<const long long*>(edge_attr),
                        icnt, indeg, key, ids);
     AIG_LAUNCH_CHECK();
-    int rc = run_csr(s, gs, 32, key, skey, ids, sid, ei, 1, sptr, adj, temp, tb);
+    int rc = run_csr(s, gs, bits_for((unsigned long long)N), key, skey, ids, sid, ei, 1, sptr, adj, temp, tb);
     if (rc) return rc;
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, nullptr};

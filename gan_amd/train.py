@@ -31,6 +31,7 @@ What differs, on purpose:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import csv
 import gc
 import os
@@ -196,6 +197,17 @@ def depth_top(batch: Data) -> int:
     return top
 
 
+@contextlib.contextmanager
+def _no_cyclic_gc():
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_on:
+            gc.enable()
+
+
 class CapturedCriticTerms:
     """``-mean(D(real))`` and ``gp_lambda * GP`` with their gradients w.r.t. the critic's parameters,
     recorded ONCE PER MINIBATCH SHAPE as HIP graphs and replayed for every minibatch of that shape.
@@ -284,23 +296,33 @@ class CapturedCriticTerms:
                     compute_fake()
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
-        # thread-local capture: a communicator's watchdog thread may query events while we record
+        # thread-local capture: a communicator's watchdog thread may query events while we record.  The cyclic
+        # collector is held off while a recording is open: it can run in any thread at any allocation (the
+        # autograd worker's included), and a collected object that owns device resources - an earlier recording,
+        # say - would release them in the middle of the capture, which the runtime answers with an abort.
         self.graph_real = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_real, capture_error_mode="thread_local"):
+        with _no_cyclic_gc(), torch.cuda.graph(self.graph_real, capture_error_mode="thread_local"):
             self.d_real, grads_real = compute_real()
         self._grads_real = self._present(grads_real)
         self.graph_gp = None
         if closed_form_gp:
             self.graph_gp = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
+            with _no_cyclic_gc(), torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
                 self.gp, self.grad_norm, grads_gp = compute_gp()
             self._grads_gp = self._present(grads_gp)
         self.graph_fake = None
         if self.fake_side:
             self.graph_fake = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_fake, capture_error_mode="thread_local"):
+            with _no_cyclic_gc(), torch.cuda.graph(self.graph_fake, capture_error_mode="thread_local"):
                 self.d_fake, grads_fake = compute_fake()
             self._grads_fake = self._present(grads_fake)
+
+    def release(self) -> None:
+        """Drop the recordings and what refers back to this object now (called when a recording is replaced),
+        instead of whenever the cyclic collector gets to it."""
+        self.graph_real = self.graph_gp = self.graph_fake = None
+        self._compute_gp = None
+        self._grads_real = self._grads_gp = self._grads_fake = ([], [])
 
     def _present(self, grads):
         """(parameters, gradients) of the parameters a term reaches."""
@@ -476,7 +498,9 @@ class Trainer:
             return terms
         top = max(depth_top(real_padded), 0)
         cap = max(self.level_cap, 2 * top, 64)
-        self._captured.pop(key, None)
+        old = self._captured.pop(key, None)
+        if old is not None:
+            old.release()
         # the generated side is recorded as well when the minibatch is small enough for the step to be bound by
         # launch rate (an eager critic pass over it costs the host more than the GPU)
         fake_side = self.capture_fake == "on" or (self.capture_fake == "auto" and key[0] <= 65536)
@@ -486,7 +510,7 @@ class Trainer:
         self.captures += 1
         self._captured[key] = terms
         if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
-            self._captured.popitem(last=False)
+            self._captured.popitem(last=False)[1].release()
         return terms
 
     @property
@@ -581,9 +605,10 @@ class Trainer:
                     key = (terms.n, terms.e_cols)
                     self._fake_caps[key] = 2 * int(fake_padded.node_depth.max().item())
                     self._captured.pop(key, None)
-                for p_ in self._d_params:      # the recorded gradients are added into the .grad tensors
-                    if p_.grad is None:
-                        p_.grad = torch.zeros_like(p_)
+                if fake_recorded:
+                    for p_ in self._d_params:      # all three terms are recorded: their gradients are added
+                        if p_.grad is None:        # into .grad tensors that are zeroed in place
+                            p_.grad = torch.zeros_like(p_)
         except Exception as e:
             if self.world == 1:
                 raise
@@ -591,7 +616,10 @@ class Trainer:
         for it in range(a.n_critic):
             if failed is None:
                 try:
-                    self.opt_D.zero_grad(set_to_none=terms is None)
+                    # (an eager backward pass over the fakes installs its gradients as the .grad tensors - no
+                    #  kernel - and the recorded terms are added to them; zeroed tensors would cost it an
+                    #  accumulation launch per parameter)
+                    self.opt_D.zero_grad(set_to_none=not fake_recorded)
                     if terms is not None:
                         if fake_recorded:     # the three recorded terms are independent: the generated side
                             self.side_stream.wait_stream(main_stream)          # runs next to the other two
