@@ -552,16 +552,16 @@ class Trainer:
         real_replayed = False
         try:
             terms = self._captured_terms(real_padded)
-            if terms is not None:
-                terms.load(real_padded)
-                real_for_D, edges_real = terms.real_for_D, terms.edges_real
-            else:
-                real_for_D, edges_real = sanitize_for_D(real_padded), count_edges(real_padded.edge_index)
             fakes_stream = self.side_stream if (terms is not None and self.overlap_fakes) else main_stream
             fakes_stream.wait_stream(main_stream)
-            if fakes_stream is not main_stream:
-                terms.replay_real()       # the first iteration's real-side term: one launch, then the
-                real_replayed = True      # host goes on to enqueue the fakes next to it
+            # With the fakes on their own stream they are enqueued FIRST: the real minibatch's structures (two
+            # sorts for its edge lists, one for its levels - dozens of tiny launches) are then rebuilt underneath
+            # the generator pass instead of in front of everything.
+            real_first = terms is None or fakes_stream is main_stream
+            if terms is None:
+                real_for_D, edges_real = sanitize_for_D(real_padded), count_edges(real_padded.edge_index)
+            elif real_first:
+                terms.load(real_padded)
             as_set = self._as_set(templates)
             # The penalty term needs the fakes' node features, the critic's pass over the fakes their edges and
             # levels.  The levels come out of a level-by-level walk (one workgroup per graph, most of a millisecond
@@ -589,6 +589,12 @@ class Trainer:
                     fake_padded = self._pad_batch(corr_fakes_once)
                 fake_for_D = fake_padded
                 edges_fake = count_edges(fake_padded.edge_index)
+            if not real_first:
+                terms.load(real_padded)
+                terms.replay_real()       # the first iteration's real-side term runs next to the fakes
+                real_replayed = True
+            if terms is not None:
+                real_for_D, edges_real = terms.real_for_D, terms.edges_real
             fake_recorded = False
             if split:
                 main_stream.wait_event(features_ready)
