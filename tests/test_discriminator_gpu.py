@@ -5,6 +5,8 @@ nor installable here: PARITY UNPINNED for this layer - the checker restates its 
 forward, and these tests hold the HIP kernels to that restatement.  Tolerance: 1e-4 relative
 (north_star: losses and scores within 1e-4 relative in fp32).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,6 +24,12 @@ DEV = "cuda"
 RTOL = 1e-4
 
 
+def grad_rtol(name):
+    """Bound for a parameter gradient: 1e-4 like everything else, except the edge-attribute projection, whose
+    gradient is a sum over every edge of terms of both signs (measured up to 1.4e-4 in fp32 on both sides)."""
+    return 5e-4 if name.endswith("lin_edge.weight") else RTOL
+
+
 def make_critic(seed=0):
     p = omodel.init_discriminator_params(seed)
     D = AIGDiscriminator()
@@ -34,6 +42,8 @@ def close(a, b, rtol=RTOL, what=""):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     scale = max(np.abs(b).max(), 1e-12)
     err = np.abs(a - b).max() / scale
+    if os.environ.get("AIG_TEST_SHOW_ERRORS"):      # tuning aid: how far below its bound every comparison lands
+        print(f"[close] {what or '-'}: {err:.2e} (bound {rtol:.0e})")
     assert err <= rtol, f"{what}: max error {err:.3e} of scale {scale:.3e}"
 
 
@@ -115,7 +125,7 @@ def test_critic_forward_and_parameter_gradients(name):
     ref.sum().backward()
     for k, v in D.named_parameters():
         assert v.grad is not None, k
-        close(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=5e-4, what="grad " + k)
+        close(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=grad_rtol(k), what="grad " + k)
 
 
 _CD, _CPARAMS, _CNAMES = critic_cases()
@@ -138,7 +148,7 @@ def test_critic_against_reference_execution(name):
     if pre + "grad/out.weight" in _CD.files:
         score.sum().backward()
         for k, v in D.named_parameters():
-            close(v.grad.cpu().numpy(), _CD[pre + "grad/" + k], rtol=5e-4, what="grad " + k)
+            close(v.grad.cpu().numpy(), _CD[pre + "grad/" + k], rtol=grad_rtol(k), what="grad " + k)
     if name.startswith("padded"):
         # the critic also takes the padded edge list as it is (the edge-list builder drops the -1 columns)
         assert torch.equal(D(g), score)
@@ -164,9 +174,9 @@ def test_critic_against_reference_execution(name):
                     # autograd reports exact zeros where this package reports "no gradient"
                     assert v not in grads and float(np.abs(_CD[key]).max()) == 0.0, k
                     continue
-                close(v.grad.cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (autograd) " + k)
+                close(v.grad.cpu().numpy(), _CD[key], rtol=RTOL, what="gp grad (autograd) " + k)
                 if v in grads:
-                    close(grads[v].cpu().numpy(), _CD[key], rtol=1e-3, what="gp grad (closed form) " + k)
+                    close(grads[v].cpu().numpy(), _CD[key], rtol=RTOL, what="gp grad (closed form) " + k)
 
 
 def test_structures_rebuilt_in_place_give_the_same_critic():
@@ -256,7 +266,7 @@ def test_gat_layer_output_and_input_gradient():
     wgt = torch.randn(h.shape, generator=torch.Generator().manual_seed(3))
     (h * wgt.to(DEV)).sum().backward()
     (href * wgt).sum().backward()
-    close(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=5e-4, what="d input")
+    close(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=RTOL, what="d input")
 
 
 def test_csr_structure():
@@ -331,7 +341,7 @@ def test_gradient_penalty_and_double_backward():
         if ref_g is None or float(ref_g.abs().max()) == 0.0:
             assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
             continue
-        close(v.grad.cpu().numpy(), ref_g.numpy(), rtol=5e-4, what="gp grad " + k)
+        close(v.grad.cpu().numpy(), ref_g.numpy(), rtol=RTOL, what="gp grad " + k)
 
 
 def test_critic_full_size_runs_and_is_reproducible():
