@@ -1,6 +1,7 @@
 // Shared helpers of libaig_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstddef>
@@ -62,19 +63,20 @@ hipError_t fill_words(void* p, unsigned word, size_t bytes, hipStream_t s);
 // (a kernel attribute belongs to the device's copy of the code object); safe to call from several threads.
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
-// Per-kernel GPU time for the benchmark (aig_kernel_timing in the header): while switched on, a launch wrapped
-// in a KernelTimed is bracketed by two events on its stream (not while that stream is being recorded into a
-// graph).  Off, the wrapper is one load and a branch.
-struct KernelTimed {
-    KernelTimed(int kernel, hipStream_t s);
-    ~KernelTimed();
-    KernelTimed(const KernelTimed&) = delete;
-    KernelTimed& operator=(const KernelTimed&) = delete;
+// Per-kernel GPU time for the benchmark (aig_kernel_timing in the header): while a kernel is selected, its
+// launch carries a start and a stop event of its own (the dispatch itself stamps them at the kernel's first and
+// last wave: no marker packets around it, so the figure is the kernel's duration and nothing else) - not while
+// its stream is being recorded into a graph.  Off, the macro is one load and a branch in front of the launch.
+bool kernel_timing_events(int kernel, hipStream_t s, hipEvent_t* start, hipEvent_t* stop);
 
-private:
-    hipStream_t stream_;
-    hipEvent_t stop_ = nullptr;
-};
+#define AIG_LAUNCH_TIMED(id, kernel, grid, block, lds, stream, ...)                                           \
+    do {                                                                                                      \
+        hipEvent_t kt_a_ = nullptr, kt_b_ = nullptr;                                                          \
+        if (::aig::kernel_timing_events(id, stream, &kt_a_, &kt_b_))                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt_a_, kt_b_, 0, __VA_ARGS__);            \
+        else                                                                                                  \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
+    } while (0)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -80,23 +80,18 @@ bool kt_event(hipEvent_t* e) {   // under g_kt_mutex
 }
 }  // namespace
 
-KernelTimed::KernelTimed(int kernel, hipStream_t s) : stream_(s) {
-    if (kernel < 0 || kernel >= AIG_KT_COUNT || !(g_kt_mask >> kernel & 1u)) return;
+bool kernel_timing_events(int kernel, hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
+    if (kernel < 0 || kernel >= AIG_KT_COUNT || !(g_kt_mask >> kernel & 1u)) return false;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
     TimedLaunch t{};
-    {
-        std::lock_guard<std::mutex> lock(g_kt_mutex);
-        if (!kt_event(&t.start)) return;
-        if (!kt_event(&t.stop)) { g_kt_free.push_back(t.start); return; }
-        g_kt[kernel].push_back(t);
-    }
-    (void)hipEventRecord(t.start, s);
-    stop_ = t.stop;
-}
-
-KernelTimed::~KernelTimed() {
-    if (stop_) (void)hipEventRecord(stop_, stream_);
+    std::lock_guard<std::mutex> lock(g_kt_mutex);
+    if (!kt_event(&t.start)) return false;
+    if (!kt_event(&t.stop)) { g_kt_free.push_back(t.start); return false; }
+    g_kt[kernel].push_back(t);
+    *start = t.start;
+    *stop = t.stop;
+    return true;
 }
 
 }  // namespace aig

@@ -238,8 +238,7 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
     if (F == 128) {
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wgrad128), (size_t)(WGRAD_LDS)));
         nb = wg_blocks(n, 2 * TILE, WG_BLOCKS_MAX);
-        KernelTimed kt(AIG_KT_WGRAD128, s);
-        hipLaunchKernelGGL(k_wgrad128, dim3(nb), dim3(256), WGRAD_LDS, s, (int)n, g, x, partial);
+        AIG_LAUNCH_TIMED(AIG_KT_WGRAD128, k_wgrad128, dim3(nb), dim3(256), WGRAD_LDS, s, (int)n, g, x, partial);
     } else if (F == 1) {
         nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
         hipLaunchKernelGGL(k_wgrad_small<1>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);

@@ -875,11 +875,8 @@ extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const f
     if (n == 0) return AIG_OK;
     AIG_REQUIRE(xw && a_s && a_d && ce && bias && row_ptr && loop_ea && out && alpha_loop, "aig_gat_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    {
-        KernelTimed kt(AIG_KT_GAT_AGGREGATE, s);
-        hipLaunchKernelGGL(k_gat_aggregate, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d, ce, bias,
-                           row_ptr, csr_src, csr_ea, loop_ea, out, alpha_e, alpha_loop);
-    }
+    AIG_LAUNCH_TIMED(AIG_KT_GAT_AGGREGATE, k_gat_aggregate, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d,
+                     ce, bias, row_ptr, csr_src, csr_ea, loop_ea, out, alpha_e, alpha_loop);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -933,22 +930,16 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     // the target-side kernel holds 4 waves per SIMD (104 registers): 1024 blocks are resident at once, and a grid
     // of 1568 left the second round half empty
     const int g = grid_blocks(n, BWD_DST_BLOCKS);
-    {
-        KernelTimed kt(AIG_KT_GAT_BWD_DST, s);
-        hipLaunchKernelGGL(k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce, row_ptr,
-                           csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial_dst);
-    }
+    AIG_LAUNCH_TIMED(AIG_KT_GAT_BWD_DST, k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce,
+                     row_ptr, csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial_dst);
     AIG_LAUNCH_CHECK();
     // blocks of the by-source kernel: HUB_BLOCKS for the hubs' chunks (they leave at once when the graph
     // has none), then gs over the nodes; the finishing kernel takes a hub per block
     const int gs = grid_blocks(n, BWD_SRC_BLOCKS);
     const int4* tab = reinterpret_cast<const int4*>(hub_tab);
-    {
-        KernelTimed kt(AIG_KT_GAT_BWD_SRC, s);
-        hipLaunchKernelGGL(k_gat_bwd_src, dim3(HUB_BLOCKS + gs), dim3(THREADS), 0, s, (int)n, HUB_BLOCKS, g_pre, xw, att_src,
-                           att_dst, tab, col_ptr, csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d, d_xw,
-                           part_acc, part_das, partial);
-    }
+    AIG_LAUNCH_TIMED(AIG_KT_GAT_BWD_SRC, k_gat_bwd_src, dim3(HUB_BLOCKS + gs), dim3(THREADS), 0, s, (int)n, HUB_BLOCKS, g_pre,
+                     xw, att_src, att_dst, tab, col_ptr, csc_pos, csc_dst, alpha_e, alpha_loop, d_raw_e, d_raw_loop, d_a_d,
+                     d_xw, part_acc, part_das, partial);
     hipLaunchKernelGGL(k_gat_bwd_hub_finish, dim3(HUB_FINISH_BLOCKS), dim3(THREADS), 0, s, g_pre, xw, att_src, att_dst, tab,
                        alpha_loop, d_raw_loop, d_a_d, part_acc, part_das, d_xw, partial + (size_t)gs * 2 * H);
     AIG_LAUNCH_CHECK();

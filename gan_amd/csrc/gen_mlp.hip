@@ -678,10 +678,7 @@ int launch_linear(hipStream_t s, int M, const float* X, const Chunk& ck) {
     AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128<ACT>), (size_t)(LINEAR_LDS)));
     int ntiles = (M + BM - 1) / BM;
     int gx = ntiles < 256 ? ntiles : 256;
-    {
-        KernelTimed kt(AIG_KT_LINEAR128, s);
-        hipLaunchKernelGGL((k_linear128<ACT>), dim3(gx), dim3(THREADS), LINEAR_LDS, s, M, X, ck);
-    }
+    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128<ACT>), dim3(gx), dim3(THREADS), LINEAR_LDS, s, M, X, ck);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -367,11 +367,8 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const in
         int64_t items = (nvalid + rows - 1) / rows;
         blocks = (int)((items + HW_PER_BLOCK - 1) / HW_PER_BLOCK);
         partial = c.take<float>((size_t)blocks * H);
-        {
-            KernelTimed kt(AIG_KT_POOL_WALK, s);
-            hipLaunchKernelGGL(k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, rows, lvl_meta, h, perm,
-                               node_level, w, table, partial);
-        }
+        AIG_LAUNCH_TIMED(AIG_KT_POOL_WALK, k_pool_walk, dim3(blocks), dim3(THREADS), 0, s, (int)nvalid, rows, lvl_meta, h, perm,
+                         node_level, w, table, partial);
         AIG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_pool_finish, dim3(H), dim3(256), 0, s, blocks, (int)L, lvl_meta, partial, table, lvl_ptr, out,

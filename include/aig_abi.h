@@ -356,9 +356,9 @@ int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* e
 
 /* ---- per-kernel GPU time (a measurement aid; no counterpart in the reference) --------------------------
  * aig_kernel_timing(mask) selects the kernels to time (bit k = kernel k of the list below, 0 = none, the
- * initial state); going from none to some forgets earlier records.  Every launch of a selected kernel is
- * bracketed by two HIP events on the stream it is launched on (launches that are being recorded into a HIP
- * graph are left alone).  aig_kernel_timing_read waits for the recorded launches of one kernel and returns
+ * initial state); going from none to some forgets earlier records.  Every launch of a selected kernel carries a
+ * start and a stop HIP event of its own, stamped by the dispatch on the stream it is launched on (launches that
+ * are being recorded into a HIP graph are left alone).  aig_kernel_timing_read waits for the recorded launches of one kernel and returns
  * their summed duration and their number.  Two event records per launch: for benchmarks, not for
  * production runs. */
 enum {
