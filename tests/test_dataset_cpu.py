@@ -74,3 +74,34 @@ def test_batch_vector_and_offsets_are_built_on_first_use():
     assert [int(d.x.size(0)) for d in b.to_data_list()] == [3, 1, 4]
     with __import__("pytest").raises(AttributeError):
         b.no_such_attribute
+
+
+def test_uniform_batch_and_graph_set_views_match_the_list_forms():
+    """``Batch.from_uniform`` (tensors that are already concatenated) carries the bookkeeping of
+    ``Batch.from_data_list`` on equally sized graphs, and a ``GraphSet`` hands its graphs back unchanged."""
+    import torch
+    from gan_amd.data import Batch, Data
+    from gan_amd.dataset import pad_data
+    from gan_amd.graphset import GraphSet
+    from gan_amd.sample import block_size
+    from gan_amd.synth import synth_aig
+    graphs = [synth_aig(4, 20 + i, 3, seed=i, window=8) for i in range(3)]
+    n = max(g.x.size(0) for g in graphs)
+    me = max(g.edge_index.size(1) for g in graphs)
+    padded = [pad_data(g, n, me) for g in graphs]
+    ref = Batch.from_data_list(padded)
+    uni = Batch.from_uniform(3, n, me, x=ref.x, edge_index=ref.edge_index, edge_attr=ref.edge_attr,
+                             node_depth=ref.node_depth)
+    assert uni.num_graphs == 3 and torch.equal(uni.batch, ref.batch) and torch.equal(uni.ptr, ref.ptr)
+    for a, b in zip(uni.to_data_list(), ref.to_data_list()):
+        assert all(torch.equal(getattr(a, k), getattr(b, k)) for k in ("x", "edge_index", "edge_attr", "node_depth"))
+    gset = GraphSet.from_data_list([Data(x=p.x, edge_index=g.edge_index, edge_attr=g.edge_attr.long(),
+                                         node_depth=p.node_depth) for p, g in zip(padded, graphs)])
+    assert gset.B == 3 and gset.n == n and gset.counts() == [int(g.edge_index.size(1)) for g in graphs]
+    for g, (p, src) in enumerate(zip(padded, graphs)):
+        d = gset.graph(g)
+        assert torch.equal(d.edge_index, src.edge_index) and torch.equal(d.x, p.x)
+        assert torch.equal(d.edge_attr.view(-1), src.edge_attr.long().view(-1)) and torch.equal(d.node_depth, p.node_depth)
+        v = gset.graph(g, copy=False)
+        assert torch.equal(v.edge_index, d.edge_index) and v.x.data_ptr() == gset.x[g * n:].data_ptr()
+    assert block_size(2389, 64) == 64 and block_size(100000, 64) == 10 and block_size(5_000_000, 64) == 1
