@@ -191,3 +191,36 @@ def test_generator_set_of_one_and_templates_without_targets():
     for g in range(3):
         assert_same_graph(fixed.graph(g), ref)
     assert float(penalties_set(gset).abs().sum()) == 0.0
+
+
+def test_bulk_block_at_the_bulk_sampling_configuration():
+    """A block of 64 draws from a c7552-sized template at candidate-k 256 with bf16 scoring - the bulk-sampling
+    configuration - through ``sample_sets``: spot checks against one sample at a time, and the properties every
+    repaired sample has whatever its size (fan-ins of PO / AND nodes, acyclic, levels consistent with the edges)."""
+    from gan_amd.generator import AIGGenerator
+    from gan_amd.sample import sample_one, sample_sets
+    from gan_amd.synth import ISCAS85_SHAPES
+    from util_golden import gen_state
+    name, n_pi, n_po, n_and = ISCAS85_SHAPES[-1]
+    g = synth_aig(n_pi, n_and, n_po, seed=0, window=max(8, n_and // 8 + n_pi), orientation="dataset")
+    tpl = Data(x=g.x.to(DEV), node_depth=g.node_depth.to(DEV))
+    G = AIGGenerator(candidate_k=256, score_dtype="bf16").to(DEV).eval()
+    G.load_state_dict(gen_state())
+    zs = torch.randn(64, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    (gset,) = list(sample_sets(G, tpl, [zs]))
+    assert gset.B == 64 and gset.n == g.x.size(0)
+    for i in (0, 31, 63):
+        assert_same_graph(gset.graph(i), sample_one(G, tpl, zs[i]))
+    types = g.x[:, 0].long().numpy()
+    for i in range(0, 64, 7):
+        d = gset.graph(i)
+        src, dst = d.edge_index.cpu().numpy()
+        indeg = np.bincount(dst, minlength=types.size)
+        assert (indeg[types == 0] == 0).all() and (indeg[types == 1] <= 1).all() and (indeg[types == 2] <= 2).all()
+        assert set(indeg[types == 2].tolist()) <= {0, 2}
+        depth = d.node_depth.cpu().numpy()
+        assert (depth[dst] > depth[src]).all()              # longest-path levels: every edge goes up
+        has_in = indeg > 0
+        assert (depth[~has_in] == 0).all() and (depth[has_in] == np.maximum.reduceat(depth[src][np.argsort(dst, kind="stable")] + 1, np.flatnonzero(np.diff(np.concatenate([[-1], np.sort(dst)])) > 0))).all()
+        inv = np.bincount(dst, weights=d.edge_attr.cpu().numpy().reshape(-1), minlength=types.size)
+        assert np.array_equal(d.x[:, 1].cpu().numpy(), inv.astype(np.float32))
