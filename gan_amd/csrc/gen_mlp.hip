@@ -46,136 +46,6 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
     out[v * H + j] = acc + b[j];
 }
 
-// Y = act(X W^T + bias) for a persistent grid of row tiles (ACT 0 none, 1 ReLU, 2 ELU): the single
-// 128x128 layer the critic calls (aig_linear128).
-//
-// LDS: the weight slice (padded rows) stays for the life of the block; input tiles of BM rows are
-// double-buffered.  A plain input tile goes global -> LDS by direct 16-byte loads (no register
-// stop), one wave instruction per pair of 512-byte rows, so its image cannot be padded; instead
-// the 16-byte chunk c of row r is kept at position c ^ (r & 15) (the permutation is applied to the
-// global address of each lane), which spreads the matrix-core fragment reads - 32 rows, one chunk
-// each - over all banks.  Rows past M read row M-1 and are never stored.
-__device__ __forceinline__ void load_to_lds16(const float* src, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-template <int ACT>
-__global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __restrict__ X, Chunk ck) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wl = lds;                       // [128][LDS_LD]
-    float* Xl = lds + H * LDS_LD;          // [2][BM][H], chunks permuted within a row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntiles = (M + BM - 1) / BM;
-
-    // stage the weight slice once: 128 rows x 32 float4 (row = output column)
-    if (ck.wt) {  // the slice is stored [in][out]: transpose while staging (all loads first)
-        float4 v[(H * H / 4) / THREADS];
-#pragma unroll
-        for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
-            const int idx = q * THREADS + tid, k = idx >> 5, c4 = idx & 31;
-            v[q] = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(k) * ck.ldw + c4 * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
-            const int idx = q * THREADS + tid, k = idx >> 5, j = 4 * (idx & 31);
-            Wl[j * LDS_LD + k] = v[q].x;
-            Wl[(j + 1) * LDS_LD + k] = v[q].y;
-            Wl[(j + 2) * LDS_LD + k] = v[q].z;
-            Wl[(j + 3) * LDS_LD + k] = v[q].w;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < (H * H / 4) / THREADS; ++q) {
-            int idx = q * THREADS + tid, row = idx >> 5, c4 = idx & 31;
-            float4 v = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(row) * ck.ldw + c4 * 4);
-            *reinterpret_cast<float4*>(Wl + row * LDS_LD + c4 * 4) = v;
-        }
-    }
-
-    // plain input: wave w, instruction q fills tile rows 2(4q+w) and 2(4q+w)+1
-    auto fetch = [&](int tile, int buf) {
-#pragma unroll
-        for (int q = 0; q < BM / 8; ++q) {
-            const int pr = 2 * (4 * q + wave);
-            const int row = pr + (lane >> 5);
-            const int gr = min(tile * BM + row, M - 1);
-            const int c4 = (lane & 31) ^ (row & 15);
-            load_to_lds16(X + static_cast<size_t>(gr) * H + 4 * c4, Xl + (buf * BM + pr) * H);
-        }
-    };
-    int tile = blockIdx.x;
-    if (tile < ntiles) fetch(tile, 0);
-
-    const int frow = lane & 31, fh = lane >> 5;
-    const float* Wfrag = Wl + (wave * 32 + frow) * LDS_LD + 4 * fh;
-    float bias_v = ck.bias ? ck.bias[wave * 32 + frow] : 0.f;
-    const int swz = frow & 15;  // rows frow and frow+32 share it
-
-    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-        const int buf = it & 1;
-        const int next = tile + gridDim.x;
-        // the tile's direct loads are older than the 32 output stores of the previous trip:
-        // wait until only those stores may be outstanding, then meet the other waves
-        // (first trip: nothing but the tile and the weight slice is in flight - wait for all)
-        if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (next < ntiles) fetch(next, buf ^ 1);
-
-        f32x16 acc0 = {0}, acc1 = {0};
-        const float* Xf0 = Xl + (buf * BM + frow) * H;
-        const float* Xf1 = Xf0 + 32 * H;
-        // lane half fh takes k = 8g + 4fh + t at step t: A and B agree, so any k order is a valid sum.
-        // The fragments of group g+1 are requested before the eight products of group g are issued.
-        float4 a0 = *reinterpret_cast<const float4*>(Xf0 + 4 * (fh ^ swz));
-        float4 a1 = *reinterpret_cast<const float4*>(Xf1 + 4 * (fh ^ swz));
-        float4 b = *reinterpret_cast<const float4*>(Wfrag);
-#pragma unroll
-        for (int g = 0; g < H / 8; ++g) {
-            float4 n0 = a0, n1 = a1, nb = b;
-            if (g + 1 < H / 8) {
-                const int pc = 4 * ((2 * (g + 1) + fh) ^ swz);
-                n0 = *reinterpret_cast<const float4*>(Xf0 + pc);
-                n1 = *reinterpret_cast<const float4*>(Xf1 + pc);
-                nb = *reinterpret_cast<const float4*>(Wfrag + 8 * (g + 1));
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
-            a0 = n0; a1 = n1; b = nb;
-            // pin the issue order: this group's three LDS reads first, then its eight products
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        }
-        // epilogue: register r of a 32x32 tile is row (r&3) + 8(r>>2) + 4*fh, column = frow
-        const int col = wave * 32 + frow;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-            // rows past M land on row M-1 of the same column with the value that row has anyway
-            // (their input was row M-1): every trip issues exactly 32 stores, which the counted
-            // wait above relies on
-            int g0 = min(tile * BM + row, M - 1), g1 = min(tile * BM + row + 32, M - 1);
-            float y0 = acc0[r] + bias_v, y1 = acc1[r] + bias_v;
-            if (ACT == 1) {
-                y0 = fmaxf(y0, 0.f);
-                y1 = fmaxf(y1, 0.f);
-            } else if (ACT == 2) {  // ELU
-                y0 = y0 > 0.f ? y0 : expm1f(y0);
-                y1 = y1 > 0.f ? y1 : expm1f(y1);
-            }
-            ck.out[static_cast<size_t>(g0) * H + col] = y0;
-            ck.out[static_cast<size_t>(g1) * H + col] = y1;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Node pipeline of the generator with the weights in registers.
 //
@@ -183,14 +53,14 @@ __global__ __launch_bounds__(THREADS) void k_linear128(int M, const float* __res
 // W[col][8g + 4fh .. + 3], g = 0..15, in 64 registers per layer for the life of the block (one wave per
 // SIMD: 512 registers per lane), which leaves LDS to tiles: a tile of BM rows is read as matrix-core
 // fragments from one LDS buffer and the layer's output is written to another (same chunk permutation
-// as k_linear128's input tiles), either as the next layer's input or as a staging copy of an output
+// as aig_linear128's input tiles), either as the next layer's input or as a staging copy of an output
 // that the NEXT layer's product loop streams to memory, whole 512-byte rows at a time, one 16-byte
 // piece per thread every other group of products - so stores never come in a burst at the end of a
 // tile, when all 256 workgroups (which run in step) would otherwise issue theirs together.
 // The weights are the FIRST matrix-core operand and the tile the second, so a lane ends up with four
 // consecutive output columns (8j + 4fh .. + 3 of the wave's 32, j = 0..3) of tile rows frow and
 // frow + 32: 16-byte LDS writes.  The products of an output element and their order are those of
-// k_linear128, so both give the same bits.
+// k_linear128 below, so both give the same bits.
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_F = BM * H;  // floats per LDS tile
 
@@ -671,14 +541,176 @@ __global__ __launch_bounds__(THREADS) void k_node_pipe_bf16(int M, PipeBf16 p) {
     }
 }
 
-constexpr size_t LINEAR_LDS = (H * LDS_LD + 2 * BM * H) * sizeof(float);
+
+// ---------------------------------------------------------------------------------------------
+// Y = act(X W^T + bias), one 128x128 layer (ACT 0 none, 1 ReLU, 2 ELU): the layer the critic calls
+// (aig_linear128).  One workgroup of EIGHT waves per CU, the weight slice in registers.
+//
+// The LDS holds the padded weight slice only while the lanes pick their fragments out of it (lane (col, fh)
+// keeps W[col][8g + 4fh .. + 3], g = 0..15, for the life of the block, as the node pipeline does); afterwards
+// the same LDS is two input tiles of 64 rows.  Wave w owns output columns 32 (w & 3) .. + 31 and the 32-row
+// unit (w >> 2) of every tile: two waves per SIMD, so one wave's bias / activation / address arithmetic runs
+// under the other's products, and the per-tile barrier keeps the two in step (two independent 4-wave
+// workgroups per CU did not: the older one wins every issue slot, finishes early and leaves the other to run
+// alone at one wave per SIMD).  32-row units are dealt round-robin over the blocks (at most one unit of
+// imbalance), at any moment the blocks read and write one contiguous stretch of rows.
+// Memory traffic rides inside the product loop: the tile after this one arrives by direct global -> LDS loads
+// issued one per group of products in the first groups (loads the compiler does not count - after a counted one
+// it waits for ALL memory traffic before the next LDS read, which serialises the prefetch with the products -
+// guarded by counted waits of our own: completion is in issue order), and the outputs of the tile before this
+// one, held in registers, are stored one 16-byte piece per group further on.  Stores issued in a burst behind
+// the last product of a tile - by every workgroup of the grid at once, since they run in step - stall the waves
+// at issue: 44.5 -> 37.9 us at 100k rows with both changes, 398 -> 333 us at a million.
+// The weights are the first matrix-core operand, so a lane ends up with four consecutive output columns of its
+// row.  Products and their order per output element are those of the node pipeline (same bits).
+// ---------------------------------------------------------------------------------------------
+constexpr size_t LINEAR_R_LDS = H * LDS_LD * sizeof(float);
+static_assert(LINEAR_R_LDS >= 2 * TILE_F * sizeof(float), "two input tiles must fit where the weight slice was");
+
+constexpr int THREADS8 = 512;   // eight waves: two per SIMD
+
+template <int ACT>
+__device__ __forceinline__ float4 bias_act(const f32x16& acc, int j, const float4& bv) {
+    float4 y = make_float4(acc[4 * j] + bv.x, acc[4 * j + 1] + bv.y, acc[4 * j + 2] + bv.z, acc[4 * j + 3] + bv.w);
+    if (ACT == 1) {
+        y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
+    } else if (ACT == 2) {  // ELU
+        y.x = y.x > 0.f ? y.x : expm1f(y.x);
+        y.y = y.y > 0.f ? y.y : expm1f(y.y);
+        y.z = y.z > 0.f ? y.z : expm1f(y.z);
+        y.w = y.w > 0.f ? y.w : expm1f(y.w);
+    }
+    return y;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(THREADS8, 1) void k_linear128(int M, const float* __restrict__ X, Chunk ck) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cw = wave & 3, uh = wave >> 2;   // column group of the wave, and which 32-row unit of a tile it takes
+    const int frow = lane & 31, fh = lane >> 5;
+    // 32-row units are dealt round-robin: unit u belongs to block u % gridDim.x, and a block's units 2i, 2i+1
+    // are the two halves of its tile i (an odd unit out: the second half of the last tile is idle)
+    const int G = gridDim.x;
+    const int units = (M + 31) / 32;
+    const int nu = (units - (int)blockIdx.x + G - 1) / G;
+    if (nu <= 0) return;
+    const int nt = (nu + 1) / 2;
+
+    // the weight slice, padded rows (row = output column), staged once
+    constexpr int WQ = (H * H / 4) / THREADS8;
+    if (ck.wt) {  // stored [in][out]: transpose while staging (all loads first)
+        float4 v[WQ];
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int idx = q * THREADS8 + tid, k = idx >> 5, c4 = idx & 31;
+            v[q] = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(k) * ck.ldw + c4 * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int idx = q * THREADS8 + tid, k = idx >> 5, j = 4 * (idx & 31);
+            lds[j * LDS_LD + k] = v[q].x;
+            lds[(j + 1) * LDS_LD + k] = v[q].y;
+            lds[(j + 2) * LDS_LD + k] = v[q].z;
+            lds[(j + 3) * LDS_LD + k] = v[q].w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            const int idx = q * THREADS8 + tid, row = idx >> 5, c4 = idx & 31;
+            const float4 v = *reinterpret_cast<const float4*>(ck.w + static_cast<size_t>(row) * ck.ldw + c4 * 4);
+            *reinterpret_cast<float4*>(lds + row * LDS_LD + c4 * 4) = v;
+        }
+    }
+    float4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bv[j] = ck.bias ? *reinterpret_cast<const float4*>(ck.bias + cw * 32 + 8 * j + 4 * fh) : make_float4(0, 0, 0, 0);
+    __syncthreads();
+    float4 wr[H / 8];
+#pragma unroll
+    for (int g = 0; g < H / 8; ++g)
+        wr[g] = *reinterpret_cast<const float4*>(lds + (cw * 32 + frow) * LDS_LD + 8 * g + 4 * fh);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // weights, bias: nothing of ours in flight from here
+    __syncthreads();  // every fragment is in registers: the LDS is tiles from here on
+
+    const unsigned lds0 = lds_address(lds);
+    auto unit_row = [&](int k) { return ((long long)blockIdx.x + (long long)k * G) * 32; };   // block's k-th unit
+    // Direct load q (0..3) of a tile: wave w fills tile rows 2(8q+w) and 2(8q+w)+1 (chunk c of row r at position
+    // c ^ (r & 15)); rows past M repeat row M-1
+    auto fetch1 = [&](int q, long long ra, long long rb, unsigned dst) {
+        const int pr = 2 * (8 * q + wave);
+        const int row = pr + (lane >> 5);
+        const long long gr = min((q < 2 ? ra : rb - 32) + row, (long long)M - 1);
+        const int c4 = (lane & 31) ^ (row & 15);
+        load_to_lds16_uncounted(X + gr * H + 4 * c4, __builtin_amdgcn_readfirstlane(dst + (unsigned)(pr * H * sizeof(float))));
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fetch1(q, unit_row(0), unit_row(1), lds0);
+
+    float* const out = ck.out + cw * 32 + 4 * fh;
+    float4 hold[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hold[j] = make_float4(0, 0, 0, 0);
+    float* hold_dst = nullptr;   // this lane's row of the held outputs
+    const int swz = frow & 15;
+    for (int it = 0; it < nt; ++it) {
+        const float* Xf = lds + ((it & 1) * BM + uh * 32 + frow) * H;
+        const bool mine = 2 * it + uh < nu;   // (false: second half of an odd last tile)
+        // In flight from the trip before, in issue order: this tile's 4 loads, then the 4 stores of the tile
+        // before it (none during the first trip).  Completion is in issue order.
+        if (it <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... for every wave; nobody still reads the other tile
+        const bool more = it + 1 < nt;
+        const long long na = unit_row(2 * it + 2), nb = unit_row(2 * it + 3);
+        const unsigned ndst = lds0 + (unsigned)(((it & 1) ^ 1) * TILE_F * sizeof(float));
+        f32x16 acc = {0};
+        if (mine) {
+            // fragment reads run AHEAD groups in front of the products that use them
+            constexpr int AHEAD = 2;
+            float4 a[H / 8];
+#pragma unroll
+            for (int g = 0; g < AHEAD; ++g) a[g] = *reinterpret_cast<const float4*>(Xf + 4 * ((2 * g + fh) ^ swz));
+#pragma unroll
+            for (int g = 0; g < H / 8; ++g) {
+                if (g + AHEAD < H / 8) a[g + AHEAD] = *reinterpret_cast<const float4*>(Xf + 4 * ((2 * (g + AHEAD) + fh) ^ swz));
+                // the next tile's loads ride in the first groups of products, the held tile's stores further on
+                if (g < 4) {
+                    if (more) fetch1(g, na, nb, ndst);
+                } else if (g >= 8 && g < 12) {
+                    if (hold_dst) *reinterpret_cast<float4*>(hold_dst + 8 * (g - 8)) = hold[g - 8];
+                }
+                const float4 b = wr[g];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[g].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[g].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[g].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[g].w, acc, 0, 0, 0);
+            }
+        } else {
+            // (only ever the last trip: nothing to load; the held tile's stores follow the loop)
+        }
+        if (!mine) break;
+        // registers 4j..4j+3 of a 32x32 block: columns 8j + 4fh .. + 3 of the wave's 32, row frow of the unit.
+        // Rows past M land on row M-1 with the values that row has anyway (their input was row M-1), so a tile
+        // always issues 4 stores, which the counted wait relies on.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hold[j] = bias_act<ACT>(acc, j, bv[j]);
+        hold_dst = out + min(unit_row(2 * it + uh) + frow, (long long)M - 1) * H;
+    }
+    // the outputs still held (the last tile's; for a wave idle in the last trip, the one before)
+    if (hold_dst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(hold_dst + 8 * j) = hold[j];
+    }
+}
 
 template <int ACT>
 int launch_linear(hipStream_t s, int M, const float* X, const Chunk& ck) {
-    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128<ACT>), (size_t)(LINEAR_LDS)));
-    int ntiles = (M + BM - 1) / BM;
-    int gx = ntiles < 256 ? ntiles : 256;
-    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128<ACT>), dim3(gx), dim3(THREADS), LINEAR_LDS, s, M, X, ck);
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128<ACT>), (size_t)(LINEAR_R_LDS)));
+    const int pairs = ((M + 31) / 32 + 1) / 2;
+    const int gx = pairs < 256 ? pairs : 256;   // one workgroup of eight waves per CU
+    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128<ACT>), dim3(gx), dim3(THREADS8), LINEAR_R_LDS, s, M, X, ck);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -7,8 +7,8 @@ from gan_amd import _abi
 dev = "cuda"
 w = torch.randn(128, 128, device=dev)
 lib = _abi.lib()
-for tiles in (1, 2, 4, 6, 7, 8, 16, 32):
-    n = 256 * 64 * tiles
+for tiles in (1, 2, 4, 6, 6.1035, 7, 8, 16, 32, 61.035):
+    n = int(round(256 * 64 * tiles))
     x = torch.randn(n, 128, device=dev)
     y = torch.empty_like(x)
     ts = []
@@ -21,5 +21,5 @@ for tiles in (1, 2, 4, 6, 7, 8, 16, 32):
         if i >= 5:
             ts.append(a.elapsed_time(b) * 1e3)
     t = statistics.median(ts)
-    print(f"tiles/wg {tiles:3d}  n {n:8d}  median {t:8.1f} us  min {min(ts):8.1f}  "
+    print(f"tiles/wg {tiles:7.3f}  n {n:8d}  median {t:8.1f} us  min {min(ts):8.1f}  "
           f"{2 * n * 128 * 128 / t * 1e-6:7.1f} TFLOP/s")
