@@ -18,82 +18,92 @@ constexpr int WG_BLOCKS_MAX = 256;         // F = 128: one 64 KB partial per CU
 constexpr int WG_SMALL_BLOCKS_MAX = 512;   // small F: partials are at most 2 KB, two blocks per CU
 
 // F == 128.  Node tiles of TILE rows of g and x go global -> LDS by direct 16-byte loads (no
-// register stop; one wave instruction fills two whole 512-byte rows), double-buffered: tile t+1 is
-// in flight while the matrix cores work on tile t, one barrier per tile.  Wave w owns rows
-// 32w..32w+31 of dW and all four 32-column tiles.  MFMA 32x32x2: A[i][k] = g[n0+k][32w+i],
-// B[k][c] = x[n0+k][32t+c], k = lane>>5, i/c = lane&31; the two k rows of an operand are read by
-// the two halves of the wave, which the LDS serves in separate cycles, so rows need no padding.
+// register stop; one wave instruction fills two whole 512-byte rows), double-buffered: tile t+1 arrives
+// while the matrix cores work on tile t, one barrier per tile.  EIGHT waves per workgroup, two per SIMD
+// (one wave's operand reads and address arithmetic run under the other's products): wave w owns rows
+// 32(w&3) .. +31 of dW and the two 32-column tiles 2(w>>2), 2(w>>2)+1.  MFMA 32x32x2: A[i][k] =
+// g[n0+k][32(w&3)+i], B[k][c] = x[n0+k][32t+c], k = lane>>5, i/c = lane&31; the two k rows of an operand
+// are read by the two halves of the wave, which the LDS serves in separate cycles, so rows need no padding.
+// A tile is two 32-row units; units are dealt round-robin over the blocks (unit u belongs to block
+// u % gridDim.x: at most one unit of imbalance, and at any moment the grid reads one contiguous stretch
+// of rows).  The next tile's 8 loads per wave are issued one every fourth pair of node rows inside the
+// product loop - all at once at the top of a tile, by every workgroup of the grid in the same
+// microsecond, they stall the waves at issue.
 constexpr int TILE = 64;
 constexpr size_t WGRAD_LDS = (size_t)2 * 2 * TILE * H * sizeof(float);
 
-__global__ __launch_bounds__(256) void k_wgrad128(int n, const float* __restrict__ g, const float* __restrict__ x,
-                                                  float* __restrict__ partial /*[grid][128][128]*/) {
+__global__ __launch_bounds__(512, 1) void k_wgrad128(int n, const float* __restrict__ g, const float* __restrict__ x,
+                                                     float* __restrict__ partial /*[grid][128][128]*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][g|x][TILE][H]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int rw = w & 3, ch = w >> 2;
     const int col = lane & 31, kh = lane >> 5;
-    const int chunk = (n + gridDim.x - 1) / gridDim.x;
-    const int n0 = blockIdx.x * chunk, n1 = min(n, n0 + chunk);
-    const int ntiles = n1 > n0 ? (n1 - n0 + TILE - 1) / TILE : 0;
-    // wave w, instruction q fills tile rows 2(4q+w) and 2(4q+w)+1; lane -> (row parity kh, 16-byte column col)
+    const int G_ = gridDim.x;
+    const int units = (n + 31) / 32;
+    const int nu = (units - (int)blockIdx.x + G_ - 1) / G_;   // this block's units: blockIdx.x + k * gridDim.x
+    const int ntiles = nu > 0 ? (nu + 1) / 2 : 0;
+    auto unit_row = [&](int k) { return ((long long)blockIdx.x + (long long)k * G_) * 32; };
+    // Direct load q (0..3) of a tile: wave w fills tile rows 2(8q+w) and 2(8q+w)+1 of g and of x; lane ->
+    // (row parity kh, 16-byte column col).  Rows past n read row n-1 (zeroed in LDS before use, see below).
     // The loads are issued from inline asm: after the builtin the compiler waits for ALL memory traffic
     // before the next LDS read, i.e. for tile t+1 before the products of tile t.  These are this kernel's
     // only memory operations until the epilogue, so "none outstanding" at the top of a trip is exact.
     const unsigned lds0 = lds_address(lds);
-    auto fetch = [&](int tile, int buf) {
-        const unsigned G = lds0 + (unsigned)((size_t)buf * 2 * TILE * H * sizeof(float));
-        const unsigned X = G + (unsigned)(TILE * H * sizeof(float));
-#pragma unroll
-        for (int q = 0; q < TILE / 8; ++q) {
-            const int pr = 2 * (4 * q + w);
-            const int row = n0 + tile * TILE + pr + kh;
-            const size_t off = (size_t)(row < n1 ? row : n0) * H + 4 * col;  // rows past the range: any valid row
-            load_to_lds16_uncounted(g + off, __builtin_amdgcn_readfirstlane(G + (unsigned)(pr * H * sizeof(float))));
-            load_to_lds16_uncounted(x + off, __builtin_amdgcn_readfirstlane(X + (unsigned)(pr * H * sizeof(float))));
-        }
+    auto fetch1 = [&](int q, int tile, int buf) {
+        const unsigned Gd = lds0 + (unsigned)((size_t)buf * 2 * TILE * H * sizeof(float));
+        const unsigned Xd = Gd + (unsigned)(TILE * H * sizeof(float));
+        const int pr = 2 * (8 * q + w);
+        const long long row = unit_row(2 * tile + (q >> 1)) + (pr & 31) + kh;
+        const size_t off = (size_t)(row < n ? row : n - 1) * H + 4 * col;
+        load_to_lds16_uncounted(g + off, __builtin_amdgcn_readfirstlane(Gd + (unsigned)(pr * H * sizeof(float))));
+        load_to_lds16_uncounted(x + off, __builtin_amdgcn_readfirstlane(Xd + (unsigned)(pr * H * sizeof(float))));
     };
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-    if (ntiles > 0) fetch(0, 0);
+    f32x16 acc[2] = {{0}, {0}};
+    if (ntiles > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch1(q, 0, 0);
+    }
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of tile `tile` ...
         __syncthreads();  // ... and everybody else's: the tile is complete, the other buffer no longer read
-        const int rows = n1 - (n0 + tile * TILE);
-        if (rows < TILE) {  // last, ragged tile: rows past the range must not contribute
-            float* G = lds + (size_t)buf * 2 * TILE * H;
-            for (int i = rows * H + t; i < TILE * H; i += 256) G[i] = 0.f;
+        // rows of g that must not contribute: the second unit of an odd last tile, and the rows past n of the
+        // very last unit
+        const long long r0 = unit_row(2 * tile), r1 = unit_row(2 * tile + 1);
+        const int have0 = (int)min(32LL, (long long)n - r0);
+        const int have1 = 2 * tile + 1 < nu ? (int)min(32LL, (long long)n - r1) : 0;
+        if (have0 < 32 || have1 < 32) {   // uniform over the block
+            float* Gl = lds + (size_t)buf * 2 * TILE * H;
+            for (int i = t; i < TILE * H; i += 512) {
+                const int row = i >> 7;
+                if ((row < 32 && row >= have0) || (row >= 32 && row - 32 >= have1)) Gl[i] = 0.f;
+            }
             __syncthreads();
         }
-        if (tile + 1 < ntiles) fetch(tile + 1, buf ^ 1);
-        const float* G = lds + (size_t)buf * 2 * TILE * H + 32 * w + col;
-        const float* X = lds + (size_t)buf * 2 * TILE * H + TILE * H + col;
-        // operands of pair kk+1 are requested before the four products of pair kk are issued
-        auto products = [&](int kk_end) {
-            float a = G[kh * H];
-            float b0 = X[kh * H], b1 = X[kh * H + 32], b2 = X[kh * H + 64], b3 = X[kh * H + 96];
-#pragma unroll 8
-            for (int kk = 0; kk < kk_end; ++kk) {
-                const int rn = (2 * (kk + 1 < kk_end ? kk + 1 : kk) + kh) * H;
-                const float na = G[rn];
-                const float n0 = X[rn], n1 = X[rn + 32], n2 = X[rn + 64], n3 = X[rn + 96];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
-                a = na; b0 = n0; b1 = n1; b2 = n2; b3 = n3;
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // (the four x values come as two 2-address reads)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-        };
-        if (rows >= TILE) products(TILE / 2);
-        else products((rows + 1) / 2);  // a ragged tile: only its (zero-padded) pairs of rows
+        const bool more = tile + 1 < ntiles;
+        const float* Gp = lds + (size_t)buf * 2 * TILE * H + 32 * rw + col;
+        const float* Xp = lds + (size_t)buf * 2 * TILE * H + TILE * H + 64 * ch + col;
+        // operands of pair kk+1 are requested before the two products of pair kk are issued
+        float a = Gp[kh * H];
+        float b0 = Xp[kh * H], b1 = Xp[kh * H + 32];
+#pragma unroll
+        for (int kk = 0; kk < TILE / 2; ++kk) {
+            const int rn = (2 * (kk + 1 < TILE / 2 ? kk + 1 : kk) + kh) * H;
+            const float na = Gp[rn];
+            const float n0 = Xp[rn], n1 = Xp[rn + 32];
+            if ((kk & 7) == 0 && more) fetch1(kk >> 3, tile + 1, buf ^ 1);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            a = na; b0 = n0; b1 = n1;
+        }
     }
     float* out = partial + (size_t)blockIdx.x * H * H;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;  // accumulator register -> tile row
-            out[(size_t)(32 * w + row) * H + 32 * tt + col] = acc[tt][r];
+            out[(size_t)(32 * rw + row) * H + 32 * (2 * ch + tt) + col] = acc[tt][r];
         }
 }
 
@@ -238,7 +248,7 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
     if (F == 128) {
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wgrad128), (size_t)(WGRAD_LDS)));
         nb = wg_blocks(n, 2 * TILE, WG_BLOCKS_MAX);
-        AIG_LAUNCH_TIMED(AIG_KT_WGRAD128, k_wgrad128, dim3(nb), dim3(256), WGRAD_LDS, s, (int)n, g, x, partial);
+        AIG_LAUNCH_TIMED(AIG_KT_WGRAD128, k_wgrad128, dim3(nb), dim3(512), WGRAD_LDS, s, (int)n, g, x, partial);
     } else if (F == 1) {
         nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
         hipLaunchKernelGGL(k_wgrad_small<1>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);

@@ -501,9 +501,10 @@ class Trainer:
         old = self._captured.pop(key, None)
         if old is not None:
             old.release()
-        # the generated side is recorded as well when the minibatch is small enough for the step to be bound by
-        # launch rate (an eager critic pass over it costs the host more than the GPU)
-        fake_side = self.capture_fake == "on" or (self.capture_fake == "auto" and key[0] <= 65536)
+        # the generated side is recorded as well: small minibatches are bound by launch rate (an eager critic pass
+        # over them costs the host more than the GPU), and on large ones the ~250 small launches of an eager pass
+        # still leave gaps between the wide kernels (8.7 -> 8.0 ms/step at 100k nodes)
+        fake_side = self.capture_fake in ("on", "auto")
         terms = CapturedCriticTerms(self.D, self._d_params, real_padded, cap, self.args.gp_lambda, self.device,
                                     closed_form_gp=self.closed_form_gp, fake_side=fake_side,
                                     fake_level_cap=self._fake_caps.get(key, 0))
@@ -512,6 +513,13 @@ class Trainer:
         if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
             self._captured.popitem(last=False)[1].release()
         return terms
+
+    def _outgrown(self, terms: CapturedCriticTerms, generated: Batch) -> None:
+        """The generated minibatch is deeper than the recording of the generated side holds: this step scores it
+        eagerly, the next one records anew with twice the room."""
+        key = (terms.n, terms.e_cols)
+        self._fake_caps[key] = 2 * int(generated.node_depth.max().item())
+        self._captured.pop(key, None)
 
     @property
     def edges_last_step(self) -> int:
@@ -567,7 +575,7 @@ class Trainer:
             # levels.  The levels come out of a level-by-level walk (one workgroup per graph, most of a millisecond
             # on a large graph): when the fakes are made on their own stream, the repair hands over features and
             # edges first and the walk follows, so that the main stream can go on to the penalty term meanwhile.
-            split = as_set and fakes_stream is not main_stream and not terms.fake_side
+            split = as_set and fakes_stream is not main_stream
             deferred_wait = False
             with torch.cuda.stream(fakes_stream):
                 zs_once = [self.draw_z() for _ in templates]
@@ -596,22 +604,21 @@ class Trainer:
             if terms is not None:
                 real_for_D, edges_real = terms.real_for_D, terms.edges_real
             fake_recorded = False
+            fake_pending = False     # the generated side is recorded, its inputs are loaded once the walk is through
             if split:
                 main_stream.wait_event(features_ready)
                 terms.x_fake.copy_(corr_set.x)      # all the penalty term reads of the fakes
                 deferred_wait = True                # the rest is awaited right before the critic's pass over them
+                fake_pending = terms.fake_side
             else:
                 main_stream.wait_stream(fakes_stream)
                 self._mark("fakes ready")
             if terms is not None:
                 if not split:
                     fake_recorded = terms.load_generated(fake_padded)
-                if terms.fake_side and not fake_recorded:
-                    # deeper than the recording holds: this step scores its fakes eagerly, the next one records anew
-                    key = (terms.n, terms.e_cols)
-                    self._fake_caps[key] = 2 * int(fake_padded.node_depth.max().item())
-                    self._captured.pop(key, None)
-                if fake_recorded:
+                    if terms.fake_side and not fake_recorded:
+                        self._outgrown(terms, fake_padded)
+                if fake_recorded or fake_pending:
                     for p_ in self._d_params:      # all three terms are recorded: their gradients are added
                         if p_.grad is None:        # into .grad tensors that are zeroed in place
                             p_.grad = torch.zeros_like(p_)
@@ -625,9 +632,10 @@ class Trainer:
                     # (an eager backward pass over the fakes installs its gradients as the .grad tensors - no
                     #  kernel - and the recorded terms are added to them; zeroed tensors would cost it an
                     #  accumulation launch per parameter)
-                    self.opt_D.zero_grad(set_to_none=not fake_recorded)
+                    self.opt_D.zero_grad(set_to_none=not (fake_recorded or fake_pending))
                     if terms is not None:
-                        if fake_recorded:     # the three recorded terms are independent: the generated side
+                        fake_on_side = fake_recorded and not fake_pending
+                        if fake_on_side:      # the three recorded terms are independent: the generated side
                             self.side_stream.wait_stream(main_stream)          # runs next to the other two
                             with torch.cuda.stream(self.side_stream):
                                 terms.replay_fake()
@@ -638,8 +646,22 @@ class Trainer:
                             main_stream.wait_stream(fakes_stream)
                             deferred_wait = False
                             self._mark("fakes ready")
-                        if fake_recorded:
+                        if fake_pending:
+                            # first iteration with the fakes' level walk behind the two replays above: their edge
+                            # lists and level plan are rebuilt now (one host read: does the recording hold their
+                            # depth?) and the recorded pass over them follows on this stream
+                            fake_pending = False
+                            fake_recorded = terms.load_generated(fake_padded)
+                            if fake_recorded:
+                                terms.replay_fake()
+                            else:
+                                self._outgrown(terms, fake_padded)
+                            fake_here = fake_recorded
+                        else:
+                            fake_here = False
+                        if fake_on_side:
                             main_stream.wait_stream(self.side_stream)
+                        if fake_on_side or fake_here:
                             if it == a.n_critic - 1:      # (the buffer is written again by the generator step)
                                 D_fake_mean = terms.d_fake.clone()
                             terms.add_fake_gradients()
@@ -852,8 +874,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-overlap", dest="no_overlap", action="store_true",
                    help="generate the critic's fakes on the main stream instead of underneath the real-side term")
     p.add_argument("--capture-fake", choices=["auto", "on", "off"], default="auto",
-                   help="also record the critic's pass over generated minibatches (fakes, raw graphs) as a HIP graph: "
-                        "auto = for minibatches of up to 65536 nodes, where the step is bound by launch rate")
+                   help="also record the critic's pass over generated minibatches (fakes, raw graphs) as a HIP graph "
+                        "(auto = on; off evaluates it eagerly every time)")
     p.add_argument("--no-sets", dest="no_sets", action="store_true",
                    help="run generator, repair and penalties graph by graph instead of once per minibatch")
     p.add_argument("--no-graph-capture", dest="graph_capture", action="store_false",
