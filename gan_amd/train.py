@@ -208,6 +208,55 @@ def _no_cyclic_gc():
             gc.enable()
 
 
+class _GeneratedSide:
+    """Fixed buffers for one generated minibatch (same shapes as the real one) and what the critic's recorded pass
+    over it needs: edge lists and level plan rebuilt in place by ``load``."""
+
+    def __init__(self, n: int, e_cols: int, cap: int, device: torch.device, x: torch.Tensor):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.n, self.e_cols = n, e_cols
+        self.x = x
+        self.ei = torch.full((2, e_cols), -1, dtype=torch.int64, device=device)
+        self.ea = torch.zeros((e_cols, 1), **f32)
+        self.depth = torch.full((n,), -1, dtype=torch.int64, device=device)
+        self.plan = DynLevelPlan(n, cap, device)
+        self.csr = None
+        self.for_D = Data(x=self.x, edge_index=self.ei, edge_attr=self.ea, node_depth=self.depth)
+        self.graph = None
+        self.d = None
+        self.grads = ([], [])
+
+    def load(self, batch: Batch, check: bool = True) -> bool:
+        self.x.copy_(batch.x)
+        self.load_edges(batch.edge_index, getattr(batch, "edge_attr", None))
+        return self.load_depth(getattr(batch, "node_depth", None), check)
+
+    def load_edges(self, edge_index: Optional[torch.Tensor], edge_attr: Optional[torch.Tensor]) -> None:
+        """The edge half of ``load`` (the edge lists by target / by source rebuilt in place): all it needs are the
+        minibatch's edges, which a repaired minibatch has before its level walk is through."""
+        if self.e_cols:
+            self.ei.copy_(edge_index)
+            if edge_attr is not None and edge_attr.numel() == self.e_cols:
+                self.ea.copy_(edge_attr.reshape(-1, 1))
+            else:
+                self.ea.zero_()
+            if self.csr is None:
+                self.csr = GraphCSR(self.ei, self.ea, self.n)
+                self.for_D._csr = self.csr
+            else:
+                self.csr.rebuild(self.ei, self.ea)
+
+    def load_depth(self, node_depth: Optional[torch.Tensor], check: bool = True) -> bool:
+        """The level half of ``load``; with ``check``, one host read: does the recording hold this many levels?"""
+        if node_depth is not None:
+            self.depth.copy_(node_depth)
+        else:
+            self.depth.zero_()
+        self.plan.rebuild(self.depth)
+        self.for_D._plan = self.plan
+        return not (check and self.plan.overflowed())
+
+
 class CapturedCriticTerms:
     """``-mean(D(real))`` and ``gp_lambda * GP`` with their gradients w.r.t. the critic's parameters,
     recorded ONCE PER MINIBATCH SHAPE as HIP graphs and replayed for every minibatch of that shape.
@@ -233,7 +282,7 @@ class CapturedCriticTerms:
 
     def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], example: Batch, level_cap: int,
                  gp_lambda: float, device: torch.device, closed_form_gp: bool = True, fake_side: bool = False,
-                 fake_level_cap: int = 0):
+                 fake_level_cap: int = 0, raw_side: bool = False):
         n = int(example.x.size(0))
         e_cols = 0 if example.edge_index is None else int(example.edge_index.size(1))
         self.n, self.e_cols, self.level_cap = n, e_cols, int(level_cap)
@@ -257,14 +306,16 @@ class CapturedCriticTerms:
         # raw graphs - same shapes as the real minibatch) and its gradient, over buffers of its own
         self.fake_side = bool(fake_side)
         self.fake_cap = max(int(fake_level_cap), self.level_cap)
+        # ... and, with ``raw_side``, a second set for the generator step's raw graphs, so that they can be made and
+        # loaded while the critic iterations still replay over the first (their levels are the templates': no
+        # deeper than the real minibatch's)
+        self.fk = self.rw = None
         if self.fake_side:
-            self.ei_f = torch.full((2, e_cols), -1, dtype=torch.int64, device=device)
-            self.ea_f = torch.zeros((e_cols, 1), **f32)
-            self.depth_f = torch.full((n,), -1, dtype=torch.int64, device=device)
-            self.plan_f = DynLevelPlan(n, self.fake_cap, device)
-            self.csr_f = None
-            self.fake_for_D = Data(x=self.x_fake, edge_index=self.ei_f, edge_attr=self.ea_f, node_depth=self.depth_f)
-            self.load_generated(example, check=False)
+            self.fk = _GeneratedSide(n, e_cols, self.fake_cap, device, self.x_fake)
+            self.fk.load(example, check=False)
+            if raw_side:
+                self.rw = _GeneratedSide(n, e_cols, self.fake_cap, device, torch.zeros((n, 2), **f32))
+                self.rw.load(example, check=False)
 
         def compute_real():
             d_real = mean_score(D, self.real_for_D)
@@ -280,9 +331,9 @@ class CapturedCriticTerms:
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha, plan=self.plan)
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
-        def compute_fake():
-            d_fake = mean_score(D, self.fake_for_D)
-            return d_fake.detach(), torch.autograd.grad(d_fake, params, allow_unused=True)
+        def compute_side(side):
+            d_side = mean_score(D, side.for_D)
+            return d_side.detach(), torch.autograd.grad(d_side, params, allow_unused=True)
 
         self._compute_gp = compute_gp
         cur = torch.cuda.current_stream(device)
@@ -292,8 +343,9 @@ class CapturedCriticTerms:
             for _ in range(2):
                 compute_real()
                 compute_gp()
-                if self.fake_side:
-                    compute_fake()
+                for side_ in (self.fk, self.rw):
+                    if side_ is not None:
+                        compute_side(side_)
         cur.wait_stream(side)
         torch.cuda.synchronize(device)
         # thread-local capture: a communicator's watchdog thread may query events while we record.  The cyclic
@@ -310,19 +362,22 @@ class CapturedCriticTerms:
             with _no_cyclic_gc(), torch.cuda.graph(self.graph_gp, capture_error_mode="thread_local"):
                 self.gp, self.grad_norm, grads_gp = compute_gp()
             self._grads_gp = self._present(grads_gp)
-        self.graph_fake = None
-        if self.fake_side:
-            self.graph_fake = torch.cuda.CUDAGraph()
-            with _no_cyclic_gc(), torch.cuda.graph(self.graph_fake, capture_error_mode="thread_local"):
-                self.d_fake, grads_fake = compute_fake()
-            self._grads_fake = self._present(grads_fake)
+        for side_ in (self.fk, self.rw):
+            if side_ is not None:
+                side_.graph = torch.cuda.CUDAGraph()
+                with _no_cyclic_gc(), torch.cuda.graph(side_.graph, capture_error_mode="thread_local"):
+                    side_.d, grads_side = compute_side(side_)
+                side_.grads = self._present(grads_side)
 
     def release(self) -> None:
         """Drop the recordings and what refers back to this object now (called when a recording is replaced),
         instead of whenever the cyclic collector gets to it."""
-        self.graph_real = self.graph_gp = self.graph_fake = None
+        self.graph_real = self.graph_gp = None
         self._compute_gp = None
-        self._grads_real = self._grads_gp = self._grads_fake = ([], [])
+        self._grads_real = self._grads_gp = ([], [])
+        for side_ in (self.fk, self.rw):
+            if side_ is not None:
+                side_.graph, side_.grads = None, ([], [])
 
     def _present(self, grads):
         """(parameters, gradients) of the parameters a term reaches."""
@@ -357,43 +412,37 @@ class CapturedCriticTerms:
             count = batch._edge_count = count_edges(batch.edge_index)
         self.edges_real = count
 
+    # the critic's fakes (their features are also what the penalty term reads: ``x_fake``)
+    plan_f = property(lambda self: self.fk.plan)
+    csr_f = property(lambda self: self.fk.csr)
+    fake_for_D = property(lambda self: self.fk.for_D)
+    d_fake = property(lambda self: self.fk.d)
+
     def load_generated(self, batch: Batch, check: bool = True) -> bool:
         """Make ``batch`` (same shapes as the real minibatch) the input of the following ``replay_fake``: four
         copies, its edge lists and level plan rebuilt in place.  With ``check``, one host read tells whether its
         deepest level fits the recording (the same read the eager path spends on sizing its level plan); on
         False the caller evaluates this minibatch eagerly."""
-        self.x_fake.copy_(batch.x)
         if not self.fake_side:
+            self.x_fake.copy_(batch.x)
             return False
-        if self.e_cols:
-            self.ei_f.copy_(batch.edge_index)
-            ea = getattr(batch, "edge_attr", None)
-            if ea is not None and ea.numel() == self.e_cols:
-                self.ea_f.copy_(ea.reshape(-1, 1))
-            else:
-                self.ea_f.zero_()
-            if self.csr_f is None:
-                self.csr_f = GraphCSR(self.ei_f, self.ea_f, self.n)
-                self.fake_for_D._csr = self.csr_f
-            else:
-                self.csr_f.rebuild(self.ei_f, self.ea_f)
-        nd = getattr(batch, "node_depth", None)
-        if nd is not None:
-            self.depth_f.copy_(nd)
-        else:
-            self.depth_f.zero_()
-        self.plan_f.rebuild(self.depth_f)
-        self.fake_for_D._plan = self.plan_f
-        return not (check and self.plan_f.overflowed())
+        return self.fk.load(batch, check)
 
     def replay_real(self) -> None:
         self.graph_real.replay()
 
     def replay_fake(self) -> None:
-        self.graph_fake.replay()
+        self.fk.graph.replay()
 
     def add_fake_gradients(self, sign: float = 1.0) -> None:
-        ps, gs = self._grads_fake
+        ps, gs = self.fk.grads
+        torch._foreach_add_([p.grad for p in ps], gs, alpha=sign)
+
+    def replay_raw(self) -> None:
+        self.rw.graph.replay()
+
+    def add_raw_gradients(self, sign: float = 1.0) -> None:
+        ps, gs = self.rw.grads
         torch._foreach_add_([p.grad for p in ps], gs, alpha=sign)
 
     def replay_gp(self, alpha: torch.Tensor) -> None:
@@ -447,6 +496,9 @@ class Trainer:
         # the structural penalties only need the raw graphs and their latency-bound traversals keep
         # one CU busy: they run on a second stream underneath the critic pass of the generator step
         self.side_stream = torch.cuda.Stream(device=device)
+        # ... and the generator step's raw graphs (which depend on nothing the critic iterations compute) are
+        # made, padded and loaded into their recording's buffers on a third stream underneath those iterations
+        self.raw_stream = self.side_stream
         # ... and so do the critic's fakes (generator pass and repair), underneath the recorded
         # real-side term of the first critic iteration
         self.overlap_fakes = not bool(getattr(args, "no_overlap", False))
@@ -507,7 +559,8 @@ class Trainer:
         fake_side = self.capture_fake in ("on", "auto")
         terms = CapturedCriticTerms(self.D, self._d_params, real_padded, cap, self.args.gp_lambda, self.device,
                                     closed_form_gp=self.closed_form_gp, fake_side=fake_side,
-                                    fake_level_cap=self._fake_caps.get(key, 0))
+                                    fake_level_cap=self._fake_caps.get(key, 0),
+                                    raw_side=fake_side and self.overlap_fakes and self.use_sets)
         self.captures += 1
         self._captured[key] = terms
         if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
@@ -529,9 +582,10 @@ class Trainer:
     def _pad_batch(self, graphs: List[Data]) -> Batch:
         return Batch.from_data_list([pad_data(g, self.max_nodes, self.max_edges) for g in graphs]).to(self.device)
 
-    def _pad_set(self, gset: GraphSet) -> Batch:
-        """``_pad_batch(gset.graphs())`` in one launch (the graphs already have ``max_nodes`` nodes each)."""
-        ei, ea = pad_set(gset, self.max_edges)
+    def _pad_set(self, gset: GraphSet, edges=None) -> Batch:
+        """``_pad_batch(gset.graphs())`` in one launch (the graphs already have ``max_nodes`` nodes each);
+        ``edges``: the padded edge tensors when the caller has made them already."""
+        ei, ea = pad_set(gset, self.max_edges) if edges is None else edges
         nd = gset.node_depth
         if nd is None:
             nd = torch.zeros(gset.B * gset.n, dtype=torch.long, device=self.device)    # pad_data: depth 0 when absent
@@ -581,11 +635,32 @@ class Trainer:
                 zs_once = [self.draw_z() for _ in templates]
                 if split:
                     raw_fakes_set = G.forward_set(templates, torch.stack(zs_once))
+            if split and not real_first:
+                # The host enqueues the real side right behind the generator pass (half a millisecond of GPU
+                # work) and the repair's ~150 small launches after that: enqueued in front of the real side they
+                # kept the host busy for longer than the generator pass runs, and the first stream idle meanwhile.
+                terms.load(real_padded)
+                terms.replay_real()       # the first iteration's real-side term runs next to the fakes
+                real_replayed = True
+            finish_fakes = None
+            with torch.cuda.stream(fakes_stream):
+                if split:
                     corr_set = enforce_set(raw_fakes_set, want_depth=False)
                     features_ready = torch.cuda.Event()
                     features_ready.record()
-                    corr_set.node_depth = clean_depth_set(raw_fakes_set)
-                    fake_padded = self._pad_set(corr_set)
+
+                    def finish_fakes():
+                        # the level walk behind the fakes' depths and the padded minibatch: enqueued by the first
+                        # critic iteration AFTER its penalty term (host order: the penalty term only waits for
+                        # the features, and the walk's set-up is dozens of small launches)
+                        with torch.cuda.stream(fakes_stream):
+                            edges = pad_set(corr_set, self.max_edges)
+                            ready = torch.cuda.Event()
+                            ready.record()        # the critic's edge lists of the fakes can be built from here on
+                            corr_set.node_depth = clean_depth_set(raw_fakes_set)
+                            padded = self._pad_set(corr_set, edges)
+                            return padded, count_edges(padded.edge_index), ready
+                    fake_padded = None
                 elif as_set:
                     # generator, repair and padding for the whole minibatch: a dozen launches, no host read
                     fake_padded = self._pad_set(enforce_set(G.forward_set(templates, torch.stack(zs_once))))
@@ -596,8 +671,8 @@ class Trainer:
                     corr_fakes_once = [enforce_finish(h) for h in repairs]
                     fake_padded = self._pad_batch(corr_fakes_once)
                 fake_for_D = fake_padded
-                edges_fake = count_edges(fake_padded.edge_index)
-            if not real_first:
+                edges_fake = count_edges(fake_padded.edge_index) if fake_padded is not None else None
+            if not real_first and not real_replayed:
                 terms.load(real_padded)
                 terms.replay_real()       # the first iteration's real-side term runs next to the fakes
                 real_replayed = True
@@ -626,6 +701,21 @@ class Trainer:
             if self.world == 1:
                 raise
             failed = e
+        # The generator step's inputs early: with a recording of their own for the raw graphs (``terms.rw``), the
+        # generator pass, the padded minibatch, its edge lists and level plan and the structural penalties are
+        # enqueued on a third stream right after the first critic iteration and run underneath the other
+        # iterations; the generator step is then one replay.  The draws keep the order of train.py:241-276
+        # (z of the fakes, one alpha per critic iteration, z of the raw graphs).
+        early_raw = (failed is None and terms is not None and terms.rw is not None and as_set
+                     and terms is self._captured.get((terms.n, terms.e_cols)))
+        alphas = zs = None
+        raw_set = loss_pen = raw_loaded = None
+        if early_raw:
+            alphas = [self.draw_alpha() for _ in range(a.n_critic)]
+            zs = [self.draw_z() for _ in templates]
+            step_start = torch.cuda.Event()
+            step_start.record(main_stream)       # (what the third stream writes was last read before this point)
+        raw_from = min(1, a.n_critic - 1)    # from this iteration on the second stream belongs to the raw graphs
         for it in range(a.n_critic):
             if failed is None:
                 try:
@@ -634,29 +724,47 @@ class Trainer:
                     #  accumulation launch per parameter)
                     self.opt_D.zero_grad(set_to_none=not (fake_recorded or fake_pending))
                     if terms is not None:
-                        fake_on_side = fake_recorded and not fake_pending
+                        # (once the raw graphs' pipeline occupies the second stream, the recorded pass over the
+                        #  fakes follows the other two terms on this one)
+                        raw_turn = early_raw and it >= raw_from
+                        fake_on_side = fake_recorded and not fake_pending and not raw_turn
+                        fake_after = fake_recorded and not fake_pending and raw_turn
                         if fake_on_side:      # the three recorded terms are independent: the generated side
                             self.side_stream.wait_stream(main_stream)          # runs next to the other two
                             with torch.cuda.stream(self.side_stream):
                                 terms.replay_fake()
                         if not (it == 0 and real_replayed):
                             terms.replay_real()
-                        terms.replay_gp(self.draw_alpha())
+                        terms.replay_gp(alphas[it] if alphas is not None else self.draw_alpha())
+                        edges_ready = None
+                        if finish_fakes is not None:
+                            fake_padded, edges_fake, edges_ready = finish_fakes()
+                            fake_for_D, finish_fakes = fake_padded, None
+                        if fake_pending and edges_ready is not None:
+                            # the fakes' edge lists are rebuilt while their level walk is still under way
+                            main_stream.wait_event(edges_ready)
+                            terms.fk.load_edges(fake_padded.edge_index, fake_padded.edge_attr)
                         if deferred_wait:
                             main_stream.wait_stream(fakes_stream)
                             deferred_wait = False
                             self._mark("fakes ready")
                         if fake_pending:
-                            # first iteration with the fakes' level walk behind the two replays above: their edge
-                            # lists and level plan are rebuilt now (one host read: does the recording hold their
-                            # depth?) and the recorded pass over them follows on this stream
+                            # first iteration with the fakes' level walk behind the two replays above: their
+                            # level plan is rebuilt now (one host read: does the recording hold their depth?)
+                            # and the recorded pass over them follows on this stream
                             fake_pending = False
-                            fake_recorded = terms.load_generated(fake_padded)
+                            if edges_ready is not None:
+                                fake_recorded = terms.fk.load_depth(fake_padded.node_depth)
+                            else:
+                                fake_recorded = terms.load_generated(fake_padded)
                             if fake_recorded:
                                 terms.replay_fake()
                             else:
                                 self._outgrown(terms, fake_padded)
                             fake_here = fake_recorded
+                        elif fake_after:
+                            terms.replay_fake()
+                            fake_here = True
                         else:
                             fake_here = False
                         if fake_on_side:
@@ -698,6 +806,22 @@ class Trainer:
                     failed = e
             if self.reducer.reduce(failed is None):
                 self.opt_D.step()
+        if failed is None and early_raw:
+            # Host order: behind the replays of every critic iteration (cheap to enqueue), so the first stream has
+            # its work queued while the host issues the ~100 small launches of the raw graphs' pipeline; on the
+            # GPU the second stream has been free since iteration ``raw_from`` and starts on them at once.
+            try:
+                self.raw_stream.wait_event(step_start)
+                with torch.cuda.stream(self.raw_stream):
+                    raw_set = G.forward_set(templates, torch.stack(zs))
+                    terms.rw.load(self._pad_set(raw_set), check=False)
+                    raw_loaded = torch.cuda.Event()
+                    raw_loaded.record()
+                    loss_pen = penalties_set(raw_set)[:, 8].mean()
+            except Exception as e:
+                if self.world == 1:
+                    raise
+                failed = e
         if failed is not None:
             raise failed
         self._edges_last = edges_fake + edges_real
@@ -705,25 +829,34 @@ class Trainer:
         # ---- generator (train.py:275-299); its output carries no gradient, so backward only touches D
         self._mark("critic done")
         self.opt_G.zero_grad()
-        zs = [self.draw_z() for _ in templates]
-        if as_set:
-            raw_set = G.forward_set(templates, torch.stack(zs))
-            raw_gen = None        # the separate graphs are only made when a save step asks for them
+        early_raw = early_raw and raw_set is not None
+        pen_stream = self.raw_stream if early_raw else self.side_stream
+        if early_raw:
+            raw_gen = None
         else:
-            raw_gen = [G(t, z) for t, z in zip(templates, zs)]
-        self.side_stream.wait_stream(main_stream)
-        with torch.cuda.stream(self.side_stream):
+            zs = [self.draw_z() for _ in templates]
             if as_set:
-                loss_pen = penalties_set(raw_set)[:, 8].mean()
+                raw_set = G.forward_set(templates, torch.stack(zs))
+                raw_gen = None        # the separate graphs are only made when a save step asks for them
             else:
-                pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
-                loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
-        raw_batch_for_D = self._pad_set(raw_set) if as_set else self._pad_batch(raw_gen)
+                raw_gen = [G(t, z) for t, z in zip(templates, zs)]
+            self.side_stream.wait_stream(main_stream)
+            with torch.cuda.stream(self.side_stream):
+                if as_set:
+                    loss_pen = penalties_set(raw_set)[:, 8].mean()
+                else:
+                    pen_terms = [aig_constraint_penalties(r) for r in raw_gen]
+                    loss_pen = torch.stack([pt["total"] for pt in pen_terms]).mean()
+            raw_batch_for_D = self._pad_set(raw_set) if as_set else self._pad_batch(raw_gen)
         # the generator hands the template's depths through unchanged (generator.py:211-217) and the templates
         # are the real minibatch's graphs, so the padded depth vector of the raw batch is the real batch's: no
         # deeper than the recordings hold, and the eager pass can reuse the level plan rebuilt for this step
         raw_recorded = terms is not None and terms.fake_side and terms is self._captured.get((terms.n, terms.e_cols))
-        if raw_recorded:
+        if early_raw:
+            main_stream.wait_event(raw_loaded)
+            terms.replay_raw()
+            loss_G_adv = -terms.rw.d.clone()
+        elif raw_recorded:
             terms.load_generated(raw_batch_for_D, check=False)
             terms.replay_fake()
             loss_G_adv = -terms.d_fake.clone()
@@ -735,7 +868,7 @@ class Trainer:
             # are integers and copies), so the gradient of loss_G is the gradient of its adversarial term, and
             # the penalties' level walks run underneath the backward pass as well
             loss_G_adv.backward()
-        main_stream.wait_stream(self.side_stream)
+        main_stream.wait_stream(pen_stream)
         loss_pen.record_stream(main_stream)
         if (self.global_step % a.save_every) == 0:
             if raw_gen is None:
@@ -743,9 +876,11 @@ class Trainer:
             scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
             loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
         loss_G = loss_G_adv.detach() + a.lambda_cons * loss_pen
-        if raw_recorded:
+        if early_raw:
             # loss_G.backward(): only the critic's parameters receive a gradient (train.py:297-299) - the
             # recorded gradient of D(raw), negated
+            terms.add_raw_gradients(sign=-1.0)
+        elif raw_recorded:
             terms.add_fake_gradients(sign=-1.0)
         self.opt_G.step()
         self.last.update(loss_G=loss_G.detach(), pen=loss_pen.detach())
