@@ -361,6 +361,21 @@ extern "C" int aig_gp_forward(int64_t n, const float* x_real, const float* x_fak
     return aig_linear128(n, h1, W2, 0, b2, 2, h2, stream);
 }
 
+__global__ void k_gp_scalars(const float* __restrict__ norm_sq, float scale, float* __restrict__ out3) {
+    const float norm = sqrtf(norm_sq[0]);
+    const float d = norm - 1.0f;
+    out3[0] = norm;
+    out3[1] = d * d;
+    out3[2] = norm > 0.f ? scale * (2.0f * d / norm) : 0.f;
+}
+
+extern "C" int aig_gp_scalars(const float* norm_sq, float scale, float* out3, void* stream) {
+    AIG_REQUIRE(norm_sq && out3, "aig_gp_scalars: null pointer");
+    hipLaunchKernelGGL(k_gp_scalars, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), norm_sq, scale, out3);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
 extern "C" size_t aig_gp_input_grad_ws_bytes(int64_t n) {
     (void)n;
     return align_up((size_t)GP_BLOCKS_MAX * 4) + 256;

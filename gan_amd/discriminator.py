@@ -471,14 +471,15 @@ class AIGDiscriminator(nn.Module):
         return self._lvl_cache.lookup(key, lambda: (LevelPlan(node_depth, n, device), node_depth))[0]
 
     def gradient_penalty_closed_form(self, x_real: torch.Tensor, x_fake: torch.Tensor, alpha: torch.Tensor,
-                                     node_depth: Optional[torch.Tensor], plan=None):
+                                     node_depth: Optional[torch.Tensor], plan=None, grad_scale: float = 1.0):
         """``gradient_penalty(use_edges=False)`` of train.py:133-152 and its gradient w.r.t. the critic's
         parameters without autograd on the node tensors: on an empty edge list each attention layer
         is ``elu(x W^T + b)``, which makes the penalty a closed form (four [n,128]x[128,128]
         products, three node-dimension weight gradients, a few row-wise passes; the head's input
         gradient and its second-order share come from the head kernels).  Returns ``(gp, grad_norm, grads)`` with ``grads`` a dict
         parameter -> gradient of ``gp`` (parameters the edge-free pass never touches are absent).  ``plan``: a
-        level plan of ``node_depth`` the caller already holds (else it is looked up / built here)."""
+        level plan of ``node_depth`` the caller already holds (else it is looked up / built here); ``grad_scale``
+        multiplies every returned gradient (the loss weights the penalty by gp_lambda)."""
         lib = _abi.lib()
         dev = x_real.device
         n = int(x_real.size(0))
@@ -521,11 +522,12 @@ class AIGDiscriminator(nn.Module):
                                          _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(h1), _abi.ptr(h2),
                                          _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(norm_sq),
                                          _abi.ptr(ws), ws.numel(), st), "aig_gp_input_grad")
-        norm = torch.sqrt(norm_sq[0])
-        gp = (norm - 1.0) ** 2
-        # d gp / d g_x = coef * g_x; at norm = 0 autograd's torch.norm has the zero subgradient (train.py:150), so
-        # the penalty's gradient vanishes there instead of becoming 0 * inf (decided on the device, no host read)
-        coef = torch.where(norm > 0, 2.0 * (norm - 1.0) / norm, torch.zeros_like(norm)).reshape(1).contiguous()
+        # norm, gp = (norm - 1)^2 and coef = grad_scale * d gp / d norm / norm in one launch.  d gp / d g_x =
+        # coef * g_x; at norm = 0 autograd's torch.norm has the zero subgradient (train.py:150), so the penalty's
+        # gradient vanishes there instead of becoming 0 * inf (decided on the device, no host read)
+        sc = torch.empty(3, **f32)
+        _abi.check(lib.aig_gp_scalars(_abi.ptr(norm_sq), float(grad_scale), _abi.ptr(sc), st), "aig_gp_scalars")
+        norm, gp, coef = sc[0], sc[1], sc[2:3]
         dW1, db1 = torch.empty((HIDDEN, 2), **f32), torch.empty(HIDDEN, **f32)
         dW2, db2 = torch.empty((HIDDEN, HIDDEN), **f32), torch.empty(HIDDEN, **f32)
         u_gr = torch.empty((1, 2 * HIDDEN), **f32)

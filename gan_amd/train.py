@@ -325,6 +325,8 @@ class CapturedCriticTerms:
             if closed_form_gp:
                 gp, gn, gp_grads = D.gradient_penalty_closed_form(self.x_real, self.x_fake, self.alpha, self.depth,
                                                                   plan=self.plan)
+                # (scaled after the fact, not through ``grad_scale``: the same roundings as lambda * autograd's
+                #  gradient - Adam turns a last-bit difference in a near-zero gradient element into a full step)
                 scaled = dict(zip([p for p in params if p in gp_grads],
                                   torch._foreach_mul([gp_grads[p] for p in params if p in gp_grads], gp_lambda)))
                 return gp, gn, [scaled.get(p) for p in params]

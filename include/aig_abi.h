@@ -285,8 +285,11 @@ int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_meta, const 
  *   aig_gp_forward     x^ = alpha x_real + (1-alpha) x_fake [n,2]; h1 = elu(x^ W1^T + b1); h2 = elu(h1 W2^T + b2)
  *                      (the caller runs aig_level_pool_fwd on h2 and its own head, and hands back g_r = ds/dr [256])
  *   aig_gp_input_grad  g_z2 = (readout^T g_r) * elu'(z2); g_h1 = g_z2 W2; g_z1 = g_h1 * elu'(z1); g_x = g_z1 W1 [n,2];
- *                      *norm_sq = sum g_x^2      (the caller forms gp = (sqrt(norm_sq) - 1)^2 and
- *                      coef = d gp / d norm / norm = 2 (norm - 1) / norm)
+ *                      *norm_sq = sum g_x^2
+ *   aig_gp_scalars     out3 = {norm = sqrt(norm_sq), gp = (norm - 1)^2, coef = scale * 2 (norm - 1) / norm}: the last
+ *                      lines of train.py:150-151 and the factor d gp / d norm / norm every parameter gradient of gp
+ *                      carries, times the caller's scale (gp_lambda); coef = 0 at norm = 0 (the zero subgradient
+ *                      torch.norm has there).  One launch instead of ten scalar ones
  *   aig_gp_param_grad  gradient of gp w.r.t. W1 [128,2], b1, W2 [128,128], b2 and ubar_gr = d gp / d g_r [256]
  *                      (the caller back-propagates ubar_gr through its head to get the head's weight gradients).
  * W1/b1 = gat1.lin.weight / gat1.bias, W2/b2 = gat2.lin.weight / gat2.bias; alpha, norm_sq, coef are device scalars;
@@ -294,6 +297,7 @@ int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_meta, const 
  * ------------------------------------------------------------------------------------------- */
 int aig_gp_forward(int64_t n, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
                    const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2, void* stream);
+int aig_gp_scalars(const float* norm_sq, float scale, float* out3, void* stream);
 size_t aig_gp_input_grad_ws_bytes(int64_t n);
 int aig_gp_input_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g_r, const int32_t* node_level,
                       const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1, const float* h2,
