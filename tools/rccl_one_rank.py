@@ -31,8 +31,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    opts = None
+    if os.environ.get("NCCL_HIGH_PRIO"):
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
     dist.init_process_group(backend="nccl", rank=int(os.environ.get("RANK", "0")),
-                            world_size=int(os.environ.get("WORLD_SIZE", "1")))
+                            world_size=int(os.environ.get("WORLD_SIZE", "1")), pg_options=opts)
     assert dist.get_world_size() == 1
     n_and = int(os.environ.get("N_AND", "98000"))
     graphs = [synth_aig(1000, n_and, 1000, seed=s, window=4096, orientation="dataset") for s in range(4)]
@@ -71,6 +74,24 @@ def main():
         return ms, w, last
 
     steps = int(os.environ.get("STEPS", "12"))
+    only = os.environ.get("ONLY")          # "plain" / "coll": one configuration per process (no cross-talk)
+    if only:
+        variant = os.environ.get("VARIANT", "")
+        if variant == "no_allreduce":          # pack / scale / unpack only
+            dist.all_reduce = lambda *a, **k: None
+        elif variant == "allreduce_only":      # the collective alone, on the flat buffer as it is
+            from gan_amd import parallel as _par
+
+            def only_collective(self, ok=True):
+                if self.world == 1:
+                    return ok
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                return True
+            _par.FlatGradAllReduce.reduce = only_collective
+        ms, _, _ = run(only == "coll", steps)
+        print(json.dumps({"mode": only, "ms_per_step": round(ms, 3)}))
+        dist.destroy_process_group()
+        return
     ms_coll0, _, _ = run(True, steps)
     ms_plain, w_plain, last_plain = run(False, steps)
     ms_coll, w_coll, last_coll = run(True, steps)
