@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o p -- python3 bench.py --no-kernel-timing --no-cpu-baseline --no-side-workloads --sample-iters 1 > /tmp/tr.log 2>&1 || { tail -5 /tmp/tr.log; exit 1; }
-python3 tools/step_trace.py /tmp/tr 16 17 3 16 1 250 | grep "  w t=\|step "
+python3 tools/step_trace.py /tmp/tr 16 17 3 16 1 250 0 2400 | grep "  d t=\|step "
