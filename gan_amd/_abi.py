@@ -88,6 +88,8 @@ SIGNATURES = {
     "aig_validate": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
     "aig_resync_ws_bytes": (SZ, [I64, I64]),
     "aig_resync": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
+    "aig_resync_typed_ws_bytes": (SZ, [I64, I64]),
+    "aig_resync_typed": (INT, [I64, I64, P, P, P, P, P, P, SZ, P]),
     "aig_kernel_timing": (INT, [C.c_uint]),
     "aig_kernel_timing_read": (INT, [INT, P, P]),
     "aig_kernel_timing_name": (C.c_char_p, [INT]),
@@ -102,6 +104,8 @@ SIGNATURES = {
     "aig_penalties_batch": (INT, [I64, I64, I64, P, P, P, P, P, SZ, P]),
     "aig_resync_batch_ws_bytes": (SZ, [I64, I64, I64]),
     "aig_resync_batch": (INT, [I64, I64, I64, P, P, P, P, P, P, SZ, P]),
+    "aig_resync_typed_batch_ws_bytes": (SZ, [I64, I64, I64]),
+    "aig_resync_typed_batch": (INT, [I64, I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_pad_batch": (INT, [I64, I64, I64, P, P, P, I64, P, P, P]),
 }
 

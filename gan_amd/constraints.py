@@ -251,9 +251,17 @@ def resync_attrs(d: Data) -> Data:
         return d
     inv_cnt = torch.empty(n, dtype=torch.int64, device=dev)
     depth = torch.empty(n, dtype=torch.int64, device=dev)
-    ws = _abi.workspace(lib.aig_resync_ws_bytes(n, E), dev)
-    _abi.check(lib.aig_resync(n, E, _abi.ptr(ei), _abi.ptr(_inv64(d, E)), _abi.ptr(inv_cnt), _abi.ptr(depth),
-                              _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync")
+    x = d.x
+    if x.dtype == torch.float32 and x.size(1) == 2 and x.is_contiguous():
+        # with the node types at hand a graph whose edges all run upward in PI / AND / PO order (a repaired one)
+        # gets its levels from a sweep over that order; any other graph from the level walk, as without x
+        ws = _abi.workspace(lib.aig_resync_typed_ws_bytes(n, E), dev)
+        _abi.check(lib.aig_resync_typed(n, E, _abi.ptr(x), _abi.ptr(ei), _abi.ptr(_inv64(d, E)), _abi.ptr(inv_cnt),
+                                        _abi.ptr(depth), _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync_typed")
+    else:
+        ws = _abi.workspace(lib.aig_resync_ws_bytes(n, E), dev)
+        _abi.check(lib.aig_resync(n, E, _abi.ptr(ei), _abi.ptr(_inv64(d, E)), _abi.ptr(inv_cnt), _abi.ptr(depth),
+                                  _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync")
     d.x[:, 1] = inv_cnt
     d.node_depth = depth
     return d
@@ -328,10 +336,16 @@ def resync_set(gs: GraphSet) -> GraphSet:
     N = gs.B * gs.n
     inv_cnt = torch.empty(N, dtype=torch.int64, device=dev)
     depth = torch.empty(N, dtype=torch.int64, device=dev)
-    ws = _abi.workspace(lib.aig_resync_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
-    _abi.check(_abi.timed("aig_resync_batch", lib.aig_resync_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
-                          _abi.ptr(gs.edge_index), _abi.ptr(gs.edge_attr), _abi.ptr(inv_cnt), _abi.ptr(depth),
-                          _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync_batch")
+    if gs.x.dtype == torch.float32 and gs.x.dim() == 2 and gs.x.size(1) == 2 and gs.x.is_contiguous():
+        ws = _abi.workspace(lib.aig_resync_typed_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
+        _abi.check(_abi.timed("aig_resync_batch", lib.aig_resync_typed_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
+                              _abi.ptr(gs.x), _abi.ptr(gs.edge_index), _abi.ptr(gs.edge_attr), _abi.ptr(inv_cnt),
+                              _abi.ptr(depth), _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync_typed_batch")
+    else:
+        ws = _abi.workspace(lib.aig_resync_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
+        _abi.check(_abi.timed("aig_resync_batch", lib.aig_resync_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
+                              _abi.ptr(gs.edge_index), _abi.ptr(gs.edge_attr), _abi.ptr(inv_cnt), _abi.ptr(depth),
+                              _abi.ptr(ws), ws.numel(), _abi.stream()), "aig_resync_batch")
     gs.x[:, 1] = inv_cnt
     gs.node_depth = depth
     return gs

@@ -160,12 +160,14 @@ struct TravJob {
 };
 struct TravJobs {
     TravJob j[2];
+    const int* gate;   // per graph of a set: walk the graph only when gate[graph] != 0 (null: always)
 };
 
 // A set of graphs is walked by one block per graph (blockIdx.y; no edge leaves a graph): block (job, g)
 // owns the n nodes from g n on, ids in queues and adjacency lists stay ids of the whole set.
 template <int MODE>
 __global__ __launch_bounds__(TRAV_THREADS) void k_traverse(int n, TravJobs jobs) {
+    if (jobs.gate && jobs.gate[blockIdx.y] == 0) return;   // (uniform over the block, before any barrier)
     const TravJob jb = jobs.j[blockIdx.x];
     const int base = blockIdx.y * n;
     const int* __restrict__ ptr = jb.ptr;
@@ -351,6 +353,7 @@ template <int MODE>
 __global__ __launch_bounds__(TRAV_THREADS) void k_traverse_lds(int n, TravJobs jobs, const int4* __restrict__ rec0,
                                                                const int4* __restrict__ rec1) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
+    if (jobs.gate && jobs.gate[blockIdx.y] == 0) return;   // (uniform over the block, before any barrier)
     const TravJob jb = jobs.j[blockIdx.x];
     const int base = blockIdx.y * n;   // one block per graph of a set, see k_traverse
     const int4* __restrict__ rec = blockIdx.x ? rec1 : rec0;
@@ -574,10 +577,15 @@ struct SweepTile {
 // A tile is SWEEP_PT positions per thread: what a tile costs is mostly the memory latency that shows between two
 // tiles (a barrier waits for the requests made ahead), so fewer, larger tiles - the relaxation inside a tile runs
 // at LDS speed.
-__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_min(GraphSet gs, const int* __restrict__ tptr,
-                                                            const int* __restrict__ tsrc, const int* __restrict__ seed,
-                                                            int* __restrict__ dpos) {
-    __shared__ int ring[SWEEP_RING];
+// MODE 0: breadth-first level from the seeds (min over the predecessors that have a level).  MODE 1: longest-path
+// level (0 without predecessors, else 1 + max over the predecessors; `seed` unused) - levels only ever INCREASE in
+// the relaxation there.  `gate` (may be null): a graph is swept only when gate[graph] == 0.
+template <int MODE>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, const int* __restrict__ tptr,
+                                                        const int* __restrict__ tsrc, const int* __restrict__ seed,
+                                                        int* __restrict__ dpos, const int* __restrict__ gate) {
+    if (gate && gate[blockIdx.x] != 0) return;
+    __shared__ int ring[SWEEP_RING + 1];   // the last slot: a neutral level for "no predecessor"
     __shared__ int flag[2];
     volatile int* ring_v = ring;     // (the rounds between two barriers must re-read LDS)
     const int n = gs.n, base = blockIdx.x * gs.n, tid = threadIdx.x;
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_min(GraphSet gs, const 
             const int p = t * SWEEP_T + j * SWEEP_THREADS + tid;
             const bool live = t < ntiles && p < n;
             const int pc = base + (live ? p : 0);
-            const int lo = tptr[pc], hi = tptr[pc + 1], sd = seed[pc];
+            const int lo = tptr[pc], hi = tptr[pc + 1], sd = MODE == 0 ? seed[pc] : SWEEP_NONE;
             nd.lo = live ? lo : 0;
             nd.hi = live ? hi : 0;
             nd.seed = live ? sd : SWEEP_NONE;
@@ -624,12 +632,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_min(GraphSet gs, const 
 #pragma unroll
             for (int k = 0; k < SWEEP_INL; ++k) {
                 const int q = tl.nd[j].q[k];
-                tl.nd[j].dq[k] = q >= 0 && q < window_lo ? old[j][k] : SWEEP_NONE;
+                tl.nd[j].dq[k] = q >= 0 && q < window_lo ? old[j][k] : (MODE == 0 ? SWEEP_NONE : -1);
             }
     };
     SweepTile cur, nxt, nn;
     int par = 0;
     if (tid < 2) flag[tid] = 0;
+    if (tid == 0) ring[SWEEP_RING] = MODE == 0 ? SWEEP_NONE : -1;
     __syncthreads();
     bounds(0, cur);
     lists(0, cur);
@@ -646,23 +655,30 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_min(GraphSet gs, const 
 #pragma unroll
         for (int j = 0; j < SWEEP_PT; ++j) {
             const SweepNode& nd = cur.nd[j];
-            int best = SWEEP_NONE;
+            int best = MODE == 0 ? SWEEP_NONE : -1;
 #pragma unroll
             for (int k = 0; k < SWEEP_INL; ++k) {
                 const int q = nd.q[k];
                 const int rv = ring[(q >= 0 ? q : 0) & MASK];
-                // inside the tile: relaxed below (none: the thread's own slot, which never lowers its level)
-                inl[j][k] = q >= p0 ? (q & MASK) : ((p0 + j * SWEEP_THREADS + tid) & MASK);
-                if (q >= 0 && q < p0) best = min(best, q < window_lo ? nd.dq[k] : rv);
+                // inside the tile: relaxed below (none: the neutral slot)
+                inl[j][k] = q >= p0 ? (q & MASK) : SWEEP_RING;
+                if (q >= 0 && q < p0) {
+                    const int dv = q < window_lo ? nd.dq[k] : rv;
+                    best = MODE == 0 ? min(best, dv) : max(best, dv);
+                }
             }
             if (nd.hi - nd.lo > SWEEP_INL) {
                 anylong = true;
                 for (int e = nd.lo + SWEEP_INL; e < nd.hi; ++e) {
                     const int q = tsrc[e] - base;
-                    if (q < p0) best = min(best, q < window_lo ? dpos[base + q] : ring[q & MASK]);
+                    if (q < p0) {
+                        const int dv = q < window_lo ? dpos[base + q] : ring[q & MASK];
+                        best = MODE == 0 ? min(best, dv) : max(best, dv);
+                    }
                 }
             }
-            d[j] = nd.seed == 0 ? 0 : (best < SWEEP_NONE ? best + 1 : SWEEP_NONE);
+            if (MODE == 0) d[j] = nd.seed == 0 ? 0 : (best < SWEEP_NONE ? best + 1 : SWEEP_NONE);
+            else d[j] = best + 1;
         }
         __syncthreads();                    // every read of the slots this tile overwrites has been made
 #pragma unroll
@@ -690,15 +706,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_min(GraphSet gs, const 
                     const SweepNode& nd = cur.nd[j];
                     int nv = d[j];
 #pragma unroll
-                    for (int k = 0; k < SWEEP_INL; ++k) nv = min(nv, got[j][k] + 1);
-                    if (nd.seed == 0) nv = 0;
+                    for (int k = 0; k < SWEEP_INL; ++k) nv = MODE == 0 ? min(nv, got[j][k] + 1) : max(nv, got[j][k] + 1);
+                    if (MODE == 0 && nd.seed == 0) nv = 0;
                     if (anylong && nd.hi - nd.lo > SWEEP_INL) {
                         for (int e = nd.lo + SWEEP_INL; e < nd.hi; ++e) {
                             const int q = tsrc[e] - base;
-                            if (q >= p0) nv = min(nv, ring_v[q & MASK] + 1);   // (a PI keeps 0: min with 0)
+                            if (q >= p0) nv = MODE == 0 ? min(nv, ring_v[q & MASK] + 1) : max(nv, ring_v[q & MASK] + 1);
                         }
                     }
-                    if (nv < d[j] && p0 + j * SWEEP_THREADS + tid < n) {
+                    if ((MODE == 0 ? nv < d[j] : nv > d[j]) && p0 + j * SWEEP_THREADS + tid < n) {
                         d[j] = nv;
                         ring[(p0 + j * SWEEP_THREADS + tid) & MASK] = nv;
                         ch = true;
@@ -721,6 +737,37 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_min(GraphSet gs, const 
         }
         cur = nxt;
         nxt = nn;
+    }
+}
+
+// The resync's edges in position space (every edge with both ends in range counts there, AIGgan.py:29-62):
+// key = union position of the target, value = union position of the source.  unordered[g] is raised when an edge
+// of graph g does not run from a lower to a higher position (a self loop included): then the position order is no
+// topological order of that graph and its levels come from the Kahn walk instead of the sweep.
+__global__ void k_rs_sweep_keys(GraphSet gs, const long long* __restrict__ ei, const int* __restrict__ pos,
+                                unsigned* __restrict__ key, int* __restrict__ val, int* __restrict__ unordered) {
+    const int M = gs.M(), N = gs.N();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M; e += gridDim.x * blockDim.x) {
+        int g;
+        long long u = -1, v = -1;
+        const bool ok = load_edge(gs, ei, e, g, u, v) && in_range(u, v, gs.n);
+        int pu = 0, pv = 0;
+        if (ok) {
+            pu = pos[g * gs.n + (int)u];
+            pv = pos[g * gs.n + (int)v];
+            if (pu >= pv) unordered[g] = 1;     // (same value from every thread that stores it)
+        }
+        key[e] = ok ? (unsigned)(g * gs.n + pv) : (unsigned)N;
+        val[e] = ok ? g * gs.n + pu : 0;
+    }
+}
+// depth[node] = level at the node's position, for the graphs the sweep took
+__global__ void k_rs_sweep_out(GraphSet gs, const int* __restrict__ pos, const int* __restrict__ dpos,
+                               const int* __restrict__ unordered, int* __restrict__ depth) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int g = i / gs.n;
+        if (unordered[g] == 0) depth[i] = dpos[g * gs.n + pos[i]];
     }
 }
 
@@ -1065,7 +1112,7 @@ int run_sweep_levels(hipStream_t s, const GraphSet& gs, const long long* ei, con
     AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, val, sval, (size_t)M, 0, bits, s));
     hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey, 1u, tptr);
     hipLaunchKernelGGL(k_sweep_seed, dim3(g256(N)), dim3(256), 0, s, gs, types, pos, seed);
-    hipLaunchKernelGGL(k_sweep_min, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, sval, seed, dpos);
+    hipLaunchKernelGGL(k_sweep<0>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, sval, seed, dpos, (const int*)nullptr);
     hipLaunchKernelGGL(k_sweep_out, dim3(g256(N)), dim3(256), 0, s, gs, pos, dpos, depth32);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -1306,10 +1353,22 @@ size_t resync_ws(int64_t B, int64_t n, int64_t ecap) {
            align_up(t32 > tnb ? t32 : tnb) + 1024;
 }
 
-int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth,
-           void* ws, size_t ws_bytes, void* stream, const char* who) {
+// `x` (may be null): node features whose first column is the node type.  With it, the levels of every graph whose
+// edges all run from a lower to a higher position in the PI / AND / PO order (what a repaired graph looks like)
+// come from one sweep over the positions (k_sweep<1>) instead of the Kahn walk; the walk only runs for the graphs
+// where that does not hold (both are launched, each leaves the other's graphs alone).
+size_t resync_typed_ws(int64_t B, int64_t n, int64_t ecap) {
+    const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
+    const size_t t32 = sort_temp<unsigned>((int64_t)M, 32), ts = scan_temp((int64_t)N + 2);
+    return resync_ws(B, n, ecap) + 2 * align_up((N + 1) * sizeof(Cnt4)) + 3 * align_up((N + 2) * 4) + 4 * align_up(M * 4) +
+           align_up((size_t)(B + 16) * 4) + align_up(t32 > ts ? t32 : ts) + 1024;
+}
+
+int resync(const GraphSet& gs, const float* x, const int64_t* edge_index, const int64_t* edge_attr, int64_t* inv_cnt,
+           int64_t* depth, void* ws, size_t ws_bytes, void* stream, const char* who) {
     AIG_REQUIRE(edge_index && inv_cnt && depth && ws, "%s: null pointer", who);
-    if (ws_bytes < resync_ws(gs.B, gs.n, gs.ecap)) return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
+    if (ws_bytes < (x ? resync_typed_ws(gs.B, gs.n, gs.ecap) : resync_ws(gs.B, gs.n, gs.ecap)))
+        return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int N = gs.N(), M = gs.M();
     Carver c(ws);
@@ -1340,10 +1399,41 @@ int resync(const GraphSet& gs, const int64_t* edge_index, const int64_t* edge_at
     hipLaunchKernelGGL(k_rs_edges, dim3(g256(M)), dim3(256), 0, s, gs, ei, reinterpret_cast<const long long*>(edge_attr),
                        icnt, indeg, key, ids);
     AIG_LAUNCH_CHECK();
-    int rc = run_csr(s, gs, bits_for((unsigned long long)N), key, skey, ids, sid, ei, 1, sptr, adj, temp, tb);
+    int rc;
+    const int* gate = nullptr;
+    if (x) {
+        Cnt4* flags = c.take<Cnt4>(N + 1);
+        Cnt4* scan = c.take<Cnt4>(N + 1);
+        int* types = c.take<int>(N + 2);
+        int* pos = c.take<int>(N + 2);
+        int* tptr = c.take<int>(N + 2);
+        unsigned* tkey = c.take<unsigned>(M);
+        unsigned* tskey = c.take<unsigned>(M);
+        int* tval = c.take<int>(M);
+        int* tsval = c.take<int>(M);
+        int* unordered = c.take<int>(gs.B + 16);
+        AIG_HIP_CHECK(fill_words(unordered, 0u, (size_t)(gs.B + 16) * 4, s));
+        size_t tb2 = scan_temp(N + 2);
+        if (tb2 < tb) tb2 = tb;
+        void* temp2 = c.take<char>(tb2);
+        if ((rc = run_types_pos(s, gs, x, types, pos, nullptr, flags, scan, temp2, tb2))) return rc;
+        hipLaunchKernelGGL(k_rs_sweep_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, tkey, tval, unordered);
+        AIG_LAUNCH_CHECK();
+        AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp2, tb2, tkey, tskey, tval, tsval, (size_t)M, 0,
+                                                bits_for((unsigned long long)N), s));
+        hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, tskey, 1u, tptr);
+        int* dpos = reinterpret_cast<int*>(flags);   // free again: (N+1)*16 bytes
+        hipLaunchKernelGGL(k_sweep<1>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, tsval, (const int*)nullptr, dpos,
+                           (const int*)unordered);
+        hipLaunchKernelGGL(k_rs_sweep_out, dim3(g256(N)), dim3(256), 0, s, gs, pos, dpos, unordered, d32);
+        AIG_LAUNCH_CHECK();
+        gate = unordered;
+    }
+    rc = run_csr(s, gs, bits_for((unsigned long long)N), key, skey, ids, sid, ei, 1, sptr, adj, temp, tb);
     if (rc) return rc;
     TravJobs jobs{};
     jobs.j[0] = TravJob{sptr, adj, indeg, d32, q0, q1, nullptr};
+    jobs.gate = gate;
     if ((rc = run_traverse<1>(s, N, jobs, 1, rec, nullptr, gs.B))) return rc;
     hipLaunchKernelGGL(k_rs_cyclic, dim3(g256(N)), dim3(256), 0, s, gs, d32, cyclic);
     hipLaunchKernelGGL(k_rs_finish, dim3(g256(N)), dim3(256), 0, s, gs, cyclic, d32, icnt,
@@ -1462,7 +1552,7 @@ extern "C" int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const
                           int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX && E > 0 && E < INT_MAX, "aig_resync: needs n > 0 and E > 0");
     const GraphSet gs{1, (int)n, (int)E, nullptr};
-    return resync(gs, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync");
+    return resync(gs, nullptr, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync");
 }
 
 extern "C" size_t aig_resync_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap) { return resync_ws(B, n, ecap); }
@@ -1473,10 +1563,33 @@ extern "C" int aig_resync_batch(int64_t B, int64_t n, int64_t ecap, const int32_
     int rc = check_set("aig_resync_batch", B, n, ecap);
     if (rc) return rc;
     const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
-    return resync(gs, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync_batch");
+    return resync(gs, nullptr, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync_batch");
 }
 
 // ============================================================================================ padded minibatch
+extern "C" size_t aig_resync_typed_ws_bytes(int64_t n, int64_t E) { return resync_typed_ws(1, n, E); }
+
+extern "C" int aig_resync_typed(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
+                                int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_set("aig_resync_typed", 1, n, E);
+    if (rc) return rc;
+    AIG_REQUIRE(x, "aig_resync_typed: null pointer");
+    const GraphSet gs{1, (int)n, (int)E, nullptr};
+    return resync(gs, x, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync_typed");
+}
+
+extern "C" size_t aig_resync_typed_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap) { return resync_typed_ws(B, n, ecap); }
+
+extern "C" int aig_resync_typed_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                                      const int64_t* edge_index, const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_set("aig_resync_typed_batch", B, n, ecap);
+    if (rc) return rc;
+    AIG_REQUIRE(x, "aig_resync_typed_batch: null pointer");
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    return resync(gs, x, edge_index, edge_attr, inv_cnt, depth, ws, ws_bytes, stream, "aig_resync_typed_batch");
+}
+
 extern "C" int aig_pad_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,
                              const int64_t* edge_attr, int64_t max_edges, int64_t* out_edge_index,
                              int64_t* out_edge_attr, void* stream) {

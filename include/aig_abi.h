@@ -357,6 +357,14 @@ int aig_validate(int64_t n, int64_t E, const float* x, const int64_t* edge_index
 size_t aig_resync_ws_bytes(int64_t n, int64_t E);
 int aig_resync(int64_t n, int64_t E, const int64_t* edge_index, const int64_t* edge_attr,
                int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream);
+/* The same results (AIGgan.py:29-62) for a caller that also hands over the node features x [n,2] (column 0 =
+ * node type), as resync_attrs has them in data.x: when every in-range edge runs from a lower to a higher position
+ * in the PI / AND / PO order - what enforce_aig_constraints emits (constraints.py:558-628) unless the graph has
+ * fewer than two PIs - that order is a topological one and the levels come from one sweep over the positions
+ * instead of a walk level by level; any other graph (a cycle included) takes the walk of aig_resync. */
+size_t aig_resync_typed_ws_bytes(int64_t n, int64_t E);
+int aig_resync_typed(int64_t n, int64_t E, const float* x, const int64_t* edge_index, const int64_t* edge_attr,
+                     int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- per-kernel GPU time (a measurement aid; no counterpart in the reference) --------------------------
  * aig_kernel_timing(mask) selects the kernels to time (bit k = kernel k of the list below, 0 = none, the
@@ -444,6 +452,11 @@ size_t aig_resync_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
 int aig_resync_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,
                      const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth, void* ws, size_t ws_bytes,
                      void* stream);
+/* aig_resync_typed on B graphs (x [B n, 2]); the sweep / walk choice is made per graph, on the device. */
+size_t aig_resync_typed_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
+int aig_resync_typed_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                           const int64_t* edge_index, const int64_t* edge_attr, int64_t* inv_cnt, int64_t* depth,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* Edge slots of B graphs -> the edge tensors of the padded minibatch the critic takes: pad_data
  * (utilities/data_process.py:30-68) on every graph, then PyG's concatenation with node offsets

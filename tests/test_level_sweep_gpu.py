@@ -98,3 +98,59 @@ def test_set_of_graphs_in_one_call():
         assert_same_graph(got, ref)
     # the levels by themselves (what the training step asks for after a repair without them)
     assert np.array_equal(depth_alone.cpu().numpy(), np.concatenate([r.node_depth.numpy() for r in refs]))
+
+
+# ---- resync_attrs: longest-path levels by the same sweep when the PI / AND / PO order is a topological one
+def relabel(g, perm):
+    """The same graph with node i renamed perm[i]."""
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    x = g.x.numpy()[inv]
+    ei = perm[g.edge_index.numpy()]
+    return Data(x=torch.from_numpy(x.copy()), edge_index=torch.from_numpy(ei.astype(np.int64)), edge_attr=g.edge_attr.clone())
+
+
+@pytest.mark.parametrize("n,stride", [(4097, 1), (20000, 1), (30000, 7)])
+def test_resync_levels_by_the_sweep(n, stride):
+    from gan_amd.constraints import resync_attrs
+    g = chain_graph(n, stride, seed=3 * n)                  # every edge runs upward in position: the sweep takes it
+    ref = ocpu.resync_attrs(g.clone())
+    assert int(ref.node_depth.max()) > (n - 10) // stride - 2     # longest path: the whole chain
+    assert_same_graph(resync_attrs(to_dev(g)), ref)
+    g2 = long_list_graph(n, seed=n + 1)                      # has downward edges and self loops: the walk takes it
+    assert_same_graph(resync_attrs(to_dev(g2)), ocpu.resync_attrs(g2.clone()))
+
+
+def test_resync_of_an_acyclic_graph_whose_order_is_not_topological():
+    from gan_amd.constraints import resync_attrs
+    n = 9000
+    g = chain_graph(n, 2, seed=11)
+    rng = np.random.default_rng(4)
+    perm = np.arange(n)
+    ands = np.arange(4, n - 3)
+    perm[ands] = rng.permutation(ands)                      # ANDs renamed at random: types keep their places
+    h = relabel(g, perm)
+    ref = ocpu.resync_attrs(h.clone())
+    assert int(ref.node_depth.max()) > 1000                  # still acyclic, still deep
+    assert_same_graph(resync_attrs(to_dev(h)), ref)
+
+
+def test_resync_set_chooses_per_graph():
+    from gan_amd.constraints import resync_set
+    n = 7000
+    ordered = chain_graph(n, 1, seed=21)
+    rng = np.random.default_rng(5)
+    perm = np.arange(n)
+    perm[4:n - 3] = rng.permutation(np.arange(4, n - 3))
+    unordered = relabel(chain_graph(n, 3, seed=22), perm)
+    cyclic = chain_graph(n, 5, seed=23)
+    ei = cyclic.edge_index.clone()
+    ei[:, 0] = torch.tensor([n // 2, n // 2 - 5])            # one edge turned around: a cycle
+    cyclic.edge_index = ei
+    graphs = [ordered, unordered, cyclic, chain_graph(n, 40, seed=24)]
+    gs = resync_set(GraphSet.from_data_list([to_dev(g) for g in graphs]))
+    for got, g in zip(gs.graphs(), graphs):
+        ref = ocpu.resync_attrs(g.clone())
+        assert np.array_equal(got.node_depth.cpu().numpy(), ref.node_depth.numpy())
+        assert np.array_equal(got.x.cpu().numpy(), ref.x.numpy())
+    assert int(gs.graphs()[2].node_depth.max()) == 0         # the cyclic one reports zeros
