@@ -110,7 +110,7 @@ def relabel(g, perm):
     return Data(x=torch.from_numpy(x.copy()), edge_index=torch.from_numpy(ei.astype(np.int64)), edge_attr=g.edge_attr.clone())
 
 
-@pytest.mark.parametrize("n,stride", [(4097, 1), (20000, 1), (30000, 7)])
+@pytest.mark.parametrize("n,stride", [(16385, 1), (20000, 1), (30000, 7)])
 def test_resync_levels_by_the_sweep(n, stride):
     from gan_amd.constraints import resync_attrs
     g = chain_graph(n, stride, seed=3 * n)                  # every edge runs upward in position: the sweep takes it
@@ -123,7 +123,7 @@ def test_resync_levels_by_the_sweep(n, stride):
 
 def test_resync_of_an_acyclic_graph_whose_order_is_not_topological():
     from gan_amd.constraints import resync_attrs
-    n = 9000
+    n = 19000
     g = chain_graph(n, 2, seed=11)
     rng = np.random.default_rng(4)
     perm = np.arange(n)
@@ -137,7 +137,7 @@ def test_resync_of_an_acyclic_graph_whose_order_is_not_topological():
 
 def test_resync_set_chooses_per_graph():
     from gan_amd.constraints import resync_set
-    n = 7000
+    n = 17000
     ordered = chain_graph(n, 1, seed=21)
     rng = np.random.default_rng(5)
     perm = np.arange(n)
