@@ -244,6 +244,9 @@ def side_workload(name: str, dev, steps: int, warmup: int):
     tr.global_step = 1
     for i in range(distinct + warmup):      # one pass over the minibatches (per-sample templates), then warm-up
         tr.step(batches[i % distinct])
+    import gc
+    gc.collect()
+    gc.freeze()        # as in the main measurement (and gan_amd.train.train): no full collection inside the timed steps
     torch.cuda.synchronize()
     edges = torch.zeros((), dtype=torch.long, device=dev)
     t0 = time.perf_counter()

@@ -466,6 +466,19 @@ class CapturedCriticTerms:
             torch._foreach_add_([p.grad for p in ps], gs)
 
 
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The second stream of the training step, one per device for the life of the process.  Streams share a handful
+    of hardware queues; a trainer made after other streams have been taken from the pool could get one that shares
+    its queue with the first stream, and the step's two streams would then run one after the other."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[idx]
+
+
 class Trainer:
     """State of one training run; ``step(batch)`` is one pass of the reference's inner loop body."""
 
@@ -497,7 +510,7 @@ class Trainer:
         self.draw_alpha = lambda: torch.rand(1, 1, device=device)
         # the structural penalties only need the raw graphs and their latency-bound traversals keep
         # one CU busy: they run on a second stream underneath the critic pass of the generator step
-        self.side_stream = torch.cuda.Stream(device=device)
+        self.side_stream = _side_stream(device)
         # ... and the generator step's raw graphs (which depend on nothing the critic iterations compute) are
         # made, padded and loaded into their recording's buffers on a third stream underneath those iterations
         self.raw_stream = self.side_stream
