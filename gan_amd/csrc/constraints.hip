@@ -586,7 +586,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, const int*
                                                         int* __restrict__ dpos, const int* __restrict__ gate) {
     if (gate && gate[blockIdx.x] != 0) return;
     __shared__ int ring[SWEEP_RING + 1];   // the last slot: a neutral level for "no predecessor"
-    __shared__ int flag[2];
+    __shared__ int flag[3];
     volatile int* ring_v = ring;     // (the rounds between two barriers must re-read LDS)
     const int n = gs.n, base = blockIdx.x * gs.n, tid = threadIdx.x;
     const int ntiles = (n + SWEEP_T - 1) / SWEEP_T;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, const int*
     };
     SweepTile cur, nxt, nn;
     int par = 0;
-    if (tid < 2) flag[tid] = 0;
+    if (tid < 3) flag[tid] = 0;
     if (tid == 0) ring[SWEEP_RING] = MODE == 0 ? SWEEP_NONE : -1;
     __syncthreads();
     bounds(0, cur);
@@ -726,8 +726,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, const int*
             // flight through the relaxation (__syncthreads would wait for them here)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const bool go = flag[par] != 0;
-            if (tid == 0) flag[par ^ 1] = 0;    // (last read before the barrier above)
-            par ^= 1;
+            // three flags in turn: the one cleared here was last read before the barrier above and is next raised
+            // behind the next barrier (with two, a fast wave could raise the other flag before this store lands)
+            if (tid == 0) flag[par == 0 ? 2 : par - 1] = 0;
+            par = par == 2 ? 0 : par + 1;
             if (!go) break;
         }
 #pragma unroll

@@ -521,6 +521,13 @@ class Trainer:
         self.capture_fake = str(getattr(args, "capture_fake", "auto"))
         self._fake_caps: Dict[tuple, int] = {}   # by minibatch shape: level cap the generated side was found to need
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
+        self.probes: Optional[dict] = None  # diagnosis aid: {label: event on whatever stream was current} of the last step
+
+    def _probe(self, label: str) -> None:
+        if self.probes is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.probes[label] = ev
 
     def _mark(self, label: str) -> None:
         if self.marks is not None:
@@ -650,6 +657,7 @@ class Trainer:
                 zs_once = [self.draw_z() for _ in templates]
                 if split:
                     raw_fakes_set = G.forward_set(templates, torch.stack(zs_once))
+                    self._probe("side: fakes generated")
             if split and not real_first:
                 # The host enqueues the real side right behind the generator pass (half a millisecond of GPU
                 # work) and the repair's ~150 small launches after that: enqueued in front of the real side they
@@ -663,6 +671,7 @@ class Trainer:
                     corr_set = enforce_set(raw_fakes_set, want_depth=False)
                     features_ready = torch.cuda.Event()
                     features_ready.record()
+                    self._probe("side: fakes repaired")
 
                     def finish_fakes():
                         # the level walk behind the fakes' depths and the padded minibatch: enqueued by the first
@@ -674,6 +683,7 @@ class Trainer:
                             ready.record()        # the critic's edge lists of the fakes can be built from here on
                             corr_set.node_depth = clean_depth_set(raw_fakes_set)
                             padded = self._pad_set(corr_set, edges)
+                            self._probe("side: fakes' levels and padding")
                             return padded, count_edges(padded.edge_index), ready
                     fake_padded = None
                 elif as_set:
@@ -751,6 +761,7 @@ class Trainer:
                         if not (it == 0 and real_replayed):
                             terms.replay_real()
                         terms.replay_gp(alphas[it] if alphas is not None else self.draw_alpha())
+                        self._probe(f"main: real and penalty terms {it}")
                         edges_ready = None
                         if finish_fakes is not None:
                             fake_padded, edges_fake, edges_ready = finish_fakes()
@@ -792,6 +803,7 @@ class Trainer:
                             D_fake_mean = mean_score(D, fake_for_D)
                             D_fake_mean.backward()
                         terms.add_gradients()
+                        self._probe(f"main: critic gradients {it}")
                         if it == a.n_critic - 1:   # the logged scalars are those of the last iteration (train.py:263-272)
                             D_real_mean, gp_term, grad_norm = terms.d_real.clone(), terms.gp.clone(), terms.grad_norm.clone()
                             gap = D_real_mean - D_fake_mean.detach()
@@ -829,10 +841,13 @@ class Trainer:
                 self.raw_stream.wait_event(step_start)
                 with torch.cuda.stream(self.raw_stream):
                     raw_set = G.forward_set(templates, torch.stack(zs))
+                    self._probe("side: raw graphs generated")
                     terms.rw.load(self._pad_set(raw_set), check=False)
                     raw_loaded = torch.cuda.Event()
                     raw_loaded.record()
+                    self._probe("side: raw graphs loaded")
                     loss_pen = penalties_set(raw_set)[:, 8].mean()
+                    self._probe("side: penalties")
             except Exception as e:
                 if self.world == 1:
                     raise
@@ -871,6 +886,7 @@ class Trainer:
             main_stream.wait_event(raw_loaded)
             terms.replay_raw()
             loss_G_adv = -terms.rw.d.clone()
+            self._probe("main: raw graphs scored")
         elif raw_recorded:
             terms.load_generated(raw_batch_for_D, check=False)
             terms.replay_fake()

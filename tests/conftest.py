@@ -23,6 +23,9 @@ def _start_dp_rehearsal():
     global DP_REHEARSAL
     tmp = tempfile.mkdtemp(prefix="aig_dp_")
     out_path, log_path = os.path.join(tmp, "dp.json"), os.path.join(tmp, "dp.log")
+    keep = os.path.join(ROOT, "gpurun_out")          # (kept with the run's other outputs where that directory exists)
+    if os.path.isdir(keep) and os.access(keep, os.W_OK):
+        log_path = os.path.join(keep, "dp_rehearsal.log")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
