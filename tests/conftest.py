@@ -37,6 +37,66 @@ def _start_dp_rehearsal():
     DP_REHEARSAL = (subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT), out_path, log_path)
 
 
+WATCH = {"test": None, "since": 0.0, "trainer": None, "reported": None}
+
+
+def _start_step_watchdog(limit: float = 60.0):
+    """Every training step of the session records its probe events (``Trainer.probes``); when a test has been
+    running for ``limit`` seconds, which of the last step's events have completed and whether the step's two
+    streams are idle is written to stderr (and to gpurun_out/hang_report.json where that directory exists) - once
+    per test, ahead of the test's own time limit, which only shows the host's stack."""
+    import json
+    import threading
+    import time
+    import weakref
+
+    import torch
+
+    from gan_amd import train as train_mod
+    inner = train_mod.Trainer.step
+
+    def step(self, *a, **k):
+        WATCH["trainer"] = weakref.ref(self)
+        self.probes = {}
+        return inner(self, *a, **k)
+    train_mod.Trainer.step = step
+
+    def watch():
+        while True:
+            time.sleep(1.0)
+            test = WATCH["test"]
+            if test is None or WATCH["reported"] == test or time.time() - WATCH["since"] < limit:
+                continue
+            WATCH["reported"] = test
+            tr = WATCH["trainer"]() if WATCH["trainer"] is not None else None
+            out = {"test": test, "running_for_s": round(time.time() - WATCH["since"], 1)}
+            try:
+                if tr is not None:
+                    out.update(global_step=tr.global_step, captures=tr.captures,
+                               main_idle=torch.cuda.default_stream(tr.device).query(), side_idle=tr.side_stream.query(),
+                               probes={k: v.query() for k, v in dict(tr.probes or {}).items()})
+            except Exception as e:      # a report, not a check
+                out["error"] = repr(e)
+            text = json.dumps(out)
+            sys.stderr.write("\n[step watchdog] " + text + "\n")
+            sys.stderr.flush()
+            keep = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(keep) and os.access(keep, os.W_OK):
+                with open(os.path.join(keep, "hang_report.json"), "a") as f:
+                    f.write(text + "\n")
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
+def pytest_runtest_setup(item):
+    import time
+    WATCH["test"], WATCH["since"] = item.nodeid, time.time()
+
+
+def pytest_runtest_teardown(item, nextitem):
+    WATCH["test"] = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     import torch
@@ -46,6 +106,15 @@ def pytest_configure(config):
     # counting devices does not start the HIP runtime
     if wants_gpu and selected and torch.cuda.device_count() > 0 and os.environ.get("RANK") is None:
         _start_dp_rehearsal()
+        # ... and given the GPU to itself: it takes a few seconds, and the tests then measure and compare one
+        # process on the device, which is the configuration the package runs in (one process per GPU)
+        import subprocess
+        try:
+            DP_REHEARSAL[0].wait(timeout=150)
+        except subprocess.TimeoutExpired:
+            pass          # tests/test_parallel_gpu.py reports it
+    if wants_gpu and torch.cuda.device_count() > 0:
+        _start_step_watchdog()
 
 
 def pytest_collection_modifyitems(config, items):
