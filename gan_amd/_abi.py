@@ -63,6 +63,8 @@ SIGNATURES = {
     "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_gp_forward": (INT, [I64] + [P] * 10 + [P]),
     "aig_gp_scalars": (INT, [P, C.c_float, P, P]),
+    "aig_sort_pairs_ws_bytes": (SZ, [I64, INT, INT]),
+    "aig_sort_pairs": (INT, [I64, INT, INT, P, P, P, P, P, SZ, P]),
     "aig_gp_input_grad_ws_bytes": (SZ, [I64]),
     "aig_gp_input_grad": (INT, [I64, I64] + [P] * 14 + [P, SZ, P]),
     "aig_gp_param_grad_ws_bytes": (SZ, [I64]),

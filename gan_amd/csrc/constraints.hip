@@ -8,6 +8,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
+#include "radix.h"
 
 namespace aig {
 namespace {
@@ -90,11 +91,7 @@ int bits_for(unsigned long long maxval) {
 }
 template <typename K>
 size_t sort_temp(int64_t E, int bits) {
-    size_t bytes = 0;
-    K* k = nullptr;
-    int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(E > 0 ? E : 1), 0, bits, hipStream_t(0));
-    return bytes;
+    return rs::temp_bytes<K, int>((size_t)(E > 0 ? E : 1), bits);
 }
 size_t scan_temp(int64_t n) {
     size_t bytes = 0;
@@ -1096,7 +1093,7 @@ int run_types_pos(hipStream_t s, const GraphSet& gs, const float* x, int* types,
 int run_csr(hipStream_t s, const GraphSet& gs, int bits, unsigned* key, unsigned* skey, int* ids, int* sid,
             const long long* ei, int other_is_target, int* ptr, int* adj, void* temp, size_t tb) {
     const int N = gs.N(), M = gs.M();
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, sid, (size_t)M, 0, bits, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, skey, ids, sid, (size_t)M, bits, s));
     hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey, 1u, ptr);
     hipLaunchKernelGGL(k_gather_adj, dim3(g256(M)), dim3(256), 0, s, gs, sid, ei, other_is_target, adj);
     AIG_LAUNCH_CHECK();
@@ -1111,7 +1108,7 @@ int run_sweep_levels(hipStream_t s, const GraphSet& gs, const long long* ei, con
     const int N = gs.N(), M = gs.M();
     hipLaunchKernelGGL(k_sweep_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, key, val);
     AIG_LAUNCH_CHECK();
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, val, sval, (size_t)M, 0, bits, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, skey, val, sval, (size_t)M, bits, s));
     hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey, 1u, tptr);
     hipLaunchKernelGGL(k_sweep_seed, dim3(g256(N)), dim3(256), 0, s, gs, types, pos, seed);
     hipLaunchKernelGGL(k_sweep<0>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, sval, seed, dpos, (const int*)nullptr);
@@ -1197,7 +1194,7 @@ int enforce(const GraphSet& gs, const float* x, const int64_t* edge_index, const
     hipLaunchKernelGGL(k_enf_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, key64, key_src, ids);
     AIG_LAUNCH_CHECK();
     // by (target, source): runs of equal pairs are adjacent, first occurrence first (stable)
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, t.kb, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, t.kb, s));
     hipLaunchKernelGGL(k_enf_merge, dim3(g256(M)), dim3(256), 0, s, M, skey64, sid, inv, minv);
     hipLaunchKernelGGL(k_segment_ptr<unsigned long long>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey64,
                        (unsigned long long)N, vptr);
@@ -1319,7 +1316,7 @@ int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, 
     hipLaunchKernelGGL(k_pen_edges, dim3(g256(M)), dim3(256), 0, s, gs, ei, types, pos, counters, indeg, key64, key_src,
                        key_dst, ids, eflag);
     AIG_LAUNCH_CHECK();
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, 0, t.kb, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, t.kb, s));
     hipLaunchKernelGGL(k_pen_dups, dim3(g256(M)), dim3(256), 0, s, gs, skey64, sid, counters, eflag);
     AIG_LAUNCH_CHECK();
     // forward reachability from the PIs, backward from the POs
@@ -1421,8 +1418,7 @@ int resync(const GraphSet& gs, const float* x, const int64_t* edge_index, const 
         if ((rc = run_types_pos(s, gs, x, types, pos, nullptr, flags, scan, temp2, tb2))) return rc;
         hipLaunchKernelGGL(k_rs_sweep_keys, dim3(g256(M)), dim3(256), 0, s, gs, ei, pos, tkey, tval, unordered);
         AIG_LAUNCH_CHECK();
-        AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp2, tb2, tkey, tskey, tval, tsval, (size_t)M, 0,
-                                                bits_for((unsigned long long)N), s));
+        AIG_HIP_CHECK(rs::sort_pairs(temp2, tb2, tkey, tskey, tval, tsval, (size_t)M, bits_for((unsigned long long)N), s));
         hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, tskey, 1u, tptr);
         int* dpos = reinterpret_cast<int*>(flags);   // free again: (N+1)*16 bytes
         hipLaunchKernelGGL(k_sweep<1>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, tsval, (const int*)nullptr, dpos,
@@ -1605,5 +1601,31 @@ extern "C" int aig_pad_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* 
                        (int)max_edges, reinterpret_cast<long long*>(out_edge_index),
                        reinterpret_cast<long long*>(out_edge_attr));
     AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+// ------------------------------------------------------------------------------------------ the sort, on its own
+extern "C" size_t aig_sort_pairs_ws_bytes(int64_t items, int key_bytes, int bits) {
+    const size_t m = (size_t)(items > 0 ? items : 1);
+    return key_bytes == 8 ? rs::temp_bytes<unsigned long long, int>(m, bits) : rs::temp_bytes<unsigned, int>(m, bits);
+}
+
+extern "C" int aig_sort_pairs(int64_t items, int key_bytes, int bits, const void* keys_in, void* keys_out,
+                              const int32_t* values_in, int32_t* values_out, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(key_bytes == 4 || key_bytes == 8, "aig_sort_pairs: keys are 4 or 8 bytes wide (got %d)", key_bytes);
+    AIG_REQUIRE(items >= 0 && items < INT_MAX, "aig_sort_pairs: bad item count %lld", (long long)items);
+    AIG_REQUIRE(bits >= 0 && bits <= 8 * key_bytes, "aig_sort_pairs: bad bit count %d", bits);
+    if (items == 0) return AIG_OK;
+    AIG_REQUIRE(keys_in && keys_out && values_in && values_out && ws, "aig_sort_pairs: null pointer");
+    AIG_REQUIRE(keys_in != keys_out && values_in != values_out, "aig_sort_pairs: input and output must be different buffers");
+    if (ws_bytes < aig_sort_pairs_ws_bytes(items, key_bytes, bits)) return fail(AIG_EWORKSPACE, "aig_sort_pairs: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (key_bytes == 8) {
+        AIG_HIP_CHECK(rs::sort_pairs(ws, ws_bytes, static_cast<const unsigned long long*>(keys_in),
+                                     static_cast<unsigned long long*>(keys_out), values_in, values_out, (size_t)items, bits, s));
+    } else {
+        AIG_HIP_CHECK(rs::sort_pairs(ws, ws_bytes, static_cast<const unsigned*>(keys_in), static_cast<unsigned*>(keys_out),
+                                     values_in, values_out, (size_t)items, bits, s));
+    }
     return AIG_OK;
 }

@@ -11,6 +11,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
+#include "radix.h"
 
 namespace aig {
 namespace {
@@ -91,11 +92,7 @@ int key_bits(int64_t n) {
 }
 
 size_t sort_temp_bytes(int64_t E, int bits) {
-    size_t bytes = 0;
-    unsigned* k = nullptr;
-    int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)E, 0, bits, hipStream_t(0));
-    return bytes;
+    return rs::temp_bytes<unsigned, int>((size_t)E, bits);
 }
 
 constexpr int SEG = 32;         // an out-edge list of at most this many edges is one half-wave's work in the backward pass
@@ -833,7 +830,7 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     const long long* ei = reinterpret_cast<const long long*>(edge_index);
     hipLaunchKernelGGL(k_csr_keys, dim3(g), dim3(256), 0, s, (int)n, (int)E, ei, key, ids);
     AIG_LAUNCH_CHECK();
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, seid, (size_t)E, 0, bits, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, skey, ids, seid, (size_t)E, bits, s));
     hipLaunchKernelGGL(k_csr_ptr, dim3(gn), dim3(256), 0, s, (int)n, (int)E, skey, row_ptr);
     // key <- source of each kept edge (in target-sorted order), ids <- that position
     hipLaunchKernelGGL(k_csr_fill, dim3(g), dim3(256), 0, s, (int)n, (int)E, ei, edge_attr, skey, seid, csr_src, csr_ea,
@@ -841,7 +838,7 @@ extern "C" int aig_gat_csr(int64_t n, int64_t E, const int64_t* edge_index, cons
     AIG_LAUNCH_CHECK();
     // seid is free again: reuse it for the sorted source keys
     unsigned* ssrc = reinterpret_cast<unsigned*>(seid);
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, ssrc, ids, csc_pos, (size_t)E, 0, bits, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, ssrc, ids, csc_pos, (size_t)E, bits, s));
     hipLaunchKernelGGL(k_csr_ptr, dim3(gn), dim3(256), 0, s, (int)n, (int)E, ssrc, col_ptr);
     hipLaunchKernelGGL(k_csc_fill, dim3(g), dim3(256), 0, s, (int)E, row_ptr + n, skey, csc_pos, csc_dst);
     hipLaunchKernelGGL(k_loop_attr, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, (int)n, row_ptr, csr_ea, loop_ea);

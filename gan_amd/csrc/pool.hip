@@ -15,6 +15,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "radix.h"
 
 namespace aig {
 namespace {
@@ -266,11 +267,7 @@ int key_bits(int64_t n) {
     return b;
 }
 size_t sort_temp_bytes(int64_t n, int bits) {
-    size_t bytes = 0;
-    unsigned* k = nullptr;
-    int* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, bits, hipStream_t(0));
-    return bytes;
+    return rs::temp_bytes<unsigned, int>((size_t)n, bits);
 }
 
 }  // namespace
@@ -319,7 +316,7 @@ int level_plan(int64_t n, int64_t L, const int64_t* depth, int32_t* perm, int32_
     hipLaunchKernelGGL(k_level_keys, dim3(g), dim3(256), 0, s, (int)n, (int)L, (const int*)meta,
                        reinterpret_cast<const long long*>(depth), key, ids);
     AIG_LAUNCH_CHECK();
-    AIG_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, key, skey, ids, perm, (size_t)n, 0, bits, s));
+    AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, skey, ids, perm, (size_t)n, bits, s));
     hipLaunchKernelGGL(k_level_ptr, dim3(grid_for(L + 2, 256, 4096)), dim3(256), 0, s, (int)n, (int)L, skey, lvl_ptr);
     hipLaunchKernelGGL(k_level_weights, dim3(g), dim3(256), 0, s, (int)n, (int)L, (const int*)meta, skey, perm, lvl_ptr,
                        node_level, w);

@@ -279,6 +279,17 @@ int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_meta, const 
                            const float* w, const int32_t* argmax, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stable sort of (key, value) pairs by bits [0, bits) of the key - no counterpart in the reference (torch's sorts,
+ * scatters and PyG's index bookkeeping stand where the library sorts: constraints.py:88-112, discriminator.py:83-96,
+ * GATConv's aggregation).  The building block of the edge lists by target / by source, the level plans and the
+ * repair's pair keys, exported for its tests: keys are 4 or 8 bytes wide (key_bytes), values int32; inputs are left
+ * as they were; input and output buffers must differ.  Equal keys keep their input order.
+ * ------------------------------------------------------------------------------------------- */
+size_t aig_sort_pairs_ws_bytes(int64_t items, int key_bytes, int bits);
+int aig_sort_pairs(int64_t items, int key_bytes, int bits, const void* keys_in, void* keys_out, const int32_t* values_in,
+                   int32_t* values_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Gradient penalty on the edge-free interpolate - gradient_penalty(use_edges=False), train.py:133-152, through
  * AIGDiscriminator.forward on an empty edge list (discriminator.py:42-100), in closed form.  Without edges a
  * GAT layer is elu(x W^T + b), so with r = readout(h2), s = head(r):

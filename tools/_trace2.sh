@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o p -- python3 bench.py --no-kernel-timing --no-cpu-baseline --no-side-workloads --sample-iters 1 > /tmp/tr.log 2>&1 || { tail -5 /tmp/tr.log; exit 1; }
+python3 tools/step_trace.py /tmp/tr 10 20 > gpurun_out/s5_trace.txt 2>&1
+python3 tools/step_trace.py /tmp/tr 16 17 3 16 1 250 0 2400 > gpurun_out/s5_trace_detail.txt 2>&1
+tail -12 gpurun_out/s5_trace.txt
