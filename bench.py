@@ -491,6 +491,25 @@ def main():
     run_steps(a.steps, only=batches[0])
     barrier()
     ms_repeated = (time.perf_counter() - r0) * 1e3 / a.steps
+    # The same rotation with the generator step's unused backward pass left out (``Trainer.skip_unused_backward``:
+    # train.py:298 back-propagates loss_G into the critic, whose gradients train.py:253 zeroes before their next
+    # use).  An extension reported beside the headline, never as it: the headline step does all the reference does.
+    trainer.skip_unused_backward = True
+    for terms in trainer._captured.values():
+        terms.release()
+    trainer._captured.clear()
+    run_steps(nb)
+    run_steps(a.warmup, start=nb)
+    barrier()
+    u0 = time.perf_counter()
+    run_steps(a.steps, start=nb + a.warmup)
+    barrier()
+    ms_skip = (time.perf_counter() - u0) * 1e3 / a.steps
+    trainer.skip_unused_backward = False
+    for terms in trainer._captured.values():
+        terms.release()
+    trainer._captured.clear()
+    run_steps(nb)                      # (the full recordings again for what follows)
     # The roofline loop.  The headline loop above replays the critic's passes from recordings, and a replayed
     # kernel cannot carry events of its own.  So the same K steps are timed once more with the critic's pass over
     # the generated graphs left unrecorded (--capture-fake off: eager launches), and inside THAT timed region the
@@ -671,6 +690,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(elapsed * 1e3 / a.steps, 3),
             "ms_per_step_repeated_batch": round(ms_repeated, 3),
             "ms_per_step_generated_side_eager": None if ms_eager_side is None else round(ms_eager_side, 3),
+            "ms_per_step_without_unused_backward": round(ms_skip, 3),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {desc}; {nb} different minibatches per GPU in rotation inside the timed "

@@ -282,7 +282,7 @@ class CapturedCriticTerms:
 
     def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], example: Batch, level_cap: int,
                  gp_lambda: float, device: torch.device, closed_form_gp: bool = True, fake_side: bool = False,
-                 fake_level_cap: int = 0, raw_side: bool = False):
+                 fake_level_cap: int = 0, raw_side: bool = False, raw_grads: bool = True):
         n = int(example.x.size(0))
         e_cols = 0 if example.edge_index is None else int(example.edge_index.size(1))
         self.n, self.e_cols, self.level_cap = n, e_cols, int(level_cap)
@@ -334,6 +334,9 @@ class CapturedCriticTerms:
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 
         def compute_side(side):
+            if side is self.rw and not raw_grads:     # the generator step's score alone (see Trainer.skip_unused_backward)
+                with torch.no_grad():
+                    return mean_score(D, side.for_D).detach(), [None] * len(params)
             d_side = mean_score(D, side.for_D)
             return d_side.detach(), torch.autograd.grad(d_side, params, allow_unused=True)
 
@@ -445,7 +448,8 @@ class CapturedCriticTerms:
 
     def add_raw_gradients(self, sign: float = 1.0) -> None:
         ps, gs = self.rw.grads
-        torch._foreach_add_([p.grad for p in ps], gs, alpha=sign)
+        if ps:
+            torch._foreach_add_([p.grad for p in ps], gs, alpha=sign)
 
     def replay_gp(self, alpha: torch.Tensor) -> None:
         """The penalty term between the real minibatch and the generated one of the last ``load_generated``."""
@@ -519,6 +523,11 @@ class Trainer:
         self.overlap_fakes = not bool(getattr(args, "no_overlap", False))
         self.use_sets = not bool(getattr(args, "no_sets", False))
         self.capture_fake = str(getattr(args, "capture_fake", "auto"))
+        # ``loss_G.backward()`` (train.py:298) reaches the critic's parameters only - the generator's outputs are
+        # integers and copies - and the critic's gradients are zeroed before their next use (train.py:253): that
+        # backward pass changes nothing a run can observe.  Off by default (the step then does what the reference's
+        # does); with it on, the generator step is the critic's forward pass over the raw graphs alone.
+        self.skip_unused_backward = bool(getattr(args, "skip_unused_backward", False))
         self._fake_caps: Dict[tuple, int] = {}   # by minibatch shape: level cap the generated side was found to need
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
         self.probes: Optional[dict] = None  # diagnosis aid: {label: event on whatever stream was current} of the last step
@@ -582,7 +591,8 @@ class Trainer:
         terms = CapturedCriticTerms(self.D, self._d_params, real_padded, cap, self.args.gp_lambda, self.device,
                                     closed_form_gp=self.closed_form_gp, fake_side=fake_side,
                                     fake_level_cap=self._fake_caps.get(key, 0),
-                                    raw_side=fake_side and self.overlap_fakes and self.use_sets)
+                                    raw_side=fake_side and self.overlap_fakes and self.use_sets,
+                                    raw_grads=not self.skip_unused_backward)
         self.captures += 1
         self._captured[key] = terms
         if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
@@ -887,10 +897,16 @@ class Trainer:
             terms.replay_raw()
             loss_G_adv = -terms.rw.d.clone()
             self._probe("main: raw graphs scored")
-        elif raw_recorded:
+        elif raw_recorded and not self.skip_unused_backward:
             terms.load_generated(raw_batch_for_D, check=False)
             terms.replay_fake()
             loss_G_adv = -terms.d_fake.clone()
+        elif self.skip_unused_backward:
+            raw_recorded = False
+            if terms is not None:
+                raw_batch_for_D._plan = terms.plan
+            with torch.no_grad():
+                loss_G_adv = -mean_score(D, raw_batch_for_D)
         else:
             if terms is not None:
                 raw_batch_for_D._plan = terms.plan
@@ -1042,6 +1058,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--capture-fake", choices=["auto", "on", "off"], default="auto",
                    help="also record the critic's pass over generated minibatches (fakes, raw graphs) as a HIP graph "
                         "(auto = on; off evaluates it eagerly every time)")
+    p.add_argument("--skip-unused-backward", dest="skip_unused_backward", action="store_true",
+                   help="leave out the backward pass of the generator step: it only reaches the critic's gradients, which "
+                        "are zeroed before their next use (weights, metrics and samples are unchanged)")
     p.add_argument("--no-sets", dest="no_sets", action="store_true",
                    help="run generator, repair and penalties graph by graph instead of once per minibatch")
     p.add_argument("--no-graph-capture", dest="graph_capture", action="store_false",

@@ -202,7 +202,8 @@ def test_generated_side_deeper_than_its_recording_is_scored_eagerly_then_recorde
 
 
 @pytest.mark.parametrize("name", ["bs1", "bs3"])
-@pytest.mark.parametrize("mode", ["hip_graph", "hip_graph_eager_fakes", "eager", "autograd_gp"])
+@pytest.mark.parametrize("mode", ["hip_graph", "hip_graph_eager_fakes", "eager", "autograd_gp", "skip_unused",
+                                  "eager_skip_unused"])
 def test_training_follows_reference_run(name, mode):
     """A whole ``train(args)`` run recorded from the reference's own train.py (tests/golden/make_golden_critic.py;
     its attention layer is the restated one): the same dataset, initial critic, draws and raw generator outputs
@@ -212,7 +213,11 @@ def test_training_follows_reference_run(name, mode):
     me = max(g.edge_index.size(1) for g in run.graphs)
     padded = [pad_data(g, mn, me) for g in run.graphs]
     extra = {"hip_graph": [], "hip_graph_eager_fakes": ["--capture-fake", "off"], "eager": ["--no-graph-capture"],
-             "autograd_gp": ["--autograd-gp"]}[mode]
+             "autograd_gp": ["--autograd-gp"],
+             # the generator step without its backward pass (it only reaches critic gradients that are zeroed
+             # before their next use, train.py:253,298): the run's numbers must not notice
+             "skip_unused": ["--skip-unused-backward"],
+             "eager_skip_unused": ["--no-graph-capture", "--skip-unused-backward"]}[mode]
     args = build_parser().parse_args(["--dataset-dir", "unused"] + run.argv + extra)
     tr = Trainer(args, mn, me, DEV)
     tr.G.load_state_dict(gen_state())
