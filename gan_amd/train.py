@@ -800,6 +800,7 @@ class Trainer:
                             fake_here = fake_recorded
                         elif fake_after:
                             terms.replay_fake()
+                            self._probe(f"main: generated side replayed {it}")
                             fake_here = True
                         else:
                             fake_here = False
@@ -809,6 +810,7 @@ class Trainer:
                             if it == a.n_critic - 1:      # (the buffer is written again by the generator step)
                                 D_fake_mean = terms.d_fake.clone()
                             terms.add_fake_gradients()
+                            self._probe(f"main: generated side's gradients added {it}")
                         else:
                             D_fake_mean = mean_score(D, fake_for_D)
                             D_fake_mean.backward()

@@ -38,9 +38,47 @@ def flat(params):
     return torch.cat([p.detach().reshape(-1).float().cpu() for p in params])
 
 
+WATCH = {"trainer": None, "phase": "start"}
+
+
+def start_watchdog(rank: int, limit: float = 40.0) -> None:
+    """The rehearsal takes a few seconds.  Past ``limit`` this rank says where it is - phase, which of the last
+    step's probe events have completed, whether its two streams are idle, every thread's stack - and ends."""
+    import faulthandler
+    import threading
+    import time
+
+    def watch():
+        time.sleep(limit)
+        tr = WATCH["trainer"]
+        out = {"rank": rank, "phase": WATCH["phase"]}
+        try:
+            if tr is not None:
+                out.update(global_step=tr.global_step, captures=tr.captures,
+                           main_idle=torch.cuda.default_stream(tr.device).query(), side_idle=tr.side_stream.query(),
+                           probes={k: v.query() for k, v in dict(tr.probes or {}).items()})
+        except Exception as e:
+            out["error"] = repr(e)
+        sys.stderr.write("\n[rehearsal watchdog] " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        faulthandler.dump_traceback(all_threads=True)
+        os._exit(3)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
+def watched_step(tr, batch, phase):
+    WATCH["trainer"], WATCH["phase"] = tr, phase
+    tr.probes = {}
+    out = tr.step(batch)
+    WATCH["phase"] = phase + " (enqueued)"
+    return out
+
+
 def main():
     out_path = sys.argv[1]
     rank, local_rank, world = parallel.init_distributed()
+    start_watchdog(rank)
     assert world == 2, "the rehearsal is written for two ranks"
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
@@ -90,16 +128,17 @@ def main():
         draws(single, who)
         store = {}
         record_first_gradient(single, store)
-        single.step(batches[who])
+        watched_step(single, batches[who], f"single trainer {who}")
         singles.append(store["g"])
     mean_grad = (singles[0] + singles[1]) / 2
 
     draws(dp, rank)
     seen = {}
     record_first_gradient(dp, seen)
-    dp.step(batches[rank])
+    watched_step(dp, batches[rank], "first step")
     grad_err = float((seen["g"] - mean_grad).abs().max() / mean_grad.abs().max())
-    dp.step(batches[rank])
+    watched_step(dp, batches[rank], "second step")
+    WATCH["phase"] = "gather after second step"
     weights = flat(dp.D.parameters()).to(dev)
     both = [torch.empty_like(weights) for _ in range(world)]
     dist.all_gather(both, weights)
@@ -114,9 +153,10 @@ def main():
     before = both[0].clone()
     raised = None
     try:
-        dp.step(batches[rank])
+        watched_step(dp, batches[rank], "third step")
     except RuntimeError as e:
         raised = str(e)
+    WATCH["phase"] = "gather after third step"
     weights = flat(dp.D.parameters()).to(dev)
     dist.all_gather(both, weights)
     after_failure_equal = bool(torch.equal(both[0], both[1]))
