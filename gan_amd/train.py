@@ -534,7 +534,7 @@ class Trainer:
 
     def _probe(self, label: str) -> None:
         if self.probes is not None:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.probes[label] = ev
 
@@ -643,6 +643,7 @@ class Trainer:
         failed: Optional[BaseException] = None
         main_stream = torch.cuda.current_stream(dev)
         self._mark("start")
+        self._probe("main: step start")
         real_replayed = False
         try:
             terms = self._captured_terms(real_padded)
@@ -932,6 +933,7 @@ class Trainer:
         elif raw_recorded:
             terms.add_fake_gradients(sign=-1.0)
         self.opt_G.step()
+        self._probe("main: step end")
         self.last.update(loss_G=loss_G.detach(), pen=loss_pen.detach())
         self._mark("generator done")
 
