@@ -379,6 +379,7 @@ class CapturedCriticTerms:
         instead of whenever the cyclic collector gets to it."""
         self.graph_real = self.graph_gp = None
         self._compute_gp = None
+        self.__dict__.pop("_fused_update", None)
         self._grads_real = self._grads_gp = ([], [])
         for side_ in (self.fk, self.rw):
             if side_ is not None:
@@ -470,6 +471,67 @@ class CapturedCriticTerms:
             torch._foreach_add_([p.grad for p in ps], gs)
 
 
+class FusedCriticUpdate:
+    """``opt_D.zero_grad(); (the three recorded terms' gradients summed into .grad); opt_D.step()`` of one critic
+    iteration (train.py:253,265-266) as ONE launch (``aig_adam_sum3``) instead of six: the gradients are the same
+    sums in the same order, the update is Adam's with the optimizer's own state tensors (its step counters included),
+    so iterations may go through this object or through ``opt_D.step()`` in any mix.
+
+    Built for one ``CapturedCriticTerms`` (whose gradient buffers have fixed addresses) once the optimizer holds
+    its state, i.e. after the first ordinary ``opt_D.step()``; ``valid()`` tells whether the tensors it points at are
+    still the parameters' (an eager iteration replaces the ``.grad`` tensors)."""
+
+    def __init__(self, opt: torch.optim.Adam, params: List[torch.Tensor], terms: "CapturedCriticTerms"):
+        import numpy as np
+        from . import _abi
+        group = opt.param_groups[0]
+        if len(opt.param_groups) != 1 or group.get("weight_decay", 0) != 0 or group.get("amsgrad") or group.get("maximize"):
+            raise ValueError("plain Adam only")
+        self.lr, (self.beta1, self.beta2), self.eps = float(group["lr"]), group["betas"], float(group["eps"])
+        lib = _abi.lib()
+        chunk = int(lib.aig_adam_chunk_elems())
+        # the three terms in the order their gradients are added (no terms: an update from .grad as it stands)
+        src = [dict(zip(ps, gs)) for ps, gs in ((terms.fk.grads, terms._grads_real, terms._grads_gp) if terms else ())]
+        src += [{}] * (3 - len(src))
+        recs, steps, key = [], [], []
+        for p in params:
+            st = opt.state.get(p, {})
+            if p.grad is None or not all(k in st for k in ("exp_avg", "exp_avg_sq", "step")):
+                raise ValueError("optimizer state not there yet")
+            gs = [d.get(p) for d in src]
+            tensors = [p, p.grad, st["exp_avg"], st["exp_avg_sq"]] + [g for g in gs if g is not None]
+            if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in tensors):
+                raise ValueError("contiguous float32 tensors on the device only")
+            if not (st["step"].is_cuda and st["step"].dtype == torch.float32):
+                raise ValueError("the optimizer's step counters must be float32 device tensors (fused Adam)")
+            steps.append(st["step"].data_ptr())
+            key.append((p.data_ptr(), p.grad.data_ptr()))
+            for off in range(0, p.numel(), chunk):
+                b = 4 * off
+                recs.append((p.data_ptr() + b, p.grad.data_ptr() + b) + tuple(0 if g is None else g.data_ptr() + b for g in gs) +
+                            (st["exp_avg"].data_ptr() + b, st["exp_avg_sq"].data_ptr() + b, min(chunk, p.numel() - off)))
+        self._keep = [opt.state[p] for p in params]
+        self.params, self.key = params, key
+        dev = params[0].device
+        self.table = torch.from_numpy(np.asarray(recs, dtype=np.int64).reshape(-1)).to(dev)
+        self.steps = torch.tensor(steps, dtype=torch.int64, device=dev)
+        self.nchunks, self.nsteps = len(recs), len(steps)
+
+    def valid(self) -> bool:
+        return all(p.grad is not None and (p.data_ptr(), p.grad.data_ptr()) == k for p, k in zip(self.params, self.key))
+
+    def apply(self, update_no: int, mode: int = 3) -> None:
+        """``update_no``: how many updates the optimizer has made, this one included.  ``mode`` 3: sums and update;
+        1: the sums alone (the ranks of a data-parallel run average the gradients next); 2: the update alone."""
+        from . import _abi
+        n = max(int(update_no), 1)
+        bc1 = 1.0 - self.beta1 ** n
+        bc2 = 1.0 - self.beta2 ** n
+        _abi.check(_abi.lib().aig_adam_sum3(self.nchunks, _abi.ptr(self.table), self.nsteps, _abi.ptr(self.steps),
+                                            float(n), self.lr, float(self.beta1), float(self.beta2), self.eps,
+                                            float(bc1), float(bc2 ** 0.5), int(mode), _abi.stream()), "aig_adam_sum3")
+
+
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -528,6 +590,10 @@ class Trainer:
         # backward pass changes nothing a run can observe.  Off by default (the step then does what the reference's
         # does); with it on, the generator step is the critic's forward pass over the raw graphs alone.
         self.skip_unused_backward = bool(getattr(args, "skip_unused_backward", False))
+        # one launch per critic iteration for zero_grad + the three gradient sums + Adam (FusedCriticUpdate) whenever
+        # all three terms of the iteration are recorded and no gradient exchange stands between them and the update
+        self.fused_update = not bool(getattr(args, "no_fused_update", False))
+        self._d_updates = 0      # updates opt_D has made (its step counters hold the same number)
         self._fake_caps: Dict[tuple, int] = {}   # by minibatch shape: level cap the generated side was found to need
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
         self.probes: Optional[dict] = None  # diagnosis aid: {label: event on whatever stream was current} of the last step
@@ -605,6 +671,37 @@ class Trainer:
         key = (terms.n, terms.e_cols)
         self._fake_caps[key] = 2 * int(generated.node_depth.max().item())
         self._captured.pop(key, None)
+
+    def _fused_for(self, terms: CapturedCriticTerms) -> Optional[FusedCriticUpdate]:
+        """The one-launch update for an iteration whose three terms are all recorded in ``terms`` (None: take the
+        separate launches - a generated side that is not recorded, optimizer state that does not exist before the
+        first ordinary step).  With more than one rank the sums and the update are two launches around the
+        gradient exchange."""
+        if not self.fused_update or terms.fk is None or terms.graph_gp is None:
+            return None
+        fused = terms.__dict__.get("_fused_update")
+        if fused is not None and fused.valid():
+            return fused
+        try:
+            fused = FusedCriticUpdate(self.opt_D, self._d_params, terms)
+        except ValueError:
+            return None
+        terms._fused_update = fused
+        return fused
+
+    def _dp_update(self) -> FusedCriticUpdate:
+        """The Adam half alone, from the averaged gradients in ``.grad`` (slices of the exchange buffer, so their
+        addresses never change); the optimizer's state is created here when no update has been made yet."""
+        upd = self.__dict__.get("_dp_adam")
+        if upd is None or not upd.valid():
+            for p in self._d_params:
+                st = self.opt_D.state[p]
+                if "exp_avg" not in st:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            upd = self._dp_adam = FusedCriticUpdate(self.opt_D, self._d_params, None)
+        return upd
 
     @property
     def edges_last_step(self) -> int:
@@ -753,12 +850,16 @@ class Trainer:
             step_start.record(main_stream)       # (what the third stream writes was last read before this point)
         raw_from = min(1, a.n_critic - 1)    # from this iteration on the second stream belongs to the raw graphs
         for it in range(a.n_critic):
+            updated = False      # this iteration's update has been made (by the one-launch form)
             if failed is None:
                 try:
                     # (an eager backward pass over the fakes installs its gradients as the .grad tensors - no
                     #  kernel - and the recorded terms are added to them; zeroed tensors would cost it an
                     #  accumulation launch per parameter)
-                    self.opt_D.zero_grad(set_to_none=not (fake_recorded or fake_pending))
+                    if terms is None:
+                        self.opt_D.zero_grad(set_to_none=True)
+                    # (with recorded terms the gradients are zeroed further down, right before their first use:
+                    #  when all three terms are recorded, one launch overwrites them instead)
                     if terms is not None:
                         # (once the raw graphs' pipeline occupies the second stream, the recorded pass over the
                         #  fakes follows the other two terms on this one)
@@ -810,12 +911,23 @@ class Trainer:
                         if fake_on_side or fake_here:
                             if it == a.n_critic - 1:      # (the buffer is written again by the generator step)
                                 D_fake_mean = terms.d_fake.clone()
-                            terms.add_fake_gradients()
+                            fused = self._fused_for(terms)
+                            if fused is not None and self.world == 1:
+                                self._d_updates += 1
+                                fused.apply(self._d_updates)       # zero_grad + the three sums + opt_D.step()
+                                updated = True
+                            elif fused is not None:
+                                fused.apply(0, mode=1)             # zero_grad + the three sums; the exchange is next
+                            else:
+                                self.opt_D.zero_grad(set_to_none=False)
+                                terms.add_fake_gradients()
+                                terms.add_gradients()
                             self._probe(f"main: generated side's gradients added {it}")
                         else:
+                            self.opt_D.zero_grad(set_to_none=True)
                             D_fake_mean = mean_score(D, fake_for_D)
                             D_fake_mean.backward()
-                        terms.add_gradients()
+                            terms.add_gradients()
                         self._probe(f"main: critic gradients {it}")
                         if it == a.n_critic - 1:   # the logged scalars are those of the last iteration (train.py:263-272)
                             D_real_mean, gp_term, grad_norm = terms.d_real.clone(), terms.gp.clone(), terms.grad_norm.clone()
@@ -844,8 +956,15 @@ class Trainer:
                     if self.world == 1:
                         raise
                     failed = e
+            if failed is None and updated:
+                continue
             if self.reducer.reduce(failed is None):
-                self.opt_D.step()
+                self._d_updates += 1
+                if self.world > 1 and self.fused_update:
+                    # every rank, every iteration through the same kernel: the ranks' weights stay bit-identical
+                    self._dp_update().apply(self._d_updates, mode=2)
+                else:
+                    self.opt_D.step()
         if failed is None and early_raw:
             # Host order: behind the replays of every critic iteration (cheap to enqueue), so the first stream has
             # its work queued while the host issues the ~100 small launches of the raw graphs' pipeline; on the
@@ -1062,6 +1181,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--capture-fake", choices=["auto", "on", "off"], default="auto",
                    help="also record the critic's pass over generated minibatches (fakes, raw graphs) as a HIP graph "
                         "(auto = on; off evaluates it eagerly every time)")
+    p.add_argument("--no-fused-update", dest="no_fused_update", action="store_true",
+                   help="zero the critic's gradients, add the recorded terms' gradients and step its optimizer as separate "
+                        "launches instead of one")
     p.add_argument("--skip-unused-backward", dest="skip_unused_backward", action="store_true",
                    help="leave out the backward pass of the generator step: it only reaches the critic's gradients, which "
                         "are zeroed before their next use (weights, metrics and samples are unchanged)")

@@ -279,6 +279,22 @@ int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_meta, const 
                            const float* w, const int32_t* argmax, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One critic iteration's update - opt_D.zero_grad(); loss_D.backward(); opt_D.step() of train.py:253,265-266 once
+ * the three terms' gradients exist: grad = g0 + g1 + g2 (in that order; a NULL term is skipped) and the Adam update
+ * (torch.optim.Adam without weight decay / amsgrad, train.py:221) of param, exp_avg, exp_avg_sq, in one launch.
+ * chunks: nchunks device records {float* param, *grad; const float* g0, *g1, *g2; float* exp_avg, *exp_avg_sq;
+ * int64 count} (64 bytes each), every record at most aig_adam_chunk_elems() consecutive elements of one tensor;
+ * step_ptrs: nsteps device pointers to the optimizer's float step counters, all set to step_value (the count
+ * INCLUDING this update); bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step).
+ * mode 3: both halves; mode 1: the sums alone (data-parallel ranks exchange the gradients next); mode 2: the update
+ * alone, from grad as it stands.
+ * ------------------------------------------------------------------------------------------- */
+int aig_adam_chunk_elems(void);
+int aig_adam_sum3(int64_t nchunks, const void* chunks, int64_t nsteps, const void* step_ptrs, float step_value, double lr,
+                  double beta1, double beta2, double eps, float bias_correction1, float bias_correction2_sqrt, int mode,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stable sort of (key, value) pairs by bits [0, bits) of the key - no counterpart in the reference (torch's sorts,
  * scatters and PyG's index bookkeeping stand where the library sorts: constraints.py:88-112, discriminator.py:83-96,
  * GATConv's aggregation).  The building block of the edge lists by target / by source, the level plans and the

@@ -274,3 +274,49 @@ def test_sanitize_drops_padding_edges():
     s = sanitize_for_D(g)
     assert s.edge_index.size(1) == 14 and int(s.edge_index.min()) >= 0 and s.edge_attr.size(0) == 14
     assert s.x is g.x and s.node_depth is g.node_depth
+
+
+def test_one_launch_update_matches_separate_launches():
+    """The one-launch form of a critic iteration's update (gradient sums + Adam, aig_adam_sum3) against the separate
+    launches it replaces (zero_grad, three multi-tensor adds, torch's fused Adam): the same steps from the same
+    weights and draws give the same critic, optimizer state and metrics."""
+    graphs = [synth_aig(6 + i, 50 + 9 * i, 3, seed=90 + i, window=10, orientation="dataset") for i in range(4)]
+    mn = max(g.x.size(0) for g in graphs)
+    me = max(g.edge_index.size(1) for g in graphs)
+    padded = [pad_data(g, mn, me) for g in graphs]
+    results = []
+    for extra in ([], ["--no-fused-update"]):
+        args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1000"] + extra)
+        args.level_cap = max(int(p.node_depth.max()) for p in padded)
+        tr = Trainer(args, mn, me, DEV)
+        tr.global_step = 1
+        tr.G.load_state_dict(gen_state())
+        tr.D.load_state_dict(omodel.init_discriminator_params(21))
+        g = torch.Generator().manual_seed(3)
+        draws_z = [torch.randn(128, generator=g) for _ in range(64)]
+        draws_a = [torch.rand(1, 1, generator=g) for _ in range(64)]
+        zi, ai = iter(draws_z), iter(draws_a)
+        tr.draw_z = lambda: next(zi).to(DEV)
+        tr.draw_alpha = lambda: next(ai).to(DEV)
+        rows = []
+        for step in range(6):
+            b = Batch.from_data_list([padded[(2 * step) % 4], padded[(2 * step + 1) % 4]]).to(DEV)
+            b.sample_ids = [(2 * step) % 4, (2 * step + 1) % 4]
+            rows.append({k: float(v) for k, v in tr.step(b).items()})
+        used = [t.__dict__.get("_fused_update") is not None for t in tr._captured.values()]
+        state = {k: v.detach().cpu().clone() for k, v in tr.D.state_dict().items()}
+        moments = [(tr.opt_D.state[p]["exp_avg"].cpu().clone(), tr.opt_D.state[p]["exp_avg_sq"].cpu().clone(),
+                    float(tr.opt_D.state[p]["step"])) for p in tr._d_params]
+        grads = [p.grad.detach().cpu().clone() for p in tr._d_params]
+        results.append((rows, state, moments, grads, used, tr._d_updates))
+    (r1, s1, m1, g1, used1, n1), (r2, s2, m2, g2, used2, n2) = results
+    assert any(used1) and not any(used2)
+    assert n1 == n2 == 18 and all(m[2] == 18.0 for m in m1) and all(m[2] == 18.0 for m in m2)
+    for a_, b_ in zip(r1, r2):
+        for k in a_:
+            assert rel(a_[k], b_[k]) <= 1e-5, (k, a_[k], b_[k])
+    for k in s1:
+        assert float((s1[k] - s2[k]).abs().max()) <= 1e-6 + 1e-5 * float(s2[k].abs().max()), k
+    for (ea1, es1, _), (ea2, es2, _) in zip(m1, m2):
+        assert float((ea1 - ea2).abs().max()) <= 1e-6 + 1e-4 * float(ea2.abs().max())
+        assert float((es1 - es2).abs().max()) <= 1e-9 + 1e-4 * float(es2.abs().max())
