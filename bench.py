@@ -407,6 +407,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true",
                     help="skip the short ISCAS85-sized measurement reported next to the main line at N=1")
+    ap.add_argument("--trainer-args", default="", help="further train.py flags for the trainer (diagnosis), space-separated")
+    ap.add_argument("--no-fused-update", action="store_true",
+                    help="train.py's --no-fused-update: a critic iteration's update as separate launches")
     ap.add_argument("--capture-fake", default="auto", choices=["auto", "on", "off"],
                     help="record the critic's pass over generated graphs too (train.py's option of the same name)")
     ap.add_argument("--distinct", type=int, default=None,
@@ -445,7 +448,8 @@ def main():
     groups, desc = workload_minibatches(a.workload, rank, a.distinct)
     batches, max_nodes, max_edges, top = device_minibatches(groups, dev)
     targs = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000",
-                                       "--capture-fake", a.capture_fake])
+                                       "--capture-fake", a.capture_fake] + (["--no-fused-update"] if a.no_fused_update else []) +
+                                      a.trainer_args.split())
     targs.level_cap = top        # train.py sizes the recorded critic terms by the deepest graph of the dataset
     trainer = Trainer(targs, max_nodes, max_edges, dev, rank, world)
     trainer.global_step = 1      # step 0 would add the save-step validation pass; steady state is measured
@@ -457,6 +461,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("AIG_BENCH_TRACE") == "1"
+
+    def phase(name):
+        if trace:
+            print(f"[bench rank {rank}] {name}", file=sys.stderr, flush=True)
+
+    if trace:     # a run that stalls says where: the step's probe events, the two streams, every thread's stack
+        import faulthandler
+        import threading
+        trainer.probes = {}
+        inner_step = trainer.step
+
+        def probed_step(*args, **kw):
+            trainer.probes = {}
+            return inner_step(*args, **kw)
+        trainer.step = probed_step
+
+        def watch():
+            time.sleep(float(os.environ.get("AIG_BENCH_TRACE_LIMIT", "90")))
+            out = {"rank": rank, "global_step": trainer.global_step, "captures": trainer.captures,
+                   "main_idle": torch.cuda.default_stream(dev).query(), "side_idle": trainer.side_stream.query(),
+                   "probes": {k: v.query() for k, v in dict(trainer.probes or {}).items()}}
+            print("[bench watchdog] " + json.dumps(out), file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(all_threads=True)
+            os._exit(3)
+        threading.Thread(target=watch, daemon=True).start()
+
     def run_steps(count, start=0, only=None):
         edges = torch.zeros((), dtype=torch.long, device=dev)
         for i in range(count):
@@ -467,7 +498,9 @@ def main():
     # Set-up, not measured: one pass over the rank's minibatches, as the first epoch of a run - it builds what
     # train.py keeps per dataset sample (the template and its generator plan) and the one recording of the critic
     # terms for this minibatch shape.  Then the W warm-up steps, then the K timed steps, all in rotation.
+    phase("set-up pass")
     run_steps(nb)
+    phase("set-up pass enqueued")
     # what exists now lives as long as the run (dataset, templates, plans, recordings): taken out of the cyclic
     # collector's sight, as gan_amd.train.train does after its first epoch's set-up - a full collection over these
     # ~270k objects is a 100 ms stall in the middle of some step otherwise
@@ -485,6 +518,7 @@ def main():
     recordings = trainer.captures
     # the same step count on ONE minibatch over and over (every per-object cache hot): the figure a loop that
     # never changes its input would report, kept beside the rotating one
+    phase("headline loop done; repeated-batch loop")
     run_steps(3, only=batches[0])      # (the allocator settles into the new pattern of requests first)
     barrier()
     r0 = time.perf_counter()
@@ -494,6 +528,7 @@ def main():
     # The same rotation with the generator step's unused backward pass left out (``Trainer.skip_unused_backward``:
     # train.py:298 back-propagates loss_G into the critic, whose gradients train.py:253 zeroes before their next
     # use).  An extension reported beside the headline, never as it: the headline step does all the reference does.
+    phase("loop without the unused backward pass")
     trainer.skip_unused_backward = True
     for terms in trainer._captured.values():
         terms.release()
@@ -516,6 +551,7 @@ def main():
     # library brackets the roofline kernel - the kernel alone, by events its own dispatch carries
     # (aig_kernel_timing) - and notes the sizes of the aggregate's launches.  Bracketing every entry point slowed
     # the step by 10-50 %, so only this one kernel carries events here.
+    phase("roofline loop")
     ms_eager_side = None
     kt_fake = {}
     if not a.no_kernel_timing:
@@ -535,6 +571,7 @@ def main():
         kt_fake = read_kernel_times(lib)
         lib.aig_kernel_timing(0)
         _abi.timeline.sizes_of = None
+    phase("instrumented steps")
     tl_meta = dict(_abi.timeline.meta)
     # per-entry-point GPU time from a few extra, untimed, fully instrumented steps
     inst_steps = min(3, a.steps)
@@ -561,6 +598,7 @@ def main():
     else:
         edges_total = float(edges_rank)
 
+    phase("sampling")
     # ---- sampling throughput (generator + repair + resync), same templates, fresh z per sample
     templates = trainer.templates_of(batch)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
