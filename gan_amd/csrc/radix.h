@@ -4,9 +4,10 @@
 // The library sort (rocprim::radix_sort_pairs) takes its merge-sort path below a million items - a block sort and
 // log2(items / block) merge passes, ten launches and ~60 us for 200,000 pairs - and its one-sweep path costs ~90 us
 // at any of these sizes.  Here a pass over a 9-bit digit is two launches: per-tile digit histograms, then a scatter
-// in which every tile adds up the histograms of the tiles before it by itself (at most RS_MAX_TILES tiles of 8 to 32
-// thousand items, so that sum is 32 coalesced loads per thread) - no scan kernel, no look-back state, nothing to clear.
-// 17-bit node ids are two passes = four launches.  Sizes and key widths outside that range go to the library sort.
+// in which every tile adds up the histograms of the tiles before it by itself (at most RS_MAX_TILES tiles of 8,192 or
+// 16,384 items, so that sum is 32 coalesced loads per thread) - no scan kernel, no look-back state, nothing to clear.
+// 17-bit node ids are two passes = four launches (~31 us of kernel time at 200,000 pairs).  More than three passes,
+// more than 524,288 items (262,144 with 8-byte keys) or fewer than 1,025 go to the library sort.
 //
 // Stability (equal keys keep their input order) is what the callers rely on: edge lists by target keep the order of
 // the edge slots, which fixes the order of every floating-point sum over a node's edges.
