@@ -66,6 +66,7 @@ SIGNATURES = {
     "aig_adam_chunk_elems": (INT, []),
     "aig_adam_sum3": (INT, [I64, P, I64, P, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float,
                             C.c_float, INT, P]),
+    "aig_step_metrics": (INT, [I64, P, P, P, P, P, P, C.c_float, C.c_float, C.c_float, P, P]),
     "aig_sort_pairs_ws_bytes": (SZ, [I64, INT, INT]),
     "aig_sort_pairs": (INT, [I64, INT, INT, P, P, P, P, P, SZ, P]),
     "aig_gp_input_grad_ws_bytes": (SZ, [I64]),

@@ -77,3 +77,42 @@ extern "C" int aig_adam_sum3(int64_t nchunks, const void* chunks, int64_t nsteps
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
+
+// ------------------------------------------------------------------------------------------ the step's logged scalars
+namespace aig {
+namespace {
+// out8 = {D_real, D_fake, gap, gp, grad_norm, loss_D, loss_G, pen} of train.py:263-272,289-296 from the device
+// scalars the recorded terms leave behind: gap = D_real - D_fake, loss_D = (D_fake - D_real) + gp_lambda gp,
+// pen = pen_scale * mean_g pen9[g][8], loss_G = -D_raw + lambda_cons pen.  One thread: a dozen scalar launches otherwise.
+__global__ void k_step_metrics(int B, const float* __restrict__ d_real, const float* __restrict__ d_fake,
+                               const float* __restrict__ gp, const float* __restrict__ grad_norm,
+                               const float* __restrict__ d_raw, const float* __restrict__ pen9, float gp_lambda,
+                               float lambda_cons, float pen_scale, float* __restrict__ out8) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float dr = d_real[0], df = d_fake[0], g = gp[0];
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) s += pen9[9 * i + 8];
+    float pen = s / (float)B;
+    if (pen_scale != 1.f) pen = pen * pen_scale;
+    out8[0] = dr;
+    out8[1] = df;
+    out8[2] = dr - df;
+    out8[3] = g;
+    out8[4] = grad_norm[0];
+    out8[5] = (df - dr) + gp_lambda * g;
+    out8[6] = -d_raw[0] + lambda_cons * pen;
+    out8[7] = pen;
+}
+}  // namespace
+}  // namespace aig
+
+extern "C" int aig_step_metrics(int64_t B, const float* d_real, const float* d_fake, const float* gp, const float* grad_norm,
+                                const float* d_raw, const float* pen9, float gp_lambda, float lambda_cons, float pen_scale,
+                                float* out8, void* stream) {
+    AIG_REQUIRE(B >= 1 && B < INT_MAX, "aig_step_metrics: needs at least one graph");
+    AIG_REQUIRE(d_real && d_fake && gp && grad_norm && d_raw && pen9 && out8, "aig_step_metrics: null pointer");
+    hipLaunchKernelGGL(k_step_metrics, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), (int)B, d_real, d_fake, gp,
+                       grad_norm, d_raw, pen9, gp_lambda, lambda_cons, pen_scale, out8);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}

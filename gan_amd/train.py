@@ -849,6 +849,10 @@ class Trainer:
             step_start = torch.cuda.Event()
             step_start.record(main_stream)       # (what the third stream writes was last read before this point)
         raw_from = min(1, a.n_critic - 1)    # from this iteration on the second stream belongs to the raw graphs
+        # the logged scalars in one launch at the end of the step (aig_step_metrics) when every number they are
+        # made of sits in a buffer of the recordings until then
+        metrics_late = False
+        pen_all = None
         for it in range(a.n_critic):
             updated = False      # this iteration's update has been made (by the one-launch form)
             if failed is None:
@@ -909,8 +913,10 @@ class Trainer:
                         if fake_on_side:
                             main_stream.wait_stream(self.side_stream)
                         if fake_on_side or fake_here:
-                            if it == a.n_critic - 1:      # (the buffer is written again by the generator step)
-                                D_fake_mean = terms.d_fake.clone()
+                            if it == a.n_critic - 1:
+                                metrics_late = early_raw and self.fused_update
+                                if not metrics_late:      # (the buffer is written again by the generator step)
+                                    D_fake_mean = terms.d_fake.clone()
                             fused = self._fused_for(terms)
                             if fused is not None and self.world == 1:
                                 self._d_updates += 1
@@ -929,7 +935,7 @@ class Trainer:
                             D_fake_mean.backward()
                             terms.add_gradients()
                         self._probe(f"main: critic gradients {it}")
-                        if it == a.n_critic - 1:   # the logged scalars are those of the last iteration (train.py:263-272)
+                        if it == a.n_critic - 1 and not metrics_late:   # the logged scalars are those of the last iteration (train.py:263-272)
                             D_real_mean, gp_term, grad_norm = terms.d_real.clone(), terms.gp.clone(), terms.grad_norm.clone()
                             gap = D_real_mean - D_fake_mean.detach()
                             loss_D = (D_fake_mean.detach() - D_real_mean) + a.gp_lambda * gp_term
@@ -949,7 +955,7 @@ class Trainer:
                                                                   alpha=self.draw_alpha())
                             loss_D = (D_fake_mean - D_real_mean) + a.gp_lambda * gp_term
                             loss_D.backward()
-                    if it == a.n_critic - 1:
+                    if it == a.n_critic - 1 and not metrics_late:
                         self.last = dict(D_real=D_real_mean.detach(), D_fake=D_fake_mean.detach(), gap=gap.detach(),
                                          gp=gp_term.detach(), grad_norm=grad_norm.detach(), loss_D=loss_D.detach())
                 except Exception as e:
@@ -978,7 +984,8 @@ class Trainer:
                     raw_loaded = torch.cuda.Event()
                     raw_loaded.record()
                     self._probe("side: raw graphs loaded")
-                    loss_pen = penalties_set(raw_set)[:, 8].mean()
+                    pen_all = penalties_set(raw_set)
+                    loss_pen = pen_all if metrics_late else pen_all[:, 8].mean()
                     self._probe("side: penalties")
             except Exception as e:
                 if self.world == 1:
@@ -1017,7 +1024,7 @@ class Trainer:
         if early_raw:
             main_stream.wait_event(raw_loaded)
             terms.replay_raw()
-            loss_G_adv = -terms.rw.d.clone()
+            loss_G_adv = None if metrics_late else -terms.rw.d.clone()
             self._probe("main: raw graphs scored")
         elif raw_recorded and not self.skip_unused_backward:
             terms.load_generated(raw_batch_for_D, check=False)
@@ -1039,12 +1046,26 @@ class Trainer:
             loss_G_adv.backward()
         main_stream.wait_stream(pen_stream)
         loss_pen.record_stream(main_stream)
+        pen_scale = None
         if (self.global_step % a.save_every) == 0:
             if raw_gen is None:
                 raw_gen = raw_set.graphs()
             scales = [10.0 if len(validate_strict_aig(r, check_all_on_path=True)) > 0 else 1.0 for r in raw_gen]
-            loss_pen = loss_pen * torch.tensor(scales, dtype=torch.float32, device=dev).mean()
-        loss_G = loss_G_adv.detach() + a.lambda_cons * loss_pen
+            pen_scale = torch.tensor(scales, dtype=torch.float32).mean()
+            if not metrics_late:
+                loss_pen = loss_pen * pen_scale.to(dev)
+        if metrics_late:
+            from . import _abi
+            out8 = torch.empty(8, dtype=torch.float32, device=dev)
+            _abi.check(_abi.lib().aig_step_metrics(int(pen_all.size(0)), _abi.ptr(terms.d_real), _abi.ptr(terms.d_fake),
+                                                   _abi.ptr(terms.gp), _abi.ptr(terms.grad_norm), _abi.ptr(terms.rw.d),
+                                                   _abi.ptr(pen_all), float(a.gp_lambda), float(a.lambda_cons),
+                                                   1.0 if pen_scale is None else float(pen_scale), _abi.ptr(out8),
+                                                   _abi.stream()), "aig_step_metrics")
+            self.last = dict(zip(("D_real", "D_fake", "gap", "gp", "grad_norm", "loss_D"), out8[:6].unbind()))
+            loss_G, loss_pen = out8[6], out8[7]
+        else:
+            loss_G = loss_G_adv.detach() + a.lambda_cons * loss_pen
         if early_raw:
             # loss_G.backward(): only the critic's parameters receive a gradient (train.py:297-299) - the
             # recorded gradient of D(raw), negated

@@ -294,6 +294,14 @@ int aig_adam_sum3(int64_t nchunks, const void* chunks, int64_t nsteps, const voi
                   double beta1, double beta2, double eps, float bias_correction1, float bias_correction2_sqrt, int mode,
                   void* stream);
 
+/* The scalars a training step logs (train.py:263-272,289-296, 302-311) from the device scalars the terms leave:
+ * out8 = {D_real, D_fake, gap = D_real - D_fake, gp, grad_norm, loss_D = (D_fake - D_real) + gp_lambda gp,
+ * loss_G = -D_raw + lambda_cons pen, pen = pen_scale * mean over the B graphs of pen9[g][8]} (pen9: the [B,9] rows of
+ * aig_penalties_batch; pen_scale: the save step's validation factor, 1 otherwise).  One launch for a dozen. */
+int aig_step_metrics(int64_t B, const float* d_real, const float* d_fake, const float* gp, const float* grad_norm,
+                     const float* d_raw, const float* pen9, float gp_lambda, float lambda_cons, float pen_scale,
+                     float* out8, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stable sort of (key, value) pairs by bits [0, bits) of the key - no counterpart in the reference (torch's sorts,
  * scatters and PyG's index bookkeeping stand where the library sorts: constraints.py:88-112, discriminator.py:83-96,
