@@ -789,8 +789,15 @@ class Trainer:
                             edges = pad_set(corr_set, self.max_edges)
                             ready = torch.cuda.Event()
                             ready.record()        # the critic's edge lists of the fakes can be built from here on
+                            # ... and with a recording of the generated side they are, right here: the two dozen
+                            # small launches behind its edge lists and level plan run on this stream, underneath
+                            # the first stream's real-side and penalty terms, instead of in front of its replay
+                            if terms.fake_side:
+                                terms.fk.load_edges(edges[0], edges[1])
                             corr_set.node_depth = clean_depth_set(raw_fakes_set)
                             padded = self._pad_set(corr_set, edges)
+                            if terms.fake_side:
+                                terms.fk.load_depth(padded.node_depth, check=False)
                             self._probe("side: fakes' levels and padding")
                             return padded, count_edges(padded.edge_index), ready
                     fake_padded = None
@@ -882,10 +889,6 @@ class Trainer:
                         if finish_fakes is not None:
                             fake_padded, edges_fake, edges_ready = finish_fakes()
                             fake_for_D, finish_fakes = fake_padded, None
-                        if fake_pending and edges_ready is not None:
-                            # the fakes' edge lists are rebuilt while their level walk is still under way
-                            main_stream.wait_event(edges_ready)
-                            terms.fk.load_edges(fake_padded.edge_index, fake_padded.edge_attr)
                         if deferred_wait:
                             main_stream.wait_stream(fakes_stream)
                             deferred_wait = False
@@ -895,8 +898,8 @@ class Trainer:
                             # level plan is rebuilt now (one host read: does the recording hold their depth?)
                             # and the recorded pass over them follows on this stream
                             fake_pending = False
-                            if edges_ready is not None:
-                                fake_recorded = terms.fk.load_depth(fake_padded.node_depth)
+                            if edges_ready is not None:      # (loaded on the second stream, see finish_fakes)
+                                fake_recorded = not terms.fk.plan.overflowed()
                             else:
                                 fake_recorded = terms.load_generated(fake_padded)
                             if fake_recorded:
