@@ -13,7 +13,7 @@ for r in rows:
     wx = max(int(r.get('Workgroup_Size_X', r.get('Workgroup_Size', 1)) or 1), 1) * max(int(r.get('Workgroup_Size_Y', 1) or 1), 1)
     r['wgs'] = gx // wx
 rows.sort(key=lambda r: r['s'])
-adam = [r for r in rows if 'multi_tensor_apply' in r['Kernel_Name'] and 'Adam' in r['Kernel_Name'] or 'FusedAdam' in r['Kernel_Name'] or 'fused_adam' in r['Kernel_Name'].lower()]
+adam = [r for r in rows if 'k_adam_sum3' in r['Kernel_Name'] or 'multi_tensor_apply' in r['Kernel_Name'] and 'Adam' in r['Kernel_Name'] or 'FusedAdam' in r['Kernel_Name'] or 'fused_adam' in r['Kernel_Name'].lower()]
 print("adam-like launches:", len(adam), "of", len(rows), "kernels")
 def union(iv):
     iv = sorted(iv); tot = 0; cs, ce = None, None
