@@ -99,8 +99,9 @@ __global__ void k_step_metrics(int B, const float* __restrict__ d_real, const fl
     out8[2] = dr - df;
     out8[3] = g;
     out8[4] = grad_norm[0];
-    out8[5] = (df - dr) + gp_lambda * g;
-    out8[6] = -d_raw[0] + lambda_cons * pen;
+    // (products and sums rounded separately, as the tensor expressions they replace: no contraction into fma)
+    out8[5] = __fadd_rn(df - dr, __fmul_rn(gp_lambda, g));
+    out8[6] = __fadd_rn(-d_raw[0], __fmul_rn(lambda_cons, pen));
     out8[7] = pen;
 }
 }  // namespace
