@@ -287,7 +287,7 @@ def bulk_sampling(a, rank, world, dev):
     candidate-k 256 with the node projections on the bf16 matrix cores, no collective (ranks only meet at the
     timing barriers).  A step = one block of --bulk-batch samples that goes through generator, repair and resync
     as one set of graphs (gan_amd.sample.sample_sets).  Rank 0 prints the JSON line."""
-    from gan_amd import _abi
+    from gan_amd import _abi, parallel
     from gan_amd.data import Data
     from gan_amd.generator import AIGGenerator
     from gan_amd.sample import sample_bulk
@@ -307,7 +307,7 @@ def bulk_sampling(a, rank, world, dev):
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -324,8 +324,8 @@ def bulk_sampling(a, rank, world, dev):
     barrier()
     elapsed = time.perf_counter() - t0
     stat = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(stat, op=dist.ReduceOp.MAX)
+    if dist.is_initialized():
+        parallel.all_reduce(stat, op=dist.ReduceOp.MAX)
         elapsed = float(stat.item())
     # the projection launch of a block, bracketed with events in one extra untimed step
     entry = "aig_gen_node_proj_batch"
@@ -440,7 +440,7 @@ def main():
 
     if a.workload == "bulk_k256":
         bulk_sampling(a, rank, world, dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -452,12 +452,13 @@ def main():
                                       a.trainer_args.split())
     targs.level_cap = top        # train.py sizes the recorded critic terms by the deepest graph of the dataset
     trainer = Trainer(targs, max_nodes, max_edges, dev, rank, world)
+    trainer_exchanges = trainer.exchange
     trainer.global_step = 1      # step 0 would add the save-step validation pass; steady state is measured
     nb = len(batches)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -589,11 +590,11 @@ def main():
 
     edges_rank = int(edges_dev.item())
     stat = torch.tensor([elapsed, float(edges_rank)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():      # (also with a one-rank communicator: AIG_DP_FORCE=1, see gan_amd/parallel.py)
         tmax = stat[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        parallel.all_reduce(tmax, op=dist.ReduceOp.MAX)
         esum = stat[1:].clone()
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        parallel.all_reduce(esum, op=dist.ReduceOp.SUM)
         elapsed, edges_total = float(tmax.item()), float(esum.item())
     else:
         edges_total = float(edges_rank)
@@ -613,8 +614,8 @@ def main():
         run(a.sample_iters)
         barrier()
         s_stat = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(s_stat, op=dist.ReduceOp.MAX)
+        if dist.is_initialized():
+            parallel.all_reduce(s_stat, op=dist.ReduceOp.MAX)
         return nodes_per_iter * per_iter * a.sample_iters * world / float(s_stat.item())
 
     def one_at_a_time(iters):
@@ -735,7 +736,12 @@ def main():
                                    "region; candidate-k 64, n_critic 3, hidden 128, fp32",
                        "distinct_minibatches_per_gpu": nb, "critic_term_recordings": recordings,
                        "edges_per_step_per_gpu": round(edges_rank / a.steps, 1),
-                       "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}"},
+                       "nodes_per_step_per_gpu": nodes_per_iter, "parallelism": f"dp{world}",
+                       # ranks of the RCCL communicator the gradient exchange went through (0: no communicator; a
+                       # rehearsal over gloo on shared devices is named as such)
+                       "rccl_ranks": (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0),
+                       "exchange_backend": dist.get_backend() if dist.is_initialized() else None,
+                       "gradient_exchanges_per_step": targs.n_critic if trainer_exchanges else 0},
             "sample_nodes_per_sec": round(sample_nodes_per_sec, 1),
             "sample_nodes_per_sec_streams": round(sample_nodes_per_sec_streams, 1),
             "sample_nodes_per_sec_one_at_a_time": round(sample_nodes_per_sec_single, 1),
@@ -765,7 +771,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

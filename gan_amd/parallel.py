@@ -25,12 +25,26 @@ def env_world() -> tuple:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def one_rank_exchange_requested() -> bool:
+    """``AIG_DP_FORCE=1`` under a launcher that set the rendezvous variables: a communicator of ONE rank is still
+    made and every gradient exchange, barrier and timing reduction goes through it - the whole multi-rank code path
+    over the real library on a box with a single GPU (RCCL wants a device per rank)."""
+    return os.environ.get("AIG_DP_FORCE") == "1" and "MASTER_ADDR" in os.environ
+
+
+def exchanging() -> bool:
+    """Do gradients go through a collective in this process?  More than one rank, or one rank made to."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or one_rank_exchange_requested()
+
+
 def init_distributed(backend: Optional[str] = None) -> tuple:
     rank, local_rank, world = env_world()
     # this ROCm stack shares device memory between processes through dmabuf only; RCCL needs it said before
     # the HIP runtime starts (an environment that already says otherwise is left alone)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or one_rank_exchange_requested()) and not dist.is_initialized():
         if backend is None:
             # "nccl" is RCCL on ROCm; AIG_DIST_BACKEND=gloo lets several ranks rehearse on one GPU
             backend = os.environ.get("AIG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -40,16 +54,45 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, local_rank, world
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """Device tensors of a gloo group (several ranks rehearsing on one GPU; RCCL needs a device per rank) are
+    exchanged through an explicit host copy made on the CALLER's stream.  Handed a device tensor, gloo stages it
+    itself on streams of its own and makes the caller's stream wait for them; with two processes sharing one GPU's
+    hardware queues the caller's stream was seen parked behind such a wait for good (the step's next replay never
+    started while every stream of the process this package made was idle)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce(t: torch.Tensor, op=None) -> None:
+    """``dist.all_reduce`` in place; over RCCL as it stands, over gloo through the host (see ``_host_staged``)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t):
+        host = t.cpu()                      # waits for the current stream up to here, and for nothing else
+        dist.all_reduce(host, op=op)
+        t.copy_(host)                       # on the current stream
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def broadcast(t: torch.Tensor, src: int = 0) -> None:
+    if _host_staged(t):
+        host = t.cpu()
+        dist.broadcast(host, src=src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def broadcast_parameters(modules: Iterable[torch.nn.Module], src: int = 0) -> None:
     """Every rank starts from rank ``src``'s weights (one flat broadcast per module)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not exchanging():
         return
     for m in modules:
         tensors = [p.data for p in m.parameters()] + [b.data for b in m.buffers()]
         if not tensors:
             continue
         flat = torch.cat([t.reshape(-1).float() for t in tensors])
-        dist.broadcast(flat, src=src)
+        broadcast(flat, src=src)
         off = 0
         for t in tensors:
             t.copy_(flat[off:off + t.numel()].view_as(t))
@@ -77,7 +120,8 @@ class FlatGradAllReduce:
         self.numel = sum(p.numel() for p in self.params)
         first = self.params[0]
         self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=first.device)
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # (2 stands for "exchanging": a one-rank communicator made to exchange counts its single report)
+        self.world = (max(dist.get_world_size(), 2) if exchanging() else 1)
         self._flags = torch.tensor([0.0, 1.0], dtype=torch.float32, device=first.device)
         self._view_cache = None
         if self.world > 1:
@@ -102,7 +146,7 @@ class FlatGradAllReduce:
         else:
             self.flat.zero_()
         self.flat[n:].copy_(self._flags[1:2] if ok else self._flags[0:1])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        all_reduce(self.flat)
         self.flat[:n].div_(self.flat[n].clamp(min=1.0))   # valid ranks, counted on the device
         for p, v in zip(self.params, views):
             p.grad = v

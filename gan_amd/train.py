@@ -550,6 +550,8 @@ class Trainer:
 
     def __init__(self, args, max_nodes: int, max_edges: int, device: torch.device, rank: int = 0, world: int = 1):
         self.args, self.device, self.rank, self.world = args, device, rank, world
+        # gradients are exchanged between ranks (or through a one-rank communicator made to, see gan_amd/parallel.py)
+        self.exchange = world > 1 or parallel.exchanging()
         self.max_nodes, self.max_edges = max_nodes, max_edges
         self.G = AIGGenerator(node_in_dim=2, hidden_dim=args.g_hidden, z_dim=args.z_dim,
                               candidate_k=args.candidate_k).to(device)
@@ -838,7 +840,7 @@ class Trainer:
                         if p_.grad is None:        # into .grad tensors that are zeroed in place
                             p_.grad = torch.zeros_like(p_)
         except Exception as e:
-            if self.world == 1:
+            if not self.exchange:
                 raise
             failed = e
         # The generator step's inputs early: with a recording of their own for the raw graphs (``terms.rw``), the
@@ -921,9 +923,9 @@ class Trainer:
                                 if not metrics_late:      # (the buffer is written again by the generator step)
                                     D_fake_mean = terms.d_fake.clone()
                             fused = self._fused_for(terms)
-                            if fused is not None and self.world == 1:
-                                self._d_updates += 1
-                                fused.apply(self._d_updates)       # zero_grad + the three sums + opt_D.step()
+                            if fused is not None and not self.exchange:
+                                fused.apply(self._d_updates + 1)   # zero_grad + the three sums + opt_D.step()
+                                self._d_updates += 1               # (counted once the launch is in the queue)
                                 updated = True
                             elif fused is not None:
                                 fused.apply(0, mode=1)             # zero_grad + the three sums; the exchange is next
@@ -962,18 +964,18 @@ class Trainer:
                         self.last = dict(D_real=D_real_mean.detach(), D_fake=D_fake_mean.detach(), gap=gap.detach(),
                                          gp=gp_term.detach(), grad_norm=grad_norm.detach(), loss_D=loss_D.detach())
                 except Exception as e:
-                    if self.world == 1:
+                    if not self.exchange:
                         raise
                     failed = e
             if failed is None and updated:
                 continue
             if self.reducer.reduce(failed is None):
-                self._d_updates += 1
-                if self.world > 1 and self.fused_update:
+                if self.exchange and self.fused_update:
                     # every rank, every iteration through the same kernel: the ranks' weights stay bit-identical
-                    self._dp_update().apply(self._d_updates, mode=2)
+                    self._dp_update().apply(self._d_updates + 1, mode=2)
                 else:
                     self.opt_D.step()
+                self._d_updates += 1      # (after the update is enqueued: a step that raises before leaves the count alone)
         if failed is None and early_raw:
             # Host order: behind the replays of every critic iteration (cheap to enqueue), so the first stream has
             # its work queued while the host issues the ~100 small launches of the raw graphs' pipeline; on the
@@ -991,7 +993,7 @@ class Trainer:
                     loss_pen = pen_all if metrics_late else pen_all[:, 8].mean()
                     self._probe("side: penalties")
             except Exception as e:
-                if self.world == 1:
+                if not self.exchange:
                     raise
                 failed = e
         if failed is not None:

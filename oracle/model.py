@@ -245,29 +245,65 @@ def level_readout(h: torch.Tensor, node_depth: Optional[torch.Tensor]) -> torch.
     return torch.stack(vecs, 0).mean(0, keepdim=True)
 
 
+def level_readout_segmented(h: torch.Tensor, node_depth: Optional[torch.Tensor]) -> torch.Tensor:
+    """The same readout as ``level_readout`` (models/discriminator.py:64-96) without its loop over levels, for
+    graphs of 10^5 nodes and hundreds of levels where the loop's backward pass fills an [N, H] array per level.
+    Nodes are ordered by (level, node id); a level's mean is its segment's sum over its count; a level's maximum
+    is read from ONE row per column - the first node of the level, in node order, that holds the maximum, the row
+    ``sub.max(0)`` differentiates through - so first and second derivatives follow the loop's.  The sums are
+    added in another order than ``mean(0)`` adds them: equal to the loop within rounding, not bit for bit
+    (tests/test_oracle_golden.py holds it to the loop, values and gradients)."""
+    if node_depth is None:
+        return level_readout(h, None)
+    nd = node_depth.long()
+    valid = nd >= 0
+    if int(valid.sum()) == 0:
+        return level_readout(h, node_depth)
+    ids = torch.nonzero(valid).reshape(-1)
+    lv = nd[ids]
+    order = torch.argsort(lv, stable=True)          # ids ascend, so a level's nodes stay in node order
+    ids, lv = ids[order], lv[order]
+    levels = int(lv.max().item()) + 1
+    rows = h[ids]                                   # [M, H]
+    hdim = h.size(1)
+    cnt = torch.zeros(levels, dtype=h.dtype).index_add_(0, lv, torch.ones(lv.numel(), dtype=h.dtype))
+    mean = torch.zeros((levels, hdim), dtype=h.dtype).index_add(0, lv, rows) / cnt.clamp(min=1).unsqueeze(1)
+    idx = lv.unsqueeze(1).expand(-1, hdim)
+    top = torch.full((levels, hdim), float("-inf"), dtype=h.dtype).scatter_reduce(
+        0, idx, rows.detach(), reduce="amax", include_self=True)
+    pos = torch.arange(rows.size(0)).unsqueeze(1).expand(-1, hdim)
+    first = torch.where(rows.detach() == top[lv], pos, torch.full_like(pos, rows.size(0)))
+    arg = torch.full((levels, hdim), rows.size(0), dtype=torch.long).scatter_reduce(0, idx, first, reduce="amin", include_self=True)
+    filled = cnt > 0
+    arg = torch.where(filled.unsqueeze(1), arg, torch.zeros_like(arg))
+    mx = rows.gather(0, arg) * filled.unsqueeze(1).to(h.dtype)          # an empty level is a row of zeros
+    return torch.cat([mean, mx], 1).mean(0, keepdim=True)
+
+
 def discriminator_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, edge_index: torch.Tensor,
                           edge_attr: Optional[torch.Tensor], node_depth: Optional[torch.Tensor],
-                          heads: int = 4) -> torch.Tensor:
-    """models/discriminator.py:42-100 -> tensor [1]."""
+                          heads: int = 4, readout=None) -> torch.Tensor:
+    """models/discriminator.py:42-100 -> tensor [1].  ``readout``: ``level_readout`` (the loop of
+    discriminator.py:78-87, the default) or ``level_readout_segmented``."""
     x = x.float()
     if edge_attr is None:
         edge_attr = torch.zeros((edge_index.size(1), 1), dtype=x.dtype)
     edge_attr = edge_attr.float()
     h = F.elu(gat_conv(p, "gat1.", x, edge_index, edge_attr, heads))
     h = F.elu(gat_conv(p, "gat2.", h, edge_index, edge_attr, heads))
-    g = level_readout(h, node_depth)
+    g = (readout or level_readout)(h, node_depth)
     g = torch.relu(F.linear(g, p["mlp.0.weight"], p["mlp.0.bias"]))
     g = torch.relu(F.linear(g, p["mlp.2.weight"], p["mlp.2.bias"]))
     return F.linear(g, p["out.weight"], p["out.bias"]).view(-1)
 
 
 def gradient_penalty(p: Dict[str, torch.Tensor], real_x: torch.Tensor, fake_x: torch.Tensor,
-                     node_depth: torch.Tensor, alpha: torch.Tensor):
+                     node_depth: torch.Tensor, alpha: torch.Tensor, readout=None):
     """train.py:141-152 with a given alpha [1,1]; -> (gp, grad_norm)."""
     x_inter = (alpha * real_x + (1 - alpha) * fake_x).requires_grad_(True)
     ei = torch.zeros((2, 0), dtype=torch.long)
     ea = torch.zeros((0, 1), dtype=torch.float32)
-    out = discriminator_forward(p, x_inter, ei, ea, node_depth)
+    out = discriminator_forward(p, x_inter, ei, ea, node_depth, readout=readout)
     grads = torch.autograd.grad(out.sum(), [x_inter], create_graph=True, retain_graph=True, only_inputs=True)
     gn = torch.norm(grads[0].reshape(-1), p=2)
     return (gn - 1.0) ** 2, gn.detach()

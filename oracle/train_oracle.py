@@ -25,7 +25,10 @@ def _sanitize(b: Data):
 class CpuTrainer:
     def __init__(self, gen_state: Dict[str, torch.Tensor], d_params: Dict[str, torch.Tensor], candidate_k: int,
                  max_nodes: int, max_edges: int, lr: float = 1e-4, gp_lambda: float = 10.0,
-                 lambda_cons: float = 1e-2, n_critic: int = 3):
+                 lambda_cons: float = 1e-2, n_critic: int = 3, segmented_readout: bool = False):
+        # ``segmented_readout``: the level readout without its loop over levels (model.level_readout_segmented),
+        # for graphs of 10^5 nodes, where the loop's backward pass takes minutes
+        self.readout = model.level_readout_segmented if segmented_readout else None
         self.gs = {k: v.detach().clone() for k, v in gen_state.items()}
         self.dp = {k: v.detach().clone().requires_grad_(True) for k, v in d_params.items()}
         self.K, self.max_nodes, self.max_edges = candidate_k, max_nodes, max_edges
@@ -40,7 +43,7 @@ class CpuTrainer:
 
     def _score(self, b: Data) -> torch.Tensor:
         ei, ea = _sanitize(b)
-        return model.discriminator_forward(self.dp, b.x, ei, ea, b.node_depth)
+        return model.discriminator_forward(self.dp, b.x, ei, ea, b.node_depth, readout=self.readout)
 
     def step(self, real_padded: Batch, templates: List[Data], zs_critic: List[torch.Tensor],
              zs_gen: List[torch.Tensor], alphas: List[torch.Tensor], validate: bool = True,
@@ -55,7 +58,8 @@ class CpuTrainer:
             self.opt.zero_grad()
             d_real = self._score(real_padded).mean()
             d_fake = self._score(fake_padded).mean()
-            gp, gn = model.gradient_penalty(self.dp, real_padded.x, fake_padded.x, real_padded.node_depth, alphas[it])
+            gp, gn = model.gradient_penalty(self.dp, real_padded.x, fake_padded.x, real_padded.node_depth, alphas[it],
+                                              readout=self.readout)
             loss_d = (d_fake - d_real) + self.gp_lambda * gp
             loss_d.backward()
             self.opt.step()

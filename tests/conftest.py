@@ -37,14 +37,46 @@ def _start_dp_rehearsal():
     DP_REHEARSAL = (subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT), out_path, log_path)
 
 
+RCCL_BENCH = None      # (process, result path, log path) of bench.py over a one-rank RCCL communicator
+
+
+def _start_rccl_bench():
+    """``bench.py`` with its multi-rank code switched on over a communicator of ONE rank (``AIG_DP_FORCE=1``): the
+    launcher, ``init_process_group("nccl")``, the barriers, the gradient exchange of every critic iteration and the
+    MAX / SUM reductions behind the JSON line, over the real RCCL on the box's single GPU.  Started like the
+    rehearsal, before this process's first HIP call, and after the rehearsal has ended (one process on the GPU at
+    a time); tests/test_parallel_gpu.py checks the line it prints."""
+    import socket
+    import subprocess
+    import tempfile
+    global RCCL_BENCH
+    tmp = tempfile.mkdtemp(prefix="aig_rccl_")
+    out_path, log_path = os.path.join(tmp, "bench.json"), os.path.join(tmp, "bench.log")
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep) and os.access(keep, os.W_OK):
+        log_path = os.path.join(keep, "rccl_one_rank_bench.log")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.update(AIG_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AIG_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--no-side-workloads", "--sample-iters", "1"]
+    RCCL_BENCH = (subprocess.Popen(cmd, env=env, stdout=open(out_path, "w"), stderr=open(log_path, "w"), cwd=ROOT),
+                  out_path, log_path)
+
+
 WATCH = {"test": None, "since": 0.0, "trainer": None, "reported": None}
 
 
 def _start_step_watchdog(limit: float = 60.0):
-    """Every training step of the session records its probe events (``Trainer.probes``); when a test has been
-    running for ``limit`` seconds, which of the last step's events have completed and whether the step's two
-    streams are idle is written to stderr (and to gpurun_out/hang_report.json where that directory exists) - once
-    per test, ahead of the test's own time limit, which only shows the host's stack."""
+    """When a test has been running for ``limit`` seconds, whether the last training step's two streams are idle is
+    written to stderr (and to gpurun_out/hang_report.json where that directory exists) - once per test, ahead of
+    the test's own time limit, which only shows the host's stack.  With ``AIG_TEST_PROBES=1`` every step of the
+    session also records its probe events (``Trainer.probes``) and the report says which of them completed; by
+    default the steps run as they do in production, without the probes' marker packets on the two streams."""
     import json
     import threading
     import time
@@ -55,9 +87,12 @@ def _start_step_watchdog(limit: float = 60.0):
     from gan_amd import train as train_mod
     inner = train_mod.Trainer.step
 
+    with_probes = os.environ.get("AIG_TEST_PROBES") == "1"
+
     def step(self, *a, **k):
         WATCH["trainer"] = weakref.ref(self)
-        self.probes = {}
+        if with_probes:
+            self.probes = {}
         return inner(self, *a, **k)
     train_mod.Trainer.step = step
 
@@ -114,6 +149,12 @@ def pytest_configure(config):
                 DP_REHEARSAL[0].wait(timeout=150)
         except subprocess.TimeoutExpired:
             pass          # tests/test_parallel_gpu.py reports it
+        if DP_REHEARSAL[0].poll() is not None:
+            _start_rccl_bench()
+            try:
+                RCCL_BENCH[0].wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                pass      # tests/test_parallel_gpu.py reports it
     if wants_gpu and torch.cuda.device_count() > 0:
         _start_step_watchdog()
 

@@ -41,7 +41,7 @@ def flat(params):
 WATCH = {"trainer": None, "phase": "start"}
 
 
-def start_watchdog(rank: int, limit: float = 40.0) -> None:
+def start_watchdog(rank: int, limit: float = float(os.environ.get("AIG_REHEARSAL_LIMIT", "40"))) -> None:
     """The rehearsal takes a few seconds.  Past ``limit`` this rank says where it is - phase, which of the last
     step's probe events have completed, whether its two streams are idle, every thread's stack - and ends."""
     import faulthandler
@@ -69,7 +69,8 @@ def start_watchdog(rank: int, limit: float = 40.0) -> None:
 
 def watched_step(tr, batch, phase):
     WATCH["trainer"], WATCH["phase"] = tr, phase
-    tr.probes = {}
+    if os.environ.get("AIG_TEST_PROBES") == "1":      # (off: the step runs as in production, without marker packets)
+        tr.probes = {}
     out = tr.step(batch)
     WATCH["phase"] = phase + " (enqueued)"
     return out
@@ -82,14 +83,20 @@ def main():
     assert world == 2, "the rehearsal is written for two ranks"
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    graphs = [synth_aig(6 + i, 60 + 20 * i, 4, seed=50 + i, window=16, orientation="dataset") for i in range(2)]
+    # AIG_REHEARSAL_NODES: graphs of about that many nodes instead (100000 = what `bench.py --gpus 2` steps over)
+    big = int(os.environ.get("AIG_REHEARSAL_NODES", "0"))
+    if big:
+        graphs = [synth_aig(big // 100, big - big // 50 - 1000 * i, big // 100, seed=50 + i, window=4096, orientation="dataset")
+                  for i in range(2)]
+    else:
+        graphs = [synth_aig(6 + i, 60 + 20 * i, 4, seed=50 + i, window=16, orientation="dataset") for i in range(2)]
     mn = max(g.x.size(0) for g in graphs)
     me = max(g.edge_index.size(1) for g in graphs)
     batches = [Batch.from_data_list([pad_data(g, mn, me)]).to(dev) for g in graphs]
     for i, b in enumerate(batches):
         b.sample_ids = [i]
-    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1000",
-                                      "--n-critic", "2"])
+    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "64" if big else "16", "--save-every", "1000",
+                                      "--n-critic", "3" if big else "2"])
     w = np.load(os.path.join(ROOT, "tests", "golden", "gen_weights.npz"))
     gen_state = {k: torch.from_numpy(w[k]) for k in w.files}
     torch.manual_seed(1234 + rank)                       # different initial critics: the broadcast must align them
@@ -139,11 +146,11 @@ def main():
     grad_err = float((seen["g"] - mean_grad).abs().max() / mean_grad.abs().max())
     watched_step(dp, batches[rank], "second step")
     WATCH["phase"] = "gather after second step"
-    weights = flat(dp.D.parameters()).to(dev)
+    weights = flat(dp.D.parameters())                   # (host tensors: the group is gloo, see gan_amd/parallel.py)
     both = [torch.empty_like(weights) for _ in range(world)]
     dist.all_gather(both, weights)
     weights_equal = bool(torch.equal(both[0], both[1]))
-    moved = float((both[0].cpu() - flat(init.values())).abs().max())
+    moved = float((both[0] - flat(init.values())).abs().max())
 
     # third step: rank 1 fails before it has a gradient
     if rank == 1:
@@ -157,7 +164,7 @@ def main():
     except RuntimeError as e:
         raised = str(e)
     WATCH["phase"] = "gather after third step"
-    weights = flat(dp.D.parameters()).to(dev)
+    weights = flat(dp.D.parameters())
     dist.all_gather(both, weights)
     after_failure_equal = bool(torch.equal(both[0], both[1]))
     moved_after_failure = float((both[0] - before).abs().max())     # the surviving rank's gradient still counts

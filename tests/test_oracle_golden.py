@@ -228,3 +228,38 @@ def test_cpu_trainer_follows_reference_training_run(name):
         for k in ref:
             diff = float((sd[k] - ref[k]).abs().max())
             assert diff <= 1e-6 * float(ref[k].abs().max()) + 0.1 * lr, (e, k, diff)
+
+
+@pytest.mark.parametrize("case", ["ties", "random", "gaps_and_padding", "one_level"])
+def test_segmented_readout_follows_the_level_loop(case):
+    """``oracle.model.level_readout_segmented`` (what the CPU step uses on 100k-node graphs) against the literal
+    loop over levels of models/discriminator.py:78-87: value, gradient and the gradient of a gradient norm (the
+    shape of the gradient penalty's double backward).  Tied maxima - frequent here: nodes with equal features and
+    equal neighbourhoods carry equal rows - must send their gradient to the same single row."""
+    import torch
+    from oracle import model as omodel
+    g = torch.Generator().manual_seed({"ties": 1, "random": 2, "gaps_and_padding": 3, "one_level": 4}[case])
+    n, hdim = 300, 16
+    if case == "ties":
+        h = torch.randint(0, 3, (n, hdim), generator=g).double()
+        nd = torch.randint(0, 7, (n,), generator=g)
+    elif case == "random":
+        h = torch.randn(n, hdim, generator=g, dtype=torch.float64)
+        nd = torch.randint(0, 40, (n,), generator=g)
+    elif case == "gaps_and_padding":
+        h = torch.randn(n, hdim, generator=g, dtype=torch.float64).round(decimals=1)
+        nd = torch.randint(0, 5, (n,), generator=g) * 3 - 1          # levels 2, 5, 8, 11 filled, the rest empty; -1 = padding
+    else:
+        h = torch.randn(n, hdim, generator=g, dtype=torch.float64)
+        nd = torch.zeros(n, dtype=torch.long)
+    w = torch.randn(2 * hdim, generator=g, dtype=torch.float64)
+    outs = []
+    for fn in (omodel.level_readout, omodel.level_readout_segmented):
+        hh = h.clone().requires_grad_(True)
+        out = fn(torch.nn.functional.elu(hh * 1.5), nd)
+        val = (out.reshape(-1) * w).sum()
+        (g1,) = torch.autograd.grad(val, hh, create_graph=True)
+        (g2,) = torch.autograd.grad((g1 ** 2).sum().sqrt(), hh)
+        outs.append((out.detach(), g1.detach(), g2.detach()))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-14)

@@ -203,7 +203,7 @@ def test_generated_side_deeper_than_its_recording_is_scored_eagerly_then_recorde
 
 @pytest.mark.parametrize("name", ["bs1", "bs3"])
 @pytest.mark.parametrize("mode", ["hip_graph", "hip_graph_eager_fakes", "eager", "autograd_gp", "skip_unused",
-                                  "eager_skip_unused"])
+                                  "eager_skip_unused", "separate_update"])
 def test_training_follows_reference_run(name, mode):
     """A whole ``train(args)`` run recorded from the reference's own train.py (tests/golden/make_golden_critic.py;
     its attention layer is the restated one): the same dataset, initial critic, draws and raw generator outputs
@@ -217,7 +217,10 @@ def test_training_follows_reference_run(name, mode):
              # the generator step without its backward pass (it only reaches critic gradients that are zeroed
              # before their next use, train.py:253,298): the run's numbers must not notice
              "skip_unused": ["--skip-unused-backward"],
-             "eager_skip_unused": ["--no-graph-capture", "--skip-unused-backward"]}[mode]
+             "eager_skip_unused": ["--no-graph-capture", "--skip-unused-backward"],
+             # zero_grad, the gradient sums and torch's own Adam as separate launches instead of aig_adam_sum3: the
+             # two forms differ in last bits, both follow the recorded run to the same bound
+             "separate_update": ["--no-fused-update"]}[mode]
     args = build_parser().parse_args(["--dataset-dir", "unused"] + run.argv + extra)
     tr = Trainer(args, mn, me, DEV)
     tr.G.load_state_dict(gen_state())
@@ -320,3 +323,113 @@ def test_one_launch_update_matches_separate_launches():
     for (ea1, es1, _), (ea2, es2, _) in zip(m1, m2):
         assert float((ea1 - ea2).abs().max()) <= 1e-6 + 1e-4 * float(ea2.abs().max())
         assert float((es1 - es2).abs().max()) <= 1e-9 + 1e-4 * float(es2.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The step as bench.py runs it (recorded critic terms over all three sides, one-launch update, two streams, level cap
+# from the data), at the sizes bench.py runs it on.  Only there do the position sweeps (from 16,384 nodes), the
+# hub-chunk backward pass, multi-tile sorts and real overlap between the two streams happen inside a step.
+def _bench_trainer(max_nodes, max_edges, level_cap, seed_d):
+    args = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000",
+                                      "--capture-fake", "auto"])
+    args.level_cap = level_cap
+    tr = Trainer(args, max_nodes, max_edges, DEV)
+    tr.G.load_state_dict(gen_state())
+    tr.D.load_state_dict(omodel.init_discriminator_params(seed_d))
+    return tr, args
+
+
+def _bench_minibatches(groups):
+    mn = max(g.x.size(0) for gs in groups for g in gs)
+    me = max(g.edge_index.size(1) for gs in groups for g in gs)
+    top = max(int(g.node_depth.max()) for gs in groups for g in gs)
+    host, dev, next_id = [], [], 0
+    for gs in groups:
+        padded = [pad_data(g, mn, me) for g in gs]
+        host.append(Batch.from_data_list(padded))
+        b = Batch.from_data_list(padded).to(DEV)
+        b.sample_ids = list(range(next_id, next_id + len(gs)))
+        next_id += len(gs)
+        dev.append(b)
+    return host, dev, mn, me, top
+
+
+def _steps_against_cpu(groups, steps, seed_d):
+    host, dev, mn, me, top = _bench_minibatches(groups)
+    tr, args = _bench_trainer(mn, me, top, seed_d)
+    cpu_tr = CpuTrainer(gen_state(), omodel.init_discriminator_params(seed_d), 64, mn, me, segmented_readout=True)
+    g = torch.Generator().manual_seed(17)
+    for step in range(steps):
+        k = len(groups[step % len(groups)])
+        zs = [torch.randn(128, generator=g) for _ in range(2 * k)]
+        alphas = [torch.rand(1, 1, generator=g) for _ in range(args.n_critic)]
+        zi, ai = iter(zs), iter(alphas)
+        tr.draw_z = lambda: next(zi).to(DEV)
+        tr.draw_alpha = lambda: next(ai).to(DEV)
+        got = {key: float(v) for key, v in tr.step(dev[step % len(dev)]).items()}
+        real = host[step % len(host)]
+        ref = cpu_tr.step(real, [unpad_data(d) for d in real.to_data_list()], zs[:k], zs[k:], alphas,
+                          validate=(step == 0))          # (step 0 is a save step: the validator's verdict scales the penalty)
+        for key in ("D_real", "D_fake", "gap", "gp", "grad_norm", "loss_D", "loss_G", "pen"):
+            assert rel(got[key], ref[key]) <= 1e-4, (step, key, got[key], ref[key])
+        assert tr.edges_last_step == ref["edges"], step
+    # (one recording per minibatch shape; a second one when the repaired fakes turned out deeper than the data's
+    #  deepest level, which sizes the first)
+    assert tr.captures <= 2 and all(t.fk is not None and t.rw is not None for t in tr._captured.values())
+    assert any(t.__dict__.get("_fused_update") is not None for t in tr._captured.values())       # the one-launch update ran
+    opt_steps = steps * args.n_critic
+    for key, v in tr.D.state_dict().items():
+        a, b_ = v.cpu().numpy(), cpu_tr.dp[key].detach().numpy()
+        assert np.abs(a - b_).max() <= 1e-4 * max(np.abs(b_).max(), 1e-3) + 0.1 * args.lr * opt_steps, key
+
+
+@pytest.mark.timeout(900)
+def test_bench_step_on_100k_node_minibatches_matches_cpu_checker():
+    """BASELINE.json configs[2]: two steps over two different 100k-node minibatches (train.py:229-299)."""
+    groups = [[synth_aig(1000, 98000, 1000, seed=s, window=4096, orientation="dataset")] for s in (0, 1)]
+    _steps_against_cpu(groups, steps=2, seed_d=11)
+
+
+@pytest.mark.timeout(900)
+def test_bench_step_on_the_iscas85_sized_minibatch_matches_cpu_checker():
+    """BASELINE.json configs[1]: the eleven ISCAS85-sized graphs as one minibatch padded to 2,401 nodes, two steps."""
+    from gan_amd.synth import iscas85_like
+    _steps_against_cpu([iscas85_like(seed=0), iscas85_like(seed=1)], steps=2, seed_d=12)
+
+
+@pytest.mark.timeout(600)
+def test_bench_step_is_bitwise_reproducible_across_trainers():
+    """Two fresh trainers, same weights and draws, four steps over three rotating 100k-node minibatches: critic,
+    Adam moments and every logged scalar bit-identical.  No kernel of the library adds floats atomically, so a
+    difference between two runs can only come from a missing wait between the step's two streams (a kernel reading
+    what another stream has not finished writing)."""
+    groups = [[synth_aig(1000, 98000, 1000, seed=s, window=4096, orientation="dataset")] for s in (3, 4, 5)]
+    _, dev, mn, me, top = _bench_minibatches(groups)
+    runs = []
+    for _ in range(2):
+        tr, args = _bench_trainer(mn, me, top, seed_d=5)
+        g = torch.Generator().manual_seed(23)
+        rows = []
+        for step in range(4):
+            zs = [torch.randn(128, generator=g) for _ in range(2)]
+            alphas = [torch.rand(1, 1, generator=g) for _ in range(args.n_critic)]
+            zi, ai = iter(zs), iter(alphas)
+            tr.draw_z = lambda: next(zi).to(DEV)
+            tr.draw_alpha = lambda: next(ai).to(DEV)
+            out = tr.step(dev[step % 3])
+            rows.append({k: v.detach().cpu().clone() for k, v in out.items()})
+            rows[-1]["edges"] = torch.tensor(tr.edges_last_step)
+        torch.cuda.synchronize()
+        state = {k: v.detach().cpu().clone() for k, v in tr.D.state_dict().items()}
+        moments = [(tr.opt_D.state[p]["exp_avg"].cpu().clone(), tr.opt_D.state[p]["exp_avg_sq"].cpu().clone())
+                   for p in tr._d_params]
+        runs.append((rows, state, moments))
+        del tr
+    (r1, s1, m1), (r2, s2, m2) = runs
+    for step, (a_, b_) in enumerate(zip(r1, r2)):
+        for k in a_:
+            assert torch.equal(a_[k], b_[k]), (step, k, a_[k], b_[k])
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    for (ea1, es1), (ea2, es2) in zip(m1, m2):
+        assert torch.equal(ea1, ea2) and torch.equal(es1, es2)
