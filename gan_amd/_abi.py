@@ -58,6 +58,10 @@ SIGNATURES = {
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_bwd": (INT, [I64, I64] + [P] * 27 + [P, SZ, P]),
+    "aig_gat_bwd_pooled": (INT, [I64, I64, I64] + [P] * 31 + [P, SZ, P]),
+    "aig_gat1_fwd": (INT, [I64] + [P] * 15 + [P]),
+    "aig_gat1_bwd_ws_bytes": (SZ, [I64]),
+    "aig_gat1_bwd": (INT, [I64] + [P] * 22 + [P, SZ, P]),
     "aig_level_pool_bwd": (INT, [I64, I64, P, P, P, P, P, P, P]),
     "aig_level_pool_bwd_adj_ws_bytes": (SZ, [I64]),
     "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),

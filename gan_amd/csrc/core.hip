@@ -63,7 +63,7 @@ std::mutex g_kt_mutex;
 volatile unsigned g_kt_mask = 0u;   // bit k: kernel k is being timed
 std::vector<TimedLaunch> g_kt[AIG_KT_COUNT];
 const char* const g_kt_names[AIG_KT_COUNT] = {"k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk",
-                                              "k_linear128", "k_wgrad128"};
+                                              "k_linear128", "k_wgrad128", "k_gat1_fwd", "k_gat1_bwd"};
 
 std::vector<hipEvent_t> g_kt_free;   // events of forgotten records, handed out again
 
@@ -122,6 +122,6 @@ extern "C" int aig_kernel_timing_read(int kernel, double* total_ms, int64_t* lau
     return AIG_OK;
 }
 
-extern "C" int aig_abi_version(void) { return 3; }
+extern "C" int aig_abi_version(void) { return 4; }
 
 extern "C" const char* aig_last_error(void) { return aig::err_buf(); }

@@ -11,17 +11,13 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
+#include "gat_common.h"
 #include "radix.h"
 
 namespace aig {
 namespace {
 
-constexpr int H = AIG_HIDDEN;  // heads * channels = 128
-constexpr int HEADS = 4;
-constexpr int THREADS = 256;
-constexpr int HW_PER_BLOCK = THREADS / 32;  // half-waves (one target each) per block
-constexpr float NEG_SLOPE = 0.2f;
-constexpr float SOFTMAX_EPS = 1e-16f;
+constexpr int H = GAT_H, HEADS = GAT_HEADS, THREADS = GAT_THREADS, HW_PER_BLOCK = GAT_HW_PER_BLOCK;
 
 // ------------------------------------------------------------------------------------------ CSR
 __global__ void k_csr_keys(int n, int E, const long long* __restrict__ ei, unsigned* __restrict__ key, int* __restrict__ ids) {
@@ -130,39 +126,6 @@ size_t scan_temp_bytes(int64_t n) {
     return bytes;
 }
 
-// ------------------------------------------------------------------------------------------ block -> node range
-// Blocks b, b+8, b+16, ... share an XCD (and its L2) under round-robin dispatch, so logical block
-// ids are dealt such that one XCD walks one contiguous eighth of the nodes.  Affinity only.
-__device__ __forceinline__ int logical_block(int b, int nb) { return (b & 7) * (nb >> 3) + (b >> 3); }
-
-struct NodeRange {
-    int begin, end;
-};
-__device__ __forceinline__ NodeRange block_nodes_of(int n, int block, int nb /* multiple of 8 */) {
-    int lb = logical_block(block, nb);
-    int chunk = (n + nb - 1) / nb;
-    int b = lb * chunk, e = min(n, b + chunk);
-    return {b, e};
-}
-__device__ __forceinline__ NodeRange block_nodes(int n) { return block_nodes_of(n, blockIdx.x, gridDim.x); }
-
-// value of the lane selected by a DPP control word within the row of 16
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
-constexpr int DPP_HALF_MIRROR = 0x141;           // lane j <-> 7-j within each group of 8
-
-__device__ __forceinline__ float head_sum(float v) {  // sum over the 8 lanes of one head, result in all 8
-    v += dpp<DPP_XOR1>(v);
-    v += dpp<DPP_XOR2>(v);
-    v += dpp<DPP_HALF_MIRROR>(v);  // quads are uniform by now, the mirror lane sits in the other quad
-    return v;
-}
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : NEG_SLOPE * x; }
-
 // a_s[i,h] = <xw[i,h,:], att_src[h,:]>, a_d likewise; block 0 also leaves the edge coefficients
 // ce[h] = <lin_edge.weight[h,:], att_edge[h,:]> (edge_dim = 1: the attention term of an edge is attr * ce[h])
 __global__ __launch_bounds__(THREADS) void k_gat_node_alpha(int n, const float* __restrict__ xw,
@@ -206,45 +169,6 @@ __global__ __launch_bounds__(THREADS) void k_gat_node_alpha(int n, const float* 
 // Scores, softmax and alpha are computed entry-per-lane for the four heads, reduced across lanes
 // (two DPP steps when the list has at most four entries, the usual case for an AIG), alpha is
 // stored 16 bytes per lane and handed to the row accumulation through LDS.
-// exp through the hardware exp2 (v_exp_f32, ~1 ulp of the scaled argument): the accurate library
-// routines cost tens of instructions per call and made this bandwidth kernel ALU-bound.
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-
-__device__ __forceinline__ float4 elu4(float4 o) {
-    o.x = o.x > 0.f ? o.x : fast_exp(o.x) - 1.f; o.y = o.y > 0.f ? o.y : fast_exp(o.y) - 1.f;
-    o.z = o.z > 0.f ? o.z : fast_exp(o.z) - 1.f; o.w = o.w > 0.f ? o.w : fast_exp(o.w) - 1.f;
-    return o;
-}
-__device__ __forceinline__ void axpy4(float4& acc, float w, float4 r) {
-    acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
-}
-
-struct MaxOp {
-    __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
-};
-struct SumOp {
-    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
-};
-// reduction over the lanes of a half-wave, result in every lane; `wide` (uniform per half-wave)
-// says whether lanes beyond the first quad hold data at all
-template <class Op>
-__device__ __forceinline__ float4 halfwave_reduce(float4 v, bool wide, Op op) {
-    v.x = op(v.x, dpp<DPP_XOR1>(v.x)); v.y = op(v.y, dpp<DPP_XOR1>(v.y));
-    v.z = op(v.z, dpp<DPP_XOR1>(v.z)); v.w = op(v.w, dpp<DPP_XOR1>(v.w));
-    v.x = op(v.x, dpp<DPP_XOR2>(v.x)); v.y = op(v.y, dpp<DPP_XOR2>(v.y));
-    v.z = op(v.z, dpp<DPP_XOR2>(v.z)); v.w = op(v.w, dpp<DPP_XOR2>(v.w));
-    if (wide) {
-#pragma unroll
-        for (int off = 4; off < 32; off <<= 1) {
-            v.x = op(v.x, __shfl_xor(v.x, off, 32)); v.y = op(v.y, __shfl_xor(v.y, off, 32));
-            v.z = op(v.z, __shfl_xor(v.z, off, 32)); v.w = op(v.w, __shfl_xor(v.w, off, 32));
-        }
-    } else {  // every lane learns the first quad's result
-        v.x = __shfl(v.x, 0, 32); v.y = __shfl(v.y, 0, 32); v.z = __shfl(v.z, 0, 32); v.w = __shfl(v.w, 0, 32);
-    }
-    return v;
-}
-
 __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
     int n, const float* __restrict__ xw, const float* __restrict__ a_s, const float* __restrict__ a_d,
     const float* __restrict__ ce, const float* __restrict__ bias, const int* __restrict__ row_ptr,
@@ -375,8 +299,20 @@ __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
 // lives in lane k with its four heads, loads of a level issued together with clamped indices; the
 // dot products against the gathered rows are made row-per-half-wave and handed to the entry lanes
 // through LDS.
+// POOLED: the layer feeds the level readout directly (the critic's second layer, discriminator.py:61-91), and its
+// incoming gradient is a function of the readout's 256-float gradient and a table lookup (readout_pull) - formed
+// here, row by row, instead of being written as an [n,128] array by one kernel and read back by this one.
+struct PoolGrad {
+    const float* __restrict__ g_r;        // [256]: gradient w.r.t. the readout's output
+    const int* __restrict__ node_level;   // [n]
+    const float* __restrict__ w;          // [n]
+    const int* __restrict__ argmax;       // [(L+1)][128]
+    const int* __restrict__ meta;         // plan header or NULL
+    int L;
+};
+template <bool POOLED>
 __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
-    int n, const float* __restrict__ g_out, const float* __restrict__ out, const float* __restrict__ xw,
+    int n, const float* __restrict__ g_out, PoolGrad pg, const float* __restrict__ out, const float* __restrict__ xw,
     const float* __restrict__ a_s, const float* __restrict__ a_d, const float* __restrict__ ce,
     const int* __restrict__ row_ptr, const int* __restrict__ csr_src, const float* __restrict__ csr_ea,
     const float* __restrict__ loop_ea, const float* __restrict__ alpha_e, const float* __restrict__ alpha_loop,
@@ -399,10 +335,21 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_dst(
     const float4* al_safe = reinterpret_cast<const float4*>(has_edges ? alpha_e : alpha_loop);
     float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f), dce = gsum;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g_mean = zero4, g_max = zero4;
+    float inv_levels = 0.f;
+    if (POOLED) {
+        g_mean = reinterpret_cast<const float4*>(pg.g_r)[l];
+        g_max = reinterpret_cast<const float4*>(pg.g_r + H)[l];
+        inv_levels = 1.f / (float)(level_count(pg.L, pg.meta));
+    }
     NodeRange r = block_nodes(n);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float4 o = reinterpret_cast<const float4*>(out + (size_t)i * H)[l];
-        float4 g = reinterpret_cast<const float4*>(g_out + (size_t)i * H)[l];
+        float4 g;
+        if (POOLED)
+            g = readout_pull(i, pg.node_level[i], pg.w[i], inv_levels, g_mean, g_max, reinterpret_cast<const int4*>(pg.argmax), l);
+        else
+            g = reinterpret_cast<const float4*>(g_out + (size_t)i * H)[l];
         const int beg = row_ptr[i], deg = row_ptr[i + 1] - beg;
         const float4 ad4 = ad4p[i];
         const float lea = loop_ea[i];
@@ -724,65 +671,6 @@ __global__ __launch_bounds__(THREADS) void k_gat_bwd_hub_finish(
     block_partial_2h(ps, pd, partial, blockIdx.x);
 }
 
-// out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree.
-// One launch serves up to four such sums (the parameter gradients of one backward pass): block x
-// belongs to the first job whose column count it falls into.
-struct ColSum {
-    const float* partial;  // [nb][width], the job's first column at partial[0]
-    float* out;
-    int nb, width, cols;
-    // optional: column c's sum times fac_a[c*fan + t] -> out_a[c*fan + t], likewise b (t < fan <= 256)
-    const float* fac_a;
-    float* out_a;
-    const float* fac_b;
-    float* out_b;
-    int fan;
-};
-struct ColSums {
-    ColSum j[4];
-};
-__global__ __launch_bounds__(256) void k_reduce_cols(ColSums jobs) {
-    __shared__ float red[256];
-    int c = blockIdx.x, which = 0;
-    while (which < 3 && c >= jobs.j[which].cols) c -= jobs.j[which++].cols;
-    const float* __restrict__ partial = jobs.j[which].partial;
-    float* __restrict__ out = jobs.j[which].out;
-    const int nb = jobs.j[which].nb, width = jobs.j[which].width;
-    const int t = threadIdx.x;
-    float s = 0.f;
-    for (int b = t; b < nb; b += 256) s += partial[(size_t)b * width + c];
-    red[t] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) red[t] += red[t + o];
-        __syncthreads();
-    }
-    if (t == 0) out[c] = red[0];
-    const ColSum& job = jobs.j[which];
-    if (job.fac_a && t < job.fan) {
-        const float total = red[0];
-        job.out_a[c * job.fan + t] = total * job.fac_a[c * job.fan + t];
-        job.out_b[c * job.fan + t] = total * job.fac_b[c * job.fan + t];
-    }
-}
-
-// Grid of the node-parallel kernels: a multiple of 8 (XCD grouping), at least 8 nodes per half-wave
-// before more blocks are added, capped at 2048 (measured: finer cuts than co-residency win here).
-// AIG_GAT_GRID_CAP overrides the cap (tuning aid).
-int grid_blocks(int64_t n, int limit = 2048) {
-    static const int env_cap = [] {
-        const char* e = getenv("AIG_GAT_GRID_CAP");
-        int c = e ? atoi(e) : 0;
-        return c >= 8 && c <= 2048 ? c / 8 * 8 : 2048;  // the partial-sum areas hold 2048 blocks
-    }();
-    const int cap = env_cap < limit ? env_cap : limit;
-    int64_t g = (n + 63) / 64;
-    g = (g + 7) / 8 * 8;
-    if (g > cap) g = cap;
-    if (g < 8) g = 8;
-    return (int)g;
-}
-
 }  // namespace
 }  // namespace aig
 
@@ -885,7 +773,8 @@ extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {
            align_up((size_t)2048 * (H + HEADS) * 4) + 256;
 }
 
-extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
+namespace {
+int gat_bwd(int64_t n, int64_t E, const float* g_out, const PoolGrad* pooled, const float* out, const float* xw,
                            const float* att_src, const float* att_dst, const float* ce, const float* a_s,
                            const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
                            const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
@@ -910,9 +799,11 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
         }
         return AIG_OK;
     }
-    AIG_REQUIRE(g_out && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
+    AIG_REQUIRE((g_out || pooled) && out && xw && att_src && att_dst && ce && a_s && a_d && row_ptr && loop_ea && col_ptr &&
                     hub_tab && alpha_loop && d_xw && ws,
                 "aig_gat_bwd: null pointer");
+    AIG_REQUIRE(!pooled || (pooled->g_r && pooled->node_level && pooled->w && pooled->argmax && pooled->L >= 0),
+                "aig_gat_bwd_pooled: null pointer or negative level count");
     if (ws_bytes < aig_gat_bwd_ws_bytes(n, E))
         return fail(AIG_EWORKSPACE, "aig_gat_bwd: workspace %zu < %zu", ws_bytes, aig_gat_bwd_ws_bytes(n, E));
     Carver c(ws);
@@ -927,8 +818,14 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     // the target-side kernel holds 4 waves per SIMD (104 registers): 1024 blocks are resident at once, and a grid
     // of 1568 left the second round half empty
     const int g = grid_blocks(n, BWD_DST_BLOCKS);
-    AIG_LAUNCH_TIMED(AIG_KT_GAT_BWD_DST, k_gat_bwd_dst, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, out, xw, a_s, a_d, ce,
-                     row_ptr, csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop, d_a_d, partial_dst);
+    if (pooled)
+        AIG_LAUNCH_TIMED(AIG_KT_GAT_BWD_DST, k_gat_bwd_dst<true>, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, *pooled, out, xw,
+                         a_s, a_d, ce, row_ptr, csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e, d_raw_loop,
+                         d_a_d, partial_dst);
+    else
+        AIG_LAUNCH_TIMED(AIG_KT_GAT_BWD_DST, k_gat_bwd_dst<false>, dim3(g), dim3(THREADS), 0, s, (int)n, g_out, PoolGrad{}, out,
+                         xw, a_s, a_d, ce, row_ptr, csr_src, csr_ea, loop_ea, alpha_e, alpha_loop, g_pre, d_raw_e,
+                         d_raw_loop, d_a_d, partial_dst);
     AIG_LAUNCH_CHECK();
     // blocks of the by-source kernel: HUB_BLOCKS for the hubs' chunks (they leave at once when the graph
     // has none), then gs over the nodes; the finishing kernel takes a hub per block
@@ -952,4 +849,36 @@ extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float
     hipLaunchKernelGGL(k_reduce_cols, dim3(3 * H + HEADS), dim3(256), 0, s, sums);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+}  // namespace
+
+extern "C" int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, const float* xw,
+                           const float* att_src, const float* att_dst, const float* ce, const float* a_s,
+                           const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                           const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos,
+                           const int32_t* csc_dst, const int32_t* hub_tab, const float* alpha_e,
+                           const float* alpha_loop, const float* lin_edge_w, const float* att_edge, float* d_xw,
+                           float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias, float* d_lin_edge_w,
+                           float* d_att_edge, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n == 0 || g_out, "aig_gat_bwd: null g_out");
+    return gat_bwd(n, E, g_out, nullptr, out, xw, att_src, att_dst, ce, a_s, a_d, row_ptr, csr_src, csr_ea, loop_ea, col_ptr,
+                   csc_pos, csc_dst, hub_tab, alpha_e, alpha_loop, lin_edge_w, att_edge, d_xw, d_att_src, d_att_dst, d_ce,
+                   d_bias, d_lin_edge_w, d_att_edge, ws, ws_bytes, stream);
+}
+
+extern "C" int aig_gat_bwd_pooled(int64_t n, int64_t E, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                                  const int32_t* node_level, const float* w, const int32_t* argmax, const float* out,
+                                  const float* xw, const float* att_src, const float* att_dst, const float* ce,
+                                  const float* a_s, const float* a_d, const int32_t* row_ptr, const int32_t* csr_src,
+                                  const float* csr_ea, const float* loop_ea, const int32_t* col_ptr,
+                                  const int32_t* csc_pos, const int32_t* csc_dst, const int32_t* hub_tab,
+                                  const float* alpha_e, const float* alpha_loop, const float* lin_edge_w,
+                                  const float* att_edge, float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce,
+                                  float* d_bias, float* d_lin_edge_w, float* d_att_edge, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    AIG_REQUIRE(L >= 0 && L < INT_MAX, "aig_gat_bwd_pooled: bad level count");
+    const PoolGrad pg{g_r, node_level, w, argmax, lvl_meta, (int)L};
+    return gat_bwd(n, E, nullptr, &pg, out, xw, att_src, att_dst, ce, a_s, a_d, row_ptr, csr_src, csr_ea, loop_ea, col_ptr,
+                   csc_pos, csc_dst, hub_tab, alpha_e, alpha_loop, lin_edge_w, att_edge, d_xw, d_att_src, d_att_dst, d_ce,
+                   d_bias, d_lin_edge_w, d_att_edge, ws, ws_bytes, stream);
 }

@@ -13,6 +13,7 @@
 #include <climits>
 
 #include "common.h"
+#include "gat_common.h"
 
 namespace aig {
 namespace {
@@ -25,10 +26,6 @@ constexpr int GP_BLOCKS_MAX = 2048;
 __device__ __forceinline__ float d_elu(float h) { return h > 0.f ? 1.f : h + 1.f; }
 __device__ __forceinline__ float dd_elu(float h) { return h > 0.f ? 0.f : h + 1.f; }
 __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : expm1f(z); }
-
-// number of levels L + 1: from the plan's device-side header when the plan was built without a host read
-// (meta[0] = deepest level), else from the caller's L
-__device__ __forceinline__ int level_count(int L, const int* __restrict__ meta) { return (meta ? meta[0] : L) + 1; }
 
 __device__ __forceinline__ float halfwave_sum(float v) {
 #pragma unroll
@@ -43,20 +40,6 @@ __device__ __forceinline__ Rows block_rows(int n) {
     const int chunk = (n + gridDim.x - 1) / gridDim.x;
     const int b = blockIdx.x * chunk;
     return {b, min(n, b + chunk)};
-}
-
-// gradient of the readout w.r.t. one node row, "pull" form: every (level, feature) maximum belongs
-// to exactly one node, so a node asks whether it is that node instead of being scattered to
-__device__ __forceinline__ float4 readout_pull(int i, int lvl, float wi, float inv_levels, float4 g_mean, float4 g_max,
-                                               const int4* __restrict__ argmax4, int l) {
-    int4 am = make_int4(-1, -1, -1, -1);
-    if (lvl >= 0) am = argmax4[lvl * (H / 4) + l];
-    float4 r;
-    r.x = wi * g_mean.x + (am.x == i ? g_max.x * inv_levels : 0.f);
-    r.y = wi * g_mean.y + (am.y == i ? g_max.y * inv_levels : 0.f);
-    r.z = wi * g_mean.z + (am.z == i ? g_max.z * inv_levels : 0.f);
-    r.w = wi * g_mean.w + (am.w == i ? g_max.w * inv_levels : 0.f);
-    return r;
 }
 
 // d_h[i,c] = w[i] g[c] + [argmax[level(i),c] == i] g[128+c] / (L+1)

@@ -41,6 +41,10 @@ from . import _abi
 from .data import Data
 
 HIDDEN = 128
+# Switches for the tests that compare the fused forms with the separate kernels they replace (both stay in the
+# library): the first layer without projected rows (aig_gat1_*), the readout's backward inside the second layer's.
+FUSED_FIRST_LAYER = True
+FUSED_READOUT_BACKWARD = True
 
 
 class GraphCSR:
@@ -196,6 +200,120 @@ class _GATAggregate(torch.autograd.Function):
                                    _abi.ptr(d_lw), _abi.ptr(d_ae),
                                    _abi.ptr(ws), ws.numel(), _abi.stream(), meta=(n, csr.E)), "aig_gat_bwd")
         return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None
+
+
+class _GAT1Fused(torch.autograd.Function):
+    """The whole first attention layer (projection, attention, aggregation, bias, ELU) on the two node features
+    without any [n,128] intermediate: ``aig_gat1_fwd`` / ``aig_gat1_bwd``.  Differentiable once, w.r.t. the layer's
+    parameters; the node features get no gradient (callers whose features need one take the generic path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR):
+        lib = _abi.lib()
+        n, dev = csr.n, x.device
+        x = x.detach().contiguous()
+        w, att_src, att_dst, lin_edge_w, att_edge, bias = (t.detach().contiguous() for t in (w, att_src, att_dst, lin_edge_w,
+                                                                                           att_edge, bias))
+        f32 = dict(dtype=torch.float32, device=dev)
+        coef = torch.empty(20, **f32)
+        out = torch.empty((n, HIDDEN), **f32)
+        alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
+        alpha_loop = torch.empty((max(n, 1), 4), **f32)
+        _abi.check(_abi.timed("aig_gat1_fwd", lib.aig_gat1_fwd, n, _abi.ptr(x), _abi.ptr(w), _abi.ptr(att_src),
+                              _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(bias),
+                              _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea),
+                              _abi.ptr(coef), _abi.ptr(out), _abi.ptr(alpha_e), _abi.ptr(alpha_loop), _abi.stream(),
+                              meta=(n, csr.E)), "aig_gat1_fwd")
+        ctx.csr = csr
+        ctx.save_for_backward(x, w, att_src, att_dst, lin_edge_w, att_edge, coef, out, alpha_e, alpha_loop)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        lib = _abi.lib()
+        csr: GraphCSR = ctx.csr
+        x, w, att_src, att_dst, lin_edge_w, att_edge, coef, out, alpha_e, alpha_loop = ctx.saved_tensors
+        n, dev = csr.n, x.device
+        g_out = g_out.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_w = torch.empty((HIDDEN, 2), **f32)
+        d_as, d_ad, d_bias = torch.empty((1, 4, HIDDEN // 4), **f32), torch.empty((1, 4, HIDDEN // 4), **f32), torch.empty(HIDDEN, **f32)
+        d_ce = torch.empty(4, **f32)
+        d_lw, d_ae = torch.empty((HIDDEN, 1), **f32), torch.empty((1, 4, HIDDEN // 4), **f32)
+        ws = _abi.workspace(lib.aig_gat1_bwd_ws_bytes(n), dev)
+        _abi.check(_abi.timed("aig_gat1_bwd", lib.aig_gat1_bwd, n, _abi.ptr(x), _abi.ptr(w), _abi.ptr(att_src), _abi.ptr(att_dst),
+                              _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(coef), _abi.ptr(g_out), _abi.ptr(out),
+                              _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea),
+                              _abi.ptr(alpha_e), _abi.ptr(alpha_loop), _abi.ptr(d_w), _abi.ptr(d_as), _abi.ptr(d_ad),
+                              _abi.ptr(d_ce), _abi.ptr(d_bias), _abi.ptr(d_lw), _abi.ptr(d_ae), _abi.ptr(ws), ws.numel(),
+                              _abi.stream(), meta=(n, csr.E)), "aig_gat1_bwd")
+        return None, d_w, d_as, d_ad, d_lw, d_ae, d_bias, None
+
+
+class _GATAggregatePool(torch.autograd.Function):
+    """An attention layer's aggregation (as ``_GATAggregate``) followed by the level readout (as ``_LevelPool``),
+    i.e. the critic's second layer and what consumes it (discriminator.py:61-91), as ONE autograd node: the backward
+    pass forms every row of the aggregation's incoming gradient from the readout's 256-float gradient inside the
+    attention kernel (``aig_gat_bwd_pooled``) instead of writing it as an [n,128] array and reading it back.
+    Same numbers as the two nodes in a row, bit for bit.  Differentiable once."""
+
+    @staticmethod
+    def forward(ctx, xw, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR, plan):
+        lib = _abi.lib()
+        n, dev = csr.n, xw.device
+        xw = xw.contiguous()
+        att_src, att_dst, lin_edge_w, att_edge, bias = (t.detach().contiguous().view(-1)
+                                                        for t in (att_src, att_dst, lin_edge_w, att_edge, bias))
+        f32 = dict(dtype=torch.float32, device=dev)
+        ce = torch.empty(4, **f32)
+        a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
+        out = torch.empty((n, HIDDEN), **f32)
+        alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
+        alpha_loop = torch.empty((max(n, 1), 4), **f32)
+        st = _abi.stream()
+        _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
+                              _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
+                              _abi.ptr(ce), st), "aig_gat_node_alpha")
+        _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
+                              _abi.ptr(ce), _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
+                              _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
+                              _abi.ptr(alpha_loop), st, meta=(n, csr.E)), "aig_gat_fwd")
+        r = torch.empty((1, 2 * HIDDEN), **f32)
+        argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
+        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), dev)
+        _abi.check(_abi.timed("aig_level_pool_fwd", lib.aig_level_pool_fwd, plan.n, plan.nvalid, plan.L, _abi.ptr(plan.meta),
+                              _abi.ptr(out), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr), _abi.ptr(plan.node_level),
+                              _abi.ptr(plan.w), _abi.ptr(r), _abi.ptr(argmax), _abi.ptr(ws), ws.numel(), st),
+                   "aig_level_pool_fwd")
+        ctx.csr, ctx.plan = csr, plan
+        ctx.save_for_backward(xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop, lin_edge_w, att_edge, argmax)
+        return r
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_r):
+        lib = _abi.lib()
+        csr, plan = ctx.csr, ctx.plan
+        xw, att_src, att_dst, ce, a_s, a_d, out, alpha_e, alpha_loop, lin_edge_w, att_edge, argmax = ctx.saved_tensors
+        n, dev = csr.n, xw.device
+        g_r = g_r.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_xw = torch.empty((n, HIDDEN), **f32)
+        d_as, d_ad, d_bias = torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32), torch.empty(HIDDEN, **f32)
+        d_ce = torch.empty(4, **f32)
+        d_lw, d_ae = torch.empty((HIDDEN, 1), **f32), torch.empty((1, 4, HIDDEN // 4), **f32)
+        ws = _abi.workspace(lib.aig_gat_bwd_ws_bytes(n, csr.E), dev)
+        _abi.check(_abi.timed("aig_gat_bwd", lib.aig_gat_bwd_pooled, n, csr.E, plan.L, _abi.ptr(plan.meta), _abi.ptr(g_r),
+                              _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(argmax), _abi.ptr(out), _abi.ptr(xw),
+                              _abi.ptr(att_src), _abi.ptr(att_dst), _abi.ptr(ce), _abi.ptr(a_s), _abi.ptr(a_d),
+                              _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src), _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea),
+                              _abi.ptr(csr.col_ptr), _abi.ptr(csr.csc_pos), _abi.ptr(csr.csc_dst), _abi.ptr(csr.hub_tab),
+                              _abi.ptr(alpha_e), _abi.ptr(alpha_loop), _abi.ptr(lin_edge_w), _abi.ptr(att_edge),
+                              _abi.ptr(d_xw), _abi.ptr(d_as), _abi.ptr(d_ad), _abi.ptr(d_ce), _abi.ptr(d_bias),
+                              _abi.ptr(d_lw), _abi.ptr(d_ae), _abi.ptr(ws), ws.numel(), _abi.stream(), meta=(n, csr.E)),
+                   "aig_gat_bwd_pooled")
+        return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None, None
 
 
 class _WGrad(torch.autograd.Function):
@@ -376,7 +494,14 @@ class GATLayer(nn.Module):
             state_dict.pop(dst, None)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x: torch.Tensor, csr: Optional[GraphCSR]) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, csr: Optional[GraphCSR], plan=None) -> torch.Tensor:
+        """``plan``: a level plan - the layer's output then goes straight into the level readout and the
+        readout's [1,256] row is returned (the critic's second layer; edge-carrying graphs only)."""
+        if (plan is None and csr is not None and csr.E > 0 and _is_in2(x, self.lin.weight) and not x.requires_grad
+                and FUSED_FIRST_LAYER):
+            # two input features: the whole layer without its projected rows (see _GAT1Fused)
+            return _GAT1Fused.apply(x, self.lin.weight, self.att_src, self.att_dst, self.lin_edge.weight, self.att_edge,
+                                    self.bias, csr)
         if x.size(1) in (1, 2, 4, HIDDEN) and self.lin.weight.size(0) == HIDDEN:
             xw = _Project.apply(x, self.lin.weight)
         else:
@@ -386,6 +511,9 @@ class GATLayer(nn.Module):
             return F.elu(xw + self.bias)
         # edge_dim = 1: an edge's attention term is attr * ce[h], ce[h] = <lin_edge.weight[h,:], att_edge[h,:]>,
         # formed (and differentiated) inside the kernels
+        if plan is not None:
+            return _GATAggregatePool.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), self.lin_edge.weight,
+                                           self.att_edge, self.bias, csr, plan)
         return _GATAggregate.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), self.lin_edge.weight,
                                    self.att_edge, self.bias, csr)
 
@@ -568,15 +696,19 @@ class AIGDiscriminator(nn.Module):
             csr = self.graph_csr(edge_index, edge_attr, n) if has_edges else None
         elif csr.n != n:
             raise _abi.AigAbiError(f"data._csr was built for {csr.n} nodes, the graph has {n}")
-        h = self.gat1(x, csr)
-        h = self.gat2(h, csr)
         nd = data.node_depth if (hasattr(data, "node_depth") and data.node_depth is not None) else None
         plan = data.__dict__.get("_plan") if hasattr(data, "__dict__") else None
         if plan is None:
             plan = self.level_plan(nd, n, x.device)
         elif plan.n != n:
             raise _abi.AigAbiError(f"data._plan was built for {plan.n} nodes, the graph has {n}")
-        graph_repr = _LevelPool.apply(h, plan)           # [1, 2H]
+        h = self.gat1(x, csr)
+        if csr is not None and csr.E > 0 and not twice_differentiable and FUSED_READOUT_BACKWARD:
+            # second layer and readout as one autograd node (their backward passes share a kernel)
+            graph_repr = self.gat2(h, csr, plan)
+        else:
+            h = self.gat2(h, csr)
+            graph_repr = _LevelPool.apply(h, plan)           # [1, 2H]
         if not twice_differentiable and self._head_is_fused(graph_repr):
             return _CriticHead.apply(graph_repr, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
                                      self.mlp[2].bias, self.out.weight, self.out.bias)

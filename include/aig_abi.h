@@ -185,6 +185,44 @@ int aig_gat_bwd(int64_t n, int64_t E, const float* g_out, const float* out, cons
                 float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce, float* d_bias,
                 float* d_lin_edge_w, float* d_att_edge, void* ws, size_t ws_bytes, void* stream);
 
+/* The same backward pass for a layer whose output feeds the level readout directly (the critic's second layer,
+ * discriminator.py:61-91): instead of g_out [n,128] it takes what the readout's backward pass would build it from -
+ * g_r [256] = dLoss/d(readout), the plan's node_level / w, the forward readout's argmax table, L and the plan
+ * header (aig_level_pool_bwd's arguments) - and forms each row of g_out on the fly.  Bit-identical to
+ * aig_level_pool_bwd followed by aig_gat_bwd, without writing and re-reading the [n,128] array between them. */
+int aig_gat_bwd_pooled(int64_t n, int64_t E, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                       const int32_t* node_level, const float* w, const int32_t* argmax, const float* out,
+                       const float* xw, const float* att_src, const float* att_dst, const float* ce, const float* a_s,
+                       const float* a_d, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                       const float* loop_ea, const int32_t* col_ptr, const int32_t* csc_pos, const int32_t* csc_dst,
+                       const int32_t* hub_tab, const float* alpha_e, const float* alpha_loop, const float* lin_edge_w,
+                       const float* att_edge, float* d_xw, float* d_att_src, float* d_att_dst, float* d_ce,
+                       float* d_bias, float* d_lin_edge_w, float* d_att_edge, void* ws, size_t ws_bytes, void* stream);
+
+/* The critic's FIRST attention layer as one kernel forward and one backward - GATConv(2, 32, heads=4, edge_dim=1)
+ * followed by F.elu (models/discriminator.py:30,60) on x [n,2] (node type, inverter count), W = gat1.lin.weight
+ * [128,2].  Same result as aig_linear_in2 + aig_gat_node_alpha + aig_gat_fwd up to rounding (the projected row of a
+ * source is two multiply-adds away from its 8 bytes of features, so sums over a node's list are taken in feature
+ * space and projected once), without any [n,128] intermediate: no projected rows, no a_s / a_d arrays.
+ *   coef [20] (output of the forward call, input of the backward call): the layer's attention coefficients
+ *       cs[f][h] = <W[h,:,f], att_src[h,:]> (8), cd likewise from att_dst (8), ce[h] (4)
+ * aig_gat1_bwd: given g_out [n,128] = dLoss/d out, the gradients of every parameter of the layer - d_W [128,2],
+ * d_att_src / d_att_dst / d_bias [128], d_ce [4] and (both or neither) d_lin_edge_w / d_att_edge [128] - from ONE
+ * pass over the by-target lists (no by-source lists needed).  The node features get no gradient: the reference
+ * differentiates them only on the edge-free interpolate of the gradient penalty (train.py:141-152), which does not
+ * come through here. */
+int aig_gat1_fwd(int64_t n, const float* x, const float* W, const float* att_src, const float* att_dst,
+                 const float* lin_edge_w, const float* att_edge, const float* bias, const int32_t* row_ptr,
+                 const int32_t* csr_src, const float* csr_ea, const float* loop_ea, float* coef, float* out,
+                 float* alpha_e, float* alpha_loop, void* stream);
+size_t aig_gat1_bwd_ws_bytes(int64_t n);
+int aig_gat1_bwd(int64_t n, const float* x, const float* W, const float* att_src, const float* att_dst,
+                 const float* lin_edge_w, const float* att_edge, const float* coef, const float* g_out, const float* out,
+                 const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea, const float* loop_ea,
+                 const float* alpha_e, const float* alpha_loop, float* d_W, float* d_att_src, float* d_att_dst,
+                 float* d_ce, float* d_bias, float* d_lin_edge_w, float* d_att_edge, void* ws, size_t ws_bytes,
+                 void* stream);
+
 /* Dense projection of the critic's second attention layer, y = act(x W^T + bias) with x [n,128],
  * y [n,128] on the f32 matrix cores - torch.nn.functional.linear inside GATConv.lin (discriminator.py:61) and
  * its input gradient g W.  w_in_major = 0: w is [out,in] as PyTorch stores a Linear weight; 1: w is [in,out]
@@ -415,6 +453,8 @@ enum {
     AIG_KT_POOL_WALK,         /* aig_level_pool_fwd: the walk over the nodes */
     AIG_KT_LINEAR128,         /* aig_linear128 */
     AIG_KT_WGRAD128,          /* aig_wgrad with 128 input columns */
+    AIG_KT_GAT1_FWD,          /* aig_gat1_fwd */
+    AIG_KT_GAT1_BWD,          /* aig_gat1_bwd: its one pass over the nodes */
     AIG_KT_COUNT
 };
 int aig_kernel_timing(unsigned kernel_mask);

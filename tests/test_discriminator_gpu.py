@@ -503,3 +503,57 @@ def test_hub_with_more_chunks_than_gathering_blocks():
     for k, v in D.named_parameters():
         # sums over 283k edges with heavy cancellation, in fp32 on both sides: a looser bound than elsewhere
         close(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=5e-3, what="grad " + k)
+
+
+def _score_and_grads(D, dd):
+    D.zero_grad(set_to_none=True)
+    out = D(dd)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    return out.detach().clone(), {k: v.grad.detach().clone() for k, v in D.named_parameters()}
+
+
+@pytest.mark.parametrize("name", list(graphs().keys()) + ["100k_real", "100k_two_hubs"])
+def test_fused_layers_against_the_separate_kernels(name):
+    """The first layer without projected rows (aig_gat1_fwd / aig_gat1_bwd) and the readout's backward formed inside
+    the second layer's (aig_gat_bwd_pooled) against the separate kernels they replace, which stay in the library:
+    the pooled backward is the same arithmetic (bit-identical), the first layer sums in feature space and projects
+    once (equal within rounding; bound 2e-5 of each tensor's largest element, 1e-4 for the edge projection's
+    gradient, a sum of terms of both signs over every edge)."""
+    from gan_amd import discriminator as dmod
+    if name == "100k_real":
+        d = synth_aig(1000, 98000, 1000, seed=0, window=4096, orientation="dataset")
+    elif name == "100k_two_hubs":        # what an untrained generator wires: most gates hang on two sources
+        n = 100000
+        rng = np.random.default_rng(8)
+        dst = np.repeat(np.arange(1000, n), 2)
+        src = np.where(rng.random(dst.size) < 0.85, rng.integers(0, 2, dst.size), rng.integers(0, 1000, dst.size))
+        x = np.stack([rng.choice([0, 1, 2], n), rng.integers(0, 3, n)], 1).astype(np.float32)
+        d = Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.stack([src, dst])),
+                 edge_attr=torch.from_numpy(rng.integers(0, 2, src.size).astype(np.float32)).view(-1, 1),
+                 node_depth=torch.from_numpy(rng.integers(0, 300, n)))
+    else:
+        d = graphs()[name]
+    D, _ = make_critic(seed=5)
+    dd = Data(x=d.x.to(DEV), edge_index=d.edge_index.to(DEV), edge_attr=d.edge_attr.to(DEV),
+              node_depth=d.node_depth.to(DEV).long())
+    results = {}
+    try:
+        for first, pooled in ((False, False), (False, True), (True, True)):
+            dmod.FUSED_FIRST_LAYER, dmod.FUSED_READOUT_BACKWARD = first, pooled
+            results[(first, pooled)] = _score_and_grads(D, dd)
+    finally:
+        dmod.FUSED_FIRST_LAYER = dmod.FUSED_READOUT_BACKWARD = True
+    s0, g0 = results[(False, False)]
+    s1, g1 = results[(False, True)]
+    s2, g2 = results[(True, True)]
+    assert torch.equal(s0, s1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    close(s2.cpu().numpy(), s0.cpu().numpy(), rtol=2e-5, what="score")
+    for k in g0:
+        close(g2[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=1e-4 if k.endswith("lin_edge.weight") or k.endswith("att_edge") else 2e-5,
+              what="grad " + k)
+    # ... and twice in a row the fused forms give the same bits (no atomics on floats anywhere)
+    s3, g3 = _score_and_grads(D, dd)
+    assert torch.equal(s2, s3) and all(torch.equal(g2[k], g3[k]) for k in g2)
