@@ -112,6 +112,7 @@ SIGNATURES = {
     "aig_clean_depth_batch": (INT, [I64, I64, I64, P, P, P, P, P, SZ, P]),
     "aig_penalties_batch_ws_bytes": (SZ, [I64, I64, I64]),
     "aig_penalties_batch": (INT, [I64, I64, I64, P, P, P, P, P, SZ, P]),
+    "aig_penalties_batch_hinted": (INT, [I64, I64, I64, P, P, P, P, I64, P, P, SZ, P]),
     "aig_resync_batch_ws_bytes": (SZ, [I64, I64, I64]),
     "aig_resync_batch": (INT, [I64, I64, I64, P, P, P, P, P, P, SZ, P]),
     "aig_resync_typed_batch_ws_bytes": (SZ, [I64, I64, I64]),

@@ -328,9 +328,17 @@ def penalties_set(gs: GraphSet) -> torch.Tensor:
     dev = gs.x.device
     out = torch.empty((gs.B, 9), dtype=torch.float32, device=dev)
     ws = _abi.workspace(lib.aig_penalties_batch_ws_bytes(gs.B, gs.n, gs.ecap), dev)
-    _abi.check(_abi.timed("aig_penalties_batch", lib.aig_penalties_batch, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
-                          _abi.ptr(gs.x), _abi.ptr(gs.edge_index), _abi.ptr(out), _abi.ptr(ws), ws.numel(), _abi.stream()),
-               "aig_penalties_batch")
+    hint = getattr(gs, "order_hint", None)
+    stride = 0
+    if hint is not None:
+        if hint.dtype != torch.int32 or not hint.is_cuda or hint.numel() not in (gs.n, gs.B * gs.n):
+            hint = None          # (only a shortcut: anything else than what the kernel takes is left out)
+        else:
+            hint = hint.contiguous()
+            stride = gs.n if hint.numel() == gs.B * gs.n and gs.B > 1 else 0
+    _abi.check(_abi.timed("aig_penalties_batch", lib.aig_penalties_batch_hinted, gs.B, gs.n, gs.ecap, _abi.ptr(gs.count),
+                          _abi.ptr(gs.x), _abi.ptr(gs.edge_index), _abi.ptr(hint), stride, _abi.ptr(out), _abi.ptr(ws),
+                          ws.numel(), _abi.stream()), "aig_penalties_batch_hinted")
     return out
 
 

@@ -486,15 +486,17 @@ int run_traverse(hipStream_t s, int N, const TravJobs& jobs, int njobs, int4* re
 }
 
 // adjacency in sorted order: adj[p] = other endpoint (union id) of edge slot sid[p]; which = 1: the target
+// (`relabel`, may be null: the lists then hold relabel[id] instead of the id - nodes renamed by their place in an order)
 __global__ void k_gather_adj(GraphSet gs, const int* __restrict__ sid, const long long* __restrict__ ei, int which,
-                             int* __restrict__ adj) {
+                             int* __restrict__ adj, const int* __restrict__ relabel) {
     const int m = gs.M();
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < m; p += gridDim.x * blockDim.x) {
         int g;
         long long u = -1, v = -1;
         const bool have = load_edge(gs, ei, sid[p], g, u, v);
         const long long w = which ? v : u;
-        adj[p] = have && w >= 0 && w < gs.n ? g * gs.n + (int)w : 0;   // entries past the valid keys are never read
+        const int id = have && w >= 0 && w < gs.n ? g * gs.n + (int)w : 0;   // entries past the valid keys are never read
+        adj[p] = relabel ? relabel[id] : id;
     }
 }
 
@@ -577,15 +579,22 @@ struct SweepTile {
 // MODE 0: breadth-first level from the seeds (min over the predecessors that have a level).  MODE 1: longest-path
 // level (0 without predecessors, else 1 + max over the predecessors; `seed` unused) - levels only ever INCREASE in
 // the relaxation there.  `gate` (may be null): a graph is swept only when gate[graph] == 0.
+struct SweepJob {
+    const int* tptr;
+    const int* tsrc;
+    const int* seed;
+    int* dpos;
+};
 template <int MODE>
-__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, const int* __restrict__ tptr,
-                                                        const int* __restrict__ tsrc, const int* __restrict__ seed,
-                                                        int* __restrict__ dpos, const int* __restrict__ gate) {
-    if (gate && gate[blockIdx.x] != 0) return;
+__device__ __forceinline__ void sweep_body(const GraphSet& gs, const SweepJob& jb, const int graph) {
+    const int* __restrict__ tptr = jb.tptr;
+    const int* __restrict__ tsrc = jb.tsrc;
+    const int* __restrict__ seed = jb.seed;
+    int* __restrict__ dpos = jb.dpos;
     __shared__ int ring[SWEEP_RING + 1];   // the last slot: a neutral level for "no predecessor"
     __shared__ int flag[3];
     volatile int* ring_v = ring;     // (the rounds between two barriers must re-read LDS)
-    const int n = gs.n, base = blockIdx.x * gs.n, tid = threadIdx.x;
+    const int n = gs.n, base = graph * gs.n, tid = threadIdx.x;
     const int ntiles = (n + SWEEP_T - 1) / SWEEP_T;
     constexpr int MASK = SWEEP_RING - 1;
     // Every load below is unconditional on a clamped index (a load under a condition compiles to a branch with a
@@ -737,6 +746,114 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, const int*
         cur = nxt;
         nxt = nn;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, SweepJob job, const int* __restrict__ gate) {
+    if (gate && gate[blockIdx.x] != 0) return;
+    sweep_body<MODE>(gs, job, blockIdx.x);
+}
+
+// Which positions reach a seed along the edges?  The mirror image of the reachability sweep above, for the
+// direction in which a PULL would read the lists by source - and the graphs an untrained generator wires hang tens
+// of thousands of targets on two sources.  So this one PUSHES along the lists by target (a handful of entries per
+// position): the positions are taken a tile at a time from the LAST to the first; every edge runs upward, so when a
+// tile's turn comes, every position above it has already pushed its mark down.  Inside a tile a marked position
+// marks its predecessors - in the tile's LDS flags when they lie in the tile, in memory below it - exactly once;
+// rounds repeat until no new position of the tile got marked.  reach[position] = 0 (reaches a seed; the seeds are
+// preset) or SWEEP_NONE.  One workgroup per graph.
+constexpr int REACH_ROUNDS = 4;
+__device__ __forceinline__ void reach_back_body(const GraphSet& gs, const int* __restrict__ tptr,
+                                                const int* __restrict__ tsrc, int* __restrict__ reach, const int graph) {
+    __shared__ int cur[SWEEP_T];
+    volatile int* cur_v = cur;
+    const int n = gs.n, base = graph * gs.n, tid = threadIdx.x;
+    const int ntiles = (n + SWEEP_T - 1) / SWEEP_T;
+    const int last_e = max(gs.M() - 1, 0);
+    struct Node {
+        int lo, hi, q[SWEEP_INL];
+    };
+    Node nx[SWEEP_PT];
+    auto fetch = [&](int t, Node* nd) {     // list bounds and first predecessors of tile t (unconditional, clamped loads)
+        const int a = t * SWEEP_T;
+        int lo[SWEEP_PT], hi[SWEEP_PT];
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) {
+            const int p = a + j * SWEEP_THREADS + tid;
+            const bool live = t >= 0 && p < n;
+            const int pc = base + (live ? p : 0);
+            lo[j] = tptr[pc];
+            hi[j] = tptr[pc + 1];
+            if (!live) lo[j] = hi[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) {
+            nd[j].lo = lo[j];
+            nd[j].hi = hi[j];
+#pragma unroll
+            for (int k = 0; k < SWEEP_INL; ++k) nd[j].q[k] = tsrc[min(lo[j] + k, last_e)] - base;
+        }
+    };
+    fetch(ntiles - 1, nx);
+    for (int t = ntiles - 1; t >= 0; --t) {
+        const int a = t * SWEEP_T;
+        Node nd[SWEEP_PT];
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) nd[j] = nx[j];
+        // marks pushed into this tile from above (L1-bypassing loads: the stores came from other waves of this block)
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) {
+            const int p = a + j * SWEEP_THREADS + tid;
+            cur[j * SWEEP_THREADS + tid] =
+                p < n ? __hip_atomic_load(&reach[base + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SWEEP_NONE;
+        }
+        fetch(t - 1, nx);        // the next tile's lists are requested before this tile's rounds
+        bool done[SWEEP_PT];
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) done[j] = false;
+        __syncthreads();
+        while (true) {
+            bool any = false;
+#pragma unroll 1
+            for (int round = 0; round < REACH_ROUNDS; ++round) {
+#pragma unroll
+                for (int j = SWEEP_PT - 1; j >= 0; --j) {
+                    if (done[j] || cur_v[j * SWEEP_THREADS + tid] != 0) continue;
+                    done[j] = true;
+                    auto mark = [&](int q) {
+                        if (q >= a) {
+                            if (cur_v[q - a] != 0) { cur_v[q - a] = 0; any = true; }
+                        } else {
+                            __hip_atomic_store(&reach[base + q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    };
+#pragma unroll
+                    for (int k = 0; k < SWEEP_INL; ++k)
+                        if (nd[j].lo + k < nd[j].hi) mark(nd[j].q[k]);
+                    for (int e = nd[j].lo + SWEEP_INL; e < nd[j].hi; ++e) mark(tsrc[e] - base);
+                }
+            }
+            if (!__syncthreads_or(any)) break;
+        }
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) {
+            const int p = a + j * SWEEP_THREADS + tid;
+            if (p < n && cur[j * SWEEP_THREADS + tid] == 0)
+                __hip_atomic_store(&reach[base + p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();      // the marks pushed below this tile are in memory before any wave loads the next tile
+        __syncthreads();      // (and the tile's flags are overwritten next)
+    }
+}
+
+// Both reachability passes of a graph in one launch: blockIdx.y = 0 sweeps forward from the seeds of `fwd` (levels,
+// of which only "has one" is used), blockIdx.y = 1 marks what reaches a seed of `back_reach` (preset there).
+__global__ __launch_bounds__(SWEEP_THREADS) void k_reach_pair(GraphSet gs, SweepJob fwd, const int* __restrict__ tptr,
+                                                             const int* __restrict__ tsrc, int* __restrict__ back_reach,
+                                                             const int* __restrict__ gate) {
+    if (gate && gate[blockIdx.x] != 0) return;
+    if (blockIdx.y == 0) sweep_body<0>(gs, fwd, blockIdx.x);
+    else reach_back_body(gs, tptr, tsrc, back_reach, blockIdx.x);
 }
 
 // The resync's edges in position space (every edge with both ends in range counts there, AIGgan.py:29-62):
@@ -927,7 +1044,8 @@ __device__ __forceinline__ void wave_count(int* __restrict__ counters, int g, in
 __global__ void k_pen_edges(GraphSet gs, const long long* __restrict__ ei, const int* __restrict__ types,
                             const int* __restrict__ pos, int* __restrict__ counters, int* __restrict__ indeg,
                             unsigned long long* __restrict__ pair_key, unsigned* __restrict__ key_src,
-                            unsigned* __restrict__ key_dst, int* __restrict__ ids, unsigned char* __restrict__ eflag) {
+                            unsigned* __restrict__ key_dst, int* __restrict__ ids, unsigned char* __restrict__ eflag,
+                            const int* __restrict__ ord, int* __restrict__ unordered) {
     const int M = gs.M(), N = gs.N();
     // whole waves stay in the loop (a lane past the end carries an absent edge): the counts are summed per wave
     for (int base = blockIdx.x * blockDim.x; base < M; base += gridDim.x * blockDim.x) {
@@ -954,8 +1072,12 @@ __global__ void k_pen_edges(GraphSet gs, const long long* __restrict__ ei, const
         if (eflag) eflag[e] = (unsigned char)((self ? 1 : 0) | (to_pi ? 4 : 0) | (from_po ? 8 : 0) | (bad_src ? 16 : 0));
         if (ok) atomicAdd(&indeg[v], 1);
         pair_key[e] = ok ? (unsigned long long)u * (unsigned long long)N + (unsigned long long)v : ~0ull;
-        key_src[e] = ok ? (unsigned)u : (unsigned)N;
-        key_dst[e] = ok ? (unsigned)v : (unsigned)N;
+        // the lists behind the reachability passes: by node id, or - with `ord` - by the nodes' places in an order
+        // in which every edge of a well-formed graph runs upward (unordered[g] says where that does not hold)
+        const int ou = ord ? ord[u] : u, ov = ord ? ord[v] : v;
+        if (ord && ok && u != v && !(ou < ov)) unordered[g] = 1;      // (same value from every thread that stores it)
+        key_src[e] = ok ? (unsigned)ou : (unsigned)N;
+        key_dst[e] = ok ? (unsigned)ov : (unsigned)N;
     }
 }
 
@@ -974,9 +1096,13 @@ __global__ void k_pen_dups(GraphSet gs, const unsigned long long* __restrict__ s
 }
 
 // counters[6] += |indeg - target|; counters[7] += node not (reached forward from a PI and backward from a PO)
+// (with `ord`: fwd / rev and the sweeps' fwd_sweep / rev_sweep are indexed by ord[node]; a graph's verdicts come
+//  from the sweeps unless unordered[graph] is raised)
 __global__ void k_pen_nodes(GraphSet gs, const int* __restrict__ types, const int* __restrict__ indeg,
                             const int* __restrict__ fwd, const int* __restrict__ rev, int* __restrict__ counters,
-                            unsigned char* __restrict__ on_path) {
+                            unsigned char* __restrict__ on_path, const int* __restrict__ ord,
+                            const int* __restrict__ unordered, const int* __restrict__ fwd_sweep,
+                            const int* __restrict__ rev_sweep) {
     const int N = gs.N();
     for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {   // whole waves: see k_pen_edges
         const int i = base + threadIdx.x;
@@ -985,11 +1111,55 @@ __global__ void k_pen_nodes(GraphSet gs, const int* __restrict__ types, const in
         const int t = types[j];
         const int target = t == PO_T ? 1 : (t == AND_T ? 2 : 0);
         const int d = indeg[j] - target;
-        const bool ok = fwd[j] >= 0 && rev[j] >= 0;
         const int g = j / gs.n;
+        const int o = ord ? ord[j] : j;
+        const bool walked = !ord || unordered[g] != 0;
+        const bool ok = walked ? (fwd[o] >= 0 && rev[o] >= 0) : (fwd_sweep[o] < SWEEP_NONE && rev_sweep[o] < SWEEP_NONE);
         wave_count(counters, g, 6, live ? (d < 0 ? -d : d) : 0);
         wave_count(counters, g, 7, live && !ok);
         if (live && on_path) on_path[i] = ok;
+    }
+}
+
+// An order for the reachability sweeps.  hint (may be null): a caller's claim "place of every node in an order in
+// which sources precede targets" (ids inside the graph, stride 0: one vector shared by the graphs); it is used
+// for a graph only when it is a permutation of 0..n-1 there (inv: scratch; a value claimed twice leaves one claimant
+// disagreeing with inv), else - and without a hint - the PI / AND / PO position is the order.  ord = union id.
+__global__ void k_ord_scatter(GraphSet gs, const int* __restrict__ hint, long long stride, int* __restrict__ inv) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int g = i / gs.n, li = i - g * gs.n;
+        const int h = hint[(size_t)g * stride + li];
+        if (h >= 0 && h < gs.n) inv[g * gs.n + h] = i;
+    }
+}
+__global__ void k_ord_check(GraphSet gs, const int* __restrict__ hint, long long stride, const int* __restrict__ inv,
+                            int* __restrict__ bad) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int g = i / gs.n, li = i - g * gs.n;
+        const int h = hint[(size_t)g * stride + li];
+        if (!(h >= 0 && h < gs.n) || inv[g * gs.n + h] != i) bad[g] = 1;
+    }
+}
+__global__ void k_ord_pick(GraphSet gs, const int* __restrict__ hint, long long stride, const int* __restrict__ pos,
+                           const int* __restrict__ bad, int* __restrict__ ord) {
+    const int N = gs.N();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int g = i / gs.n, li = i - g * gs.n;
+        const bool use = hint && bad[g] == 0;
+        ord[i] = g * gs.n + (use ? hint[(size_t)g * stride + li] : pos[i]);
+    }
+}
+// seeds of the two reachability passes at the nodes' places: for the walks (0 / -1) and the sweeps (0 / none)
+__global__ void k_reach_seeds(int n, const int* __restrict__ types, const int* __restrict__ ord, int* __restrict__ fwd,
+                              int* __restrict__ rev, int* __restrict__ fwd_seed, int* __restrict__ rev_seed) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int o = ord[i], t = types[i];
+        fwd[o] = t == PI_T ? 0 : -1;
+        rev[o] = t == PO_T ? 0 : -1;
+        fwd_seed[o] = t == PI_T ? 0 : SWEEP_NONE;
+        rev_seed[o] = t == PO_T ? 0 : SWEEP_NONE;
     }
 }
 
@@ -1091,11 +1261,12 @@ int run_types_pos(hipStream_t s, const GraphSet& gs, const float* x, int* types,
 
 // CSR over the edge slots whose key (an endpoint's union id) is < N: ptr[N+1], adj = the other endpoint
 int run_csr(hipStream_t s, const GraphSet& gs, int bits, unsigned* key, unsigned* skey, int* ids, int* sid,
-            const long long* ei, int other_is_target, int* ptr, int* adj, void* temp, size_t tb) {
+            const long long* ei, int other_is_target, int* ptr, int* adj, void* temp, size_t tb,
+            const int* relabel = nullptr) {
     const int N = gs.N(), M = gs.M();
     AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, skey, ids, sid, (size_t)M, bits, s));
     hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey, 1u, ptr);
-    hipLaunchKernelGGL(k_gather_adj, dim3(g256(M)), dim3(256), 0, s, gs, sid, ei, other_is_target, adj);
+    hipLaunchKernelGGL(k_gather_adj, dim3(g256(M)), dim3(256), 0, s, gs, sid, ei, other_is_target, adj, relabel);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -1111,7 +1282,8 @@ int run_sweep_levels(hipStream_t s, const GraphSet& gs, const long long* ei, con
     AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key, skey, val, sval, (size_t)M, bits, s));
     hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, skey, 1u, tptr);
     hipLaunchKernelGGL(k_sweep_seed, dim3(g256(N)), dim3(256), 0, s, gs, types, pos, seed);
-    hipLaunchKernelGGL(k_sweep<0>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, sval, seed, dpos, (const int*)nullptr);
+    hipLaunchKernelGGL(k_sweep<0>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, SweepJob{tptr, sval, seed, dpos},
+                       (const int*)nullptr);
     hipLaunchKernelGGL(k_sweep_out, dim3(g256(N)), dim3(256), 0, s, gs, pos, dpos, depth32);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -1261,15 +1433,17 @@ int clean_depth(const GraphSet& gs, const float* x, const int64_t* edge_index, i
 size_t graph_checks_ws(int64_t B, int64_t n, int64_t ecap) {
     const size_t N = (size_t)(B * n > 0 ? B * n : 1), M = (size_t)(B * ecap > 0 ? B * ecap : 1);
     const Temps t = temps_for((int64_t)N, (int64_t)M);
-    return 2 * align_up((N + 1) * sizeof(Cnt4)) + 12 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
+    return 2 * align_up((N + 1) * sizeof(Cnt4)) + 18 * align_up((N + 2) * 4) + 2 * align_up(M * 8) +
            8 * align_up(M * 4) + 2 * align_up((N + 2) * 16) + align_up((size_t)(B + 1) * PEN_CTRS * 4) +
-           align_up(t.bytes) + 2048;
+           2 * align_up((size_t)(B + 16) * 4) + align_up(t.bytes) + 2048;
 }
 
 // shared body: counters (penalties, any B) and/or flags (validator, one graph)
+// order_hint / hint_stride (penalties only, may be null): see k_ord_scatter.
 int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, float* pen_out, unsigned char* eflag,
                  unsigned char* ncode, int* indeg_out, int* pred2, unsigned char* on_path, int* summary, void* ws,
-                 size_t ws_bytes, void* stream, const char* who) {
+                 size_t ws_bytes, void* stream, const char* who, const int32_t* order_hint = nullptr,
+                 int64_t hint_stride = 0) {
     AIG_REQUIRE(x && edge_index && ws, "%s: null pointer", who);
     AIG_REQUIRE(gs.B == 1 || !ncode, "%s: the validator takes one graph at a time", who);
     if (ws_bytes < graph_checks_ws(gs.B, gs.n, gs.ecap)) return fail(AIG_EWORKSPACE, "%s: workspace too small", who);
@@ -1300,6 +1474,13 @@ int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, 
     int* sadj = c.take<int>(M);
     int* dadj = c.take<int>(M);
     int* q1 = qx;                                                 // second queue (N entries)
+    int* ord = c.take<int>(N + 2);
+    int* inv = c.take<int>(N + 2);
+    int* fwd_seed = c.take<int>(N + 2);
+    int* fwd_sweep = c.take<int>(N + 2);
+    int* rev_sweep = c.take<int>(N + 2);
+    int* bad = c.take<int>(gs.B + 16);
+    int* unordered = c.take<int>(gs.B + 16);
     int* counters = c.take<int>((size_t)(gs.B + 1) * PEN_CTRS);   // PEN_CTRS per graph, then [0] Kahn popped
     int* popped = counters + (size_t)gs.B * PEN_CTRS;
     int4* rec0 = c.take<int4>(N + 2);
@@ -1313,23 +1494,52 @@ int graph_checks(const GraphSet& gs, const float* x, const int64_t* edge_index, 
     if (rc) return rc;
     AIG_HIP_CHECK(fill_words(counters, 0u, (size_t)(gs.B + 1) * PEN_CTRS * sizeof(int), s));
     AIG_HIP_CHECK(fill_words(indeg, 0u, (size_t)(N + 2) * sizeof(int), s));
+    // The penalties' reachability from the PIs and back from the POs (constraints.py:310-339) is one pass over the
+    // nodes in an order in which every edge runs upward, and one in reverse - when such an order is at hand: the
+    // caller's hint (the generator wires every target to nodes before it in its processing order) or the
+    // PI / AND / PO position (what a repaired graph obeys).  Whether a graph obeys the order is found on the device;
+    // the graphs that do not are walked level by level as before.  Lists, seeds and verdicts then live at the
+    // nodes' places in that order.  The validator keeps node ids (its other outputs are indexed by them).
+    const bool use_ord = ncode == nullptr;
+    if (use_ord) {
+        AIG_HIP_CHECK(fill_words(bad, 0u, (size_t)(gs.B + 16) * sizeof(int), s));
+        AIG_HIP_CHECK(fill_words(unordered, 0u, (size_t)(gs.B + 16) * sizeof(int), s));
+        if (order_hint) {
+            hipLaunchKernelGGL(k_ord_scatter, dim3(g256(N)), dim3(256), 0, s, gs, order_hint, (long long)hint_stride, inv);
+            hipLaunchKernelGGL(k_ord_check, dim3(g256(N)), dim3(256), 0, s, gs, order_hint, (long long)hint_stride, inv, bad);
+        }
+        hipLaunchKernelGGL(k_ord_pick, dim3(g256(N)), dim3(256), 0, s, gs, order_hint, (long long)hint_stride, pos, bad, ord);
+        AIG_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_pen_edges, dim3(g256(M)), dim3(256), 0, s, gs, ei, types, pos, counters, indeg, key64, key_src,
-                       key_dst, ids, eflag);
+                       key_dst, ids, eflag, use_ord ? (const int*)ord : nullptr, unordered);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rs::sort_pairs(temp, tb, key64, skey64, ids, sid, (size_t)M, t.kb, s));
     hipLaunchKernelGGL(k_pen_dups, dim3(g256(M)), dim3(256), 0, s, gs, skey64, sid, counters, eflag);
     AIG_LAUNCH_CHECK();
     // forward reachability from the PIs, backward from the POs
-    if ((rc = run_csr(s, gs, t.nb, key_src, skey32, ids, sid, ei, 1, sptr, sadj, temp, tb))) return rc;
-    if ((rc = run_csr(s, gs, t.nb, key_dst, skey32, ids, sid, ei, 0, dptr, dadj, temp, tb))) return rc;
+    const int* relabel = use_ord ? ord : nullptr;
+    if ((rc = run_csr(s, gs, t.nb, key_src, skey32, ids, sid, ei, 1, sptr, sadj, temp, tb, relabel))) return rc;
+    if ((rc = run_csr(s, gs, t.nb, key_dst, skey32, ids, sid, ei, 0, dptr, dadj, temp, tb, relabel))) return rc;
     int* q0 = reinterpret_cast<int*>(flags);
-    hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, fwd);
-    hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PO_T, rev);
     TravJobs jobs{};  // the two reachability walks are independent: one launch, one block each
     jobs.j[0] = TravJob{sptr, sadj, nullptr, fwd, q0, q1, nullptr};
     jobs.j[1] = TravJob{dptr, dadj, nullptr, rev, q2, q3, nullptr};
+    if (use_ord) {
+        hipLaunchKernelGGL(k_reach_seeds, dim3(g256(N)), dim3(256), 0, s, N, types, ord, fwd, rev, fwd_seed, rev_sweep);
+        // both passes run along the lists by target (a node's predecessors): forward pulls, places ascending;
+        // backward pushes, places descending (rev_sweep is preset with the seeds).  One launch.
+        hipLaunchKernelGGL(k_reach_pair, dim3(gs.B, 2), dim3(SWEEP_THREADS), 0, s, gs, SweepJob{dptr, dadj, fwd_seed, fwd_sweep},
+                           (const int*)dptr, (const int*)dadj, rev_sweep, (const int*)unordered);
+        AIG_LAUNCH_CHECK();
+        jobs.gate = unordered;      // the walks take the graphs the sweeps left alone
+    } else {
+        hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PI_T, fwd);
+        hipLaunchKernelGGL(k_seed_depth, dim3(g256(N)), dim3(256), 0, s, N, types, PO_T, rev);
+    }
     if ((rc = run_traverse<0>(s, N, jobs, 2, rec0, rec1, gs.B))) return rc;
-    hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, gs, types, indeg, fwd, rev, counters, on_path);
+    hipLaunchKernelGGL(k_pen_nodes, dim3(g256(N)), dim3(256), 0, s, gs, types, indeg, fwd, rev, counters, on_path, relabel,
+                       (const int*)unordered, (const int*)fwd_sweep, (const int*)rev_sweep);
     AIG_LAUNCH_CHECK();
     if (pen_out) hipLaunchKernelGGL(k_pen_finish, dim3((gs.B + 63) / 64), dim3(64), 0, s, gs, counters, pen_out);
     if (ncode) {
@@ -1421,7 +1631,7 @@ int resync(const GraphSet& gs, const float* x, const int64_t* edge_index, const 
         AIG_HIP_CHECK(rs::sort_pairs(temp2, tb2, tkey, tskey, tval, tsval, (size_t)M, bits_for((unsigned long long)N), s));
         hipLaunchKernelGGL(k_segment_ptr<unsigned>, dim3(g256(N + 1)), dim3(256), 0, s, N, M, tskey, 1u, tptr);
         int* dpos = reinterpret_cast<int*>(flags);   // free again: (N+1)*16 bytes
-        hipLaunchKernelGGL(k_sweep<1>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, tptr, tsval, (const int*)nullptr, dpos,
+        hipLaunchKernelGGL(k_sweep<1>, dim3(gs.B), dim3(SWEEP_THREADS), 0, s, gs, SweepJob{tptr, tsval, nullptr, dpos},
                            (const int*)unordered);
         hipLaunchKernelGGL(k_rs_sweep_out, dim3(g256(N)), dim3(256), 0, s, gs, pos, dpos, unordered, d32);
         AIG_LAUNCH_CHECK();
@@ -1528,6 +1738,18 @@ extern "C" int aig_penalties_batch(int64_t B, int64_t n, int64_t ecap, const int
     const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
     return graph_checks(gs, x, edge_index, out9, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
                         stream, "aig_penalties_batch");
+}
+
+extern "C" int aig_penalties_batch_hinted(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                                          const int64_t* edge_index, const int32_t* order_hint, int64_t hint_stride,
+                                          float* out9, void* ws, size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(out9, "aig_penalties_batch_hinted: null output");
+    AIG_REQUIRE(hint_stride == 0 || hint_stride == n, "aig_penalties_batch_hinted: the hint's stride is 0 (shared) or n");
+    int rc = check_set("aig_penalties_batch_hinted", B, n, ecap);
+    if (rc) return rc;
+    const GraphSet gs{(int)B, (int)n, (int)ecap, ecount};
+    return graph_checks(gs, x, edge_index, out9, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                        stream, "aig_penalties_batch_hinted", order_hint, hint_stride);
 }
 
 extern "C" size_t aig_validate_ws_bytes(int64_t n, int64_t E) { return graph_checks_ws(1, n, E); }

@@ -278,7 +278,9 @@ class AIGGenerator(nn.Module):
         a.edge_index, a.edge_attr, a.ecount, a.x_out = _abi.ptr(edge_index), _abi.ptr(edge_attr), _abi.ptr(ecount), _abi.ptr(x_out)
         _abi.check(_abi.timed("aig_gen_wire_batch", lib.aig_gen_wire_batch, C.byref(a), stream, meta=(n, B, K)),
                    "aig_gen_wire_batch")
-        return GraphSet(B, n, ecap, x_out, edge_index, edge_attr, ecount, nd_all, counts_host=Es, x_dtype=first.x.dtype)
+        out = GraphSet(B, n, ecap, x_out, edge_index, edge_attr, ecount, nd_all, counts_host=Es, x_dtype=first.x.dtype)
+        out.order_hint = arrays["rank"]      # every emitted edge runs from an earlier to a later node of this order
+        return out
 
     def _wire(self, plan, x_in, x_src, nd, pa, pb, pa2, pb2, n, K, E, dev, debug=None) -> Data:
         """Scores, tie-exact selection and edge assembly from the four projection planes (generator.py:139-209)."""

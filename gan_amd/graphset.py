@@ -12,6 +12,7 @@ Layout (what the ``*_batch`` entry points of the library take):
 * ``edge_attr``    int64 ``[B, ecap]``
 * ``count``        int32 ``[B]`` on the device (``None``: every slot holds an edge)
 * ``node_depth``   ``[B*n]``, or ``[n]`` when all graphs share one template's depths, or ``None``
+* ``order_hint``   int32 ``[B*n]`` / ``[n]`` / ``None``: see ``GraphSet.__init__``
 """
 from __future__ import annotations
 
@@ -23,7 +24,8 @@ from .data import Data
 
 
 class GraphSet:
-    __slots__ = ("B", "n", "ecap", "x", "edge_index", "edge_attr", "count", "node_depth", "_counts_host", "x_dtype")
+    __slots__ = ("B", "n", "ecap", "x", "edge_index", "edge_attr", "count", "node_depth", "_counts_host", "x_dtype",
+                 "order_hint")
 
     def __init__(self, B: int, n: int, ecap: int, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
                  count: Optional[torch.Tensor], node_depth: Optional[torch.Tensor] = None,
@@ -32,6 +34,10 @@ class GraphSet:
         self.x, self.edge_index, self.edge_attr, self.count, self.node_depth = x, edge_index, edge_attr, count, node_depth
         self._counts_host = None if counts_host is None else [int(c) for c in counts_host]
         self.x_dtype = x_dtype      # dtype the per-graph views hand out for x (the template's)
+        # int32 [B*n] or [n] (shared), or None: place of every node in an order in which the set's edges run from
+        # earlier to later nodes - the generator leaves its processing rank here; the penalties use it as a
+        # (device-checked) shortcut for their reachability term
+        self.order_hint = None
 
     # ------------------------------------------------------------------ host side of the counts
     def counts(self) -> List[int]:

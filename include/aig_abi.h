@@ -522,6 +522,21 @@ size_t aig_penalties_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
 int aig_penalties_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
                         const int64_t* edge_index, float* out9, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with a hint that makes the reachability term cheap (same results, whatever the hint holds).
+ * reach_violation (constraints.py:310-339: nodes not both reached forward from a PI and backward from a PO) is a
+ * walk level by level in general; when an order of the nodes is known in which every edge runs from an earlier to
+ * a later node, it is one pass over the nodes in that order and one in reverse.
+ *   order_hint int32 [B][n] (hint_stride = n) or [n] shared by all graphs (hint_stride = 0), may be NULL: the place
+ *       of every node in such an order - e.g. the generator's processing rank (aig_gen_order), in which every
+ *       emitted edge runs upward (generator.py:131-189).
+ * The hint is checked on the device, per graph: it must be a permutation of 0..n-1, else the graph's PI / AND / PO
+ * position is tried instead (what a repaired graph obeys; also the order tried by aig_penalties /
+ * aig_penalties_batch); a graph with an edge (self loops aside) that does not run upward in the order tried is
+ * walked level by level as before.  Workspace: aig_penalties_batch_ws_bytes. */
+int aig_penalties_batch_hinted(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const float* x,
+                               const int64_t* edge_index, const int32_t* order_hint, int64_t hint_stride, float* out9,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* aig_resync on B graphs (a graph with a cycle gets zeros, the others their levels). */
 size_t aig_resync_batch_ws_bytes(int64_t B, int64_t n, int64_t ecap);
 int aig_resync_batch(int64_t B, int64_t n, int64_t ecap, const int32_t* ecount, const int64_t* edge_index,

@@ -224,3 +224,57 @@ def test_bulk_block_at_the_bulk_sampling_configuration():
         assert (depth[~has_in] == 0).all() and (depth[has_in] == np.maximum.reduceat(depth[src][np.argsort(dst, kind="stable")] + 1, np.flatnonzero(np.diff(np.concatenate([[-1], np.sort(dst)])) > 0))).all()
         inv = np.bincount(dst, weights=d.edge_attr.cpu().numpy().reshape(-1), minlength=types.size)
         assert np.array_equal(d.x[:, 1].cpu().numpy(), inv.astype(np.float32))
+
+
+@pytest.mark.parametrize("n_and,k", [(300, 16), (30000, 64)])
+def test_penalties_with_an_order_hint(n_and, k):
+    """The reachability term of the penalties as two sweeps along an order hint (the generator's processing rank,
+    which its sets carry): same nine numbers as the CPU checker, and the same whatever the hint holds - no hint, the
+    reverse order (a permutation every edge violates), vectors that are no permutation, one template's rank shared by
+    all graphs - because the hint is checked on the device and a graph it does not fit is walked level by level."""
+    from gan_amd.generator import AIGGenerator
+    from util_golden import gen_state
+    G = AIGGenerator(candidate_k=k).to(DEV)
+    G.load_state_dict(gen_state())
+    templates = []
+    for i, orientation in enumerate(("dataset", "forward", "dataset")):
+        t = synth_aig(40, n_and, 30, seed=60 + i, window=max(8, n_and // 6), orientation=orientation)
+        templates.append(Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV)))
+    zs = torch.randn(3, 128, generator=torch.Generator().manual_seed(4)).to(DEV)
+    raw = G.forward_set(templates, zs)
+    n = raw.n
+    rank = raw.order_hint
+    assert rank is not None and rank.dtype == torch.int32 and rank.numel() == 3 * n
+    want = []
+    for g in range(3):
+        d = raw.graph(g)
+        ref = ocpu.aig_constraint_penalties(Data(x=d.x.cpu(), edge_index=d.edge_index.cpu(), edge_attr=d.edge_attr.cpu()))
+        want.append([float(ref[key]) for key in PEN_KEYS])
+    want = np.asarray(want, dtype=np.float32)
+    assert want[:, 7].min() > 0          # some nodes are off every PI -> PO path: the term under test is not trivially zero
+    got = penalties_set(raw).cpu().numpy()
+    assert np.array_equal(got, want), (got, want)
+    flat = rank.reshape(3, n)
+    perm = torch.stack([torch.randperm(n, generator=torch.Generator().manual_seed(s)) for s in range(3)]).to(DEV).int()
+    variants = {
+        "none": None,
+        "reversed": (n - 1 - flat).contiguous(),
+        "all_zero": torch.zeros_like(flat),
+        "out_of_range": (flat + n).contiguous(),
+        "one_value_twice": torch.cat([flat[:, :1], flat[:, :-1]], 1).contiguous(),
+        "random_permutation": perm,
+        "first_graphs_rank_for_all": flat[0].contiguous(),
+        "wrong_dtype": flat.long(),
+    }
+    for name, hint in variants.items():
+        raw.order_hint = hint
+        assert np.array_equal(penalties_set(raw).cpu().numpy(), got), name
+    # graphs full of cycles, with hints of every kind
+    junk = GraphSet.from_data_list([to_dev(junk_graph(n, 3 * n, 200 + i, "long")) for i in range(3)])
+    base = penalties_set(junk).cpu().numpy()
+    for g in range(3):
+        ref = ocpu.aig_constraint_penalties(junk.graph(g).cpu())
+        assert [float(ref[key]) for key in PEN_KEYS] == [float(v) for v in base[g, :9]]
+    for name, hint in variants.items():
+        junk.order_hint = hint
+        assert np.array_equal(penalties_set(junk).cpu().numpy(), base), name
