@@ -13,10 +13,11 @@ all-reduced over RCCL after each critic backward.  Rank 0 prints ONE JSON line:
   sample_nodes_per_sec   template nodes/s of G.forward + enforce + resync (candidate-k 64), whole job, in
                    blocks of draws that go through the kernels as one set of graphs (bulk sampling);
                    ..._streams keeps single samples in flight on several streams, ..._one_at_a_time is the plain loop
-  roofline         the memory-bound kernel with the largest share of the step (the target-side pass of the GAT
-                   backward, k_gat_bwd_dst): algorithmic bytes of its eager launches inside the timed region / their
-                   duration from events the library records around the kernel itself on its launch stream;
-                   roofline_kernels lists all four memory-bound critic kernels, per graph kind (real / fake)
+  roofline         the kernel with the largest share of the step's kernel time among those with a known algorithmic cost
+                   (chosen from this run's own census of a few fully eager steps): algorithmic bytes or flops of its eager
+                   launches inside a timed region / their duration from events the library records around the kernel
+                   itself on its launch stream; roofline_kernels lists every such kernel, per graph kind (real / fake);
+                   roofline_step sets the algorithmic bytes and flops of the whole step against ms_per_step
   cpu_baseline     the CPU checker's training step on a bounded sample, timed on this host (rank 0, N=1)
 
 Inputs are resident in HBM before the timed region starts.
@@ -99,7 +100,7 @@ def rocprof_shares():
     """Share of GPU time per kernel (percent) from the committed rocprofv3 summary of this bench command."""
     import csv
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_bench_synth100k_kernel_stats.csv")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_bench_synth100k_kernel_stats.csv")
     out = {}
     try:
         with open(path) as f:
@@ -111,41 +112,101 @@ def rocprof_shares():
     return out
 
 
-# kernels the library can time itself (aig_kernel_timing): index = its kernel id
-TIMED_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_linear128", "k_wgrad128"]
-HBM_KERNELS = TIMED_KERNELS[:4]
-# the memory-bound kernel with the largest share of the step's GPU time (profiles/r02_bench_synth100k_kernel_stats.csv):
-# the one whose launches carry events inside the timed region
-ROOFLINE_KERNEL = "k_gat_bwd_dst"
+# Kernels whose launches the library can bracket with events of their own (aig_kernel_timing; index = kernel id) and
+# what one launch on a graph of n nodes / e edges / `levels` depth levels costs by the algorithm: bytes for the
+# memory-bound ones (every gathered row counts once per list entry, whether a cache serves it or not), flops for the
+# two dense products (which sit at the ridge: their bytes are given too).
+HBM_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_gat1_fwd", "k_gat1_bwd"]
+MFMA_KERNELS = ["k_linear128", "k_wgrad128"]
+
+
+def timed_kernel_names(lib):
+    names, k = [], 0
+    while lib.aig_kernel_timing_name(k):
+        names.append(lib.aig_kernel_timing_name(k).decode())
+        k += 1
+    return names
 
 
 def kernel_bytes(kernel: str, n: int, e: int, levels: int) -> int:
-    """Algorithmic bytes of one launch on a graph of n nodes, e edges (E' = e + n list entries with the self
-    loops), `levels` depth levels; every gathered row counts, whether a cache serves it or not.
-      k_gat_bwd_dst  rows g_out, out read and g_pre written (3 x 512 B per node), one gathered source row per list
-                     entry (512 B), a_s per entry and a_d per node (16 B), row pointers, source id + attribute per
-                     edge (8 B), self-loop attribute (4 B), alpha read and d_raw written per entry (16 B each),
-                     d_a_d written per node (16 B)
-      k_gat_bwd_src  one gathered g_pre row per list entry, the node's own xw row read and d_xw row written, alpha
-                     and d_raw read per entry (16 B each), d_a_d per node, column pointers, position + target per edge
-      k_pool_walk    512 B row + 12 B of plan per node, 1 KB of level table per level"""
+    """Algorithmic bytes of one launch (E' = e + n list entries with the self loops).
+      k_gat_aggregate  see gat_fwd_bytes
+      k_gat_bwd_dst    (second layer, fed by the readout: its incoming gradient is formed from 256 floats and a table)
+                       row out read and g_pre written (2 x 512 B per node), level + weight per node (8 B), one gathered
+                       source row per list entry (512 B), a_s per entry and a_d per node (16 B), row pointers, source id
+                       + attribute per edge (8 B), self-loop attribute (4 B), alpha read and d_raw written per entry
+                       (16 B each), d_a_d written per node (16 B), the argmax table (512 B per level)
+      k_gat_bwd_src    one gathered g_pre row per list entry, the node's own xw row read and d_xw row written, alpha
+                       and d_raw read per entry (16 B each), d_a_d per node, column pointers, position + target per edge
+      k_pool_walk      512 B row + 12 B of plan per node, 1 KB of level table per level
+      k_gat1_fwd       (first layer, no projected rows) per node: list bounds, own features, self-loop attribute (16 B),
+                       the row written (512 B), alpha of the self loop (16 B), its own features as the loop's source
+                       (8 B); per edge: source id, attribute, the source's features, alpha written (32 B)
+      k_gat1_bwd       per node: rows g_out and out read (1024 B), bounds / features / loop attribute / loop alpha
+                       (40 B); per edge: source id, attribute, source features, alpha (32 B)
+      k_linear128, k_wgrad128   two [n,128] f32 arrays (1024 B per node)"""
     ep = e + n
     if kernel == "k_gat_aggregate":
         return gat_fwd_bytes(n, e)
     if kernel == "k_gat_bwd_dst":
-        return 1536 * n + 512 * ep + 16 * ep + 16 * n + 4 * (n + 1) + 8 * e + 4 * n + 32 * ep + 16 * n
+        return 1024 * n + 8 * n + 512 * ep + 16 * ep + 16 * n + 4 * (n + 1) + 8 * e + 4 * n + 32 * ep + 16 * n + 512 * levels
     if kernel == "k_gat_bwd_src":
         return 512 * ep + 1024 * n + 32 * ep + 16 * n + 4 * (n + 1) + 8 * e
     if kernel == "k_pool_walk":
         return 524 * n + 1024 * levels
+    if kernel == "k_gat1_fwd":
+        return 552 * n + 32 * e
+    if kernel == "k_gat1_bwd":
+        return 1064 * n + 32 * e
+    if kernel in MFMA_KERNELS:
+        return 1024 * n
     raise KeyError(kernel)
+
+
+def kernel_flops(kernel: str, n: int) -> float:
+    """[n,128] x [128,128] (k_linear128) and its transpose-side reduction over the nodes (k_wgrad128)."""
+    if kernel in MFMA_KERNELS:
+        return 2.0 * 128 * 128 * n
+    raise KeyError(kernel)
+
+
+def step_cost_model(n: int, e_real: int, e_fake: int, levels: int, K: int, n_critic: int = 3):
+    """Algorithmic HBM bytes and flops of ONE training step on a minibatch of n nodes, itemised: what the step's kernels
+    read and write by the algorithm (arrays streamed once per kernel that takes them; gathered rows once per list
+    entry), summed over the step's passes.  [n,128] f32 arrays are counted in units of A = 512 n bytes.
+      edge pass (critic forward + backward over a graph with edges; 2 n_critic + 1 per step: real and fake sides of
+      every critic iteration, raw graphs of the generator step): first layer forward, second layer's projection,
+      attention terms (A + 32 n), aggregate, readout walk, target-side and source-side backward, projection's input
+      gradient and weight gradient (k_linear128, k_wgrad128), first layer backward
+      penalty term (closed-form gradient penalty, n_critic per step): 32 A (20 array reads, 12 writes over its eleven
+      row passes, four products and four node-dimension reductions)
+      generator pass (2 per step): node pipeline 8 n + 5 A, scoring (K + 127 staged rows of 512 B per 64 targets and
+      4 K bytes of logits per target), selection (4 K per target), emission (~1.5 KB per target)"""
+    A = 512 * n
+
+    def edge_pass(e):
+        b = (kernel_bytes("k_gat1_fwd", n, e, levels) + 2 * A + (A + 32 * n) + kernel_bytes("k_gat_aggregate", n, e, levels) +
+             kernel_bytes("k_pool_walk", n, e, levels) + kernel_bytes("k_gat_bwd_dst", n, e, levels) +
+             kernel_bytes("k_gat_bwd_src", n, e, levels) + 2 * A + 2 * A + kernel_bytes("k_gat1_bwd", n, e, levels))
+        return b, 3 * 2.0 * 128 * 128 * n
+    real_b, real_f = edge_pass(e_real)
+    fake_b, fake_f = edge_pass(e_fake)
+    gp_b, gp_f = 32 * A, 9 * 2.0 * 128 * 128 * n           # 4 products + 2 weight gradients over 128 columns (+ small ones)
+    targets = n
+    gen_b = 8 * n + 5 * A + targets * ((K + 127) * 512 // 64 + 4 * K) + targets * 4 * K + targets * 1536
+    gen_f = 7 * 2.0 * 128 * 128 * n + 3.0 * 128 * K * targets
+    items = {"critic_pass_real": (n_critic, real_b, real_f), "critic_pass_generated": (n_critic + 1, fake_b, fake_f),
+             "penalty_term": (n_critic, gp_b, gp_f), "generator_pass": (2, gen_b, gen_f)}
+    total_b = sum(c * b for c, b, _ in items.values())
+    total_f = sum(c * f for c, _, f in items.values())
+    return total_b, total_f, {k: {"per_step": c, "bytes": int(b), "flops": f} for k, (c, b, f) in items.items()}
 
 
 def read_kernel_times(lib):
     """{kernel: (total ms, launches)} recorded by the library's kernel timer since it was switched on."""
     import ctypes as C
     out = {}
-    for k, name in enumerate(TIMED_KERNELS):
+    for k, name in enumerate(timed_kernel_names(lib)):
         ms, cnt = C.c_double(), C.c_int64()
         if lib.aig_kernel_timing_read(k, C.byref(ms), C.byref(cnt)) == 0 and cnt.value:
             out[name] = (ms.value, cnt.value)
@@ -546,6 +607,26 @@ def main():
         terms.release()
     trainer._captured.clear()
     run_steps(nb)                      # (the full recordings again for what follows)
+    # Which kernel is the roofline entry about?  The one with the largest share of the step's kernel time among the
+    # kernels whose algorithmic cost is known (HBM_KERNELS, MFMA_KERNELS) - by THIS run's timings: a few untimed
+    # steps with every critic pass launched eagerly (replayed launches cannot carry events) and every such kernel
+    # bracketed by events of its own.
+    phase("kernel census")
+    census, census_steps = {}, min(3, a.steps)
+    names_lib = timed_kernel_names(lib)
+    all_mask = (1 << len(names_lib)) - 1
+    if not a.no_kernel_timing:
+        trainer.graph_capture = False
+        run_steps(2)
+        barrier()
+        lib.aig_kernel_timing(all_mask)
+        run_steps(census_steps, start=2)
+        barrier()
+        census = read_kernel_times(lib)
+        lib.aig_kernel_timing(0)
+        trainer.graph_capture = True
+    modelled = [k for k in HBM_KERNELS + MFMA_KERNELS if k in census]
+    roofline_kernel = max(modelled, key=lambda k: census[k][0]) if modelled else None
     # The roofline loop.  The headline loop above replays the critic's passes from recordings, and a replayed
     # kernel cannot carry events of its own.  So the same K steps are timed once more with the critic's pass over
     # the generated graphs left unrecorded (--capture-fake off: eager launches), and inside THAT timed region the
@@ -555,7 +636,7 @@ def main():
     phase("roofline loop")
     ms_eager_side = None
     kt_fake = {}
-    if not a.no_kernel_timing:
+    if roofline_kernel is not None:
         trainer.capture_fake = "off"
         for terms in trainer._captured.values():
             terms.release()
@@ -564,7 +645,7 @@ def main():
         run_steps(a.warmup, start=nb)
         barrier()
         _abi.timeline.sizes_of = {"aig_gat_fwd"}
-        lib.aig_kernel_timing(1 << TIMED_KERNELS.index(ROOFLINE_KERNEL))
+        lib.aig_kernel_timing(1 << names_lib.index(roofline_kernel))
         e0 = time.perf_counter()
         run_steps(a.steps, start=nb + a.warmup)
         barrier()
@@ -579,7 +660,7 @@ def main():
     _abi.timeline.reset()
     _abi.timeline.only = None
     _abi.timeline.enabled = True
-    lib.aig_kernel_timing(0 if a.no_kernel_timing else 0xF)       # here all four memory-bound kernels carry events
+    lib.aig_kernel_timing(0 if a.no_kernel_timing else all_mask)  # here every modelled kernel carries events
     run_steps(inst_steps)
     barrier()
     kt_fake_all = read_kernel_times(lib)
@@ -655,7 +736,7 @@ def main():
         real0 = trainer._captured_terms(batches[0])
         if real0 is not None:
             real0.load(batches[0])
-            lib.aig_kernel_timing(0xF)
+            lib.aig_kernel_timing(all_mask)
             for _ in range(5):
                 trainer.D.zero_grad()
                 trainer.D(real0.real_for_D).sum().backward()
@@ -671,23 +752,39 @@ def main():
         peaks = measured_peaks()
         shares = rocprof_shares()
 
+        census_total = sum(ms for ms, _ in census.values())
+
         def kernel_line(kernel, kind, times, where):
             ms, launches = times[kernel]
             us = ms * 1e3 / launches
-            bytes_alg = kernel_bytes(kernel, int(n_avg), int(e_avg), top + 1)
+            nn, ee = int(n_avg), int(e_avg)
+            line = {"kernel": kernel, "graph_kind": kind, "measured": where, "launches": launches, "avg_launch_us": round(us, 2),
+                    "rocprof_share_of_gpu_time_pct": shares.get(kernel)}
+            if kernel in census:      # this run's own census: ms per step of this kernel, share among the timed kernels
+                line["census_ms_per_step"] = round(census[kernel][0] / census_steps, 4)
+                line["census_launches_per_step"] = round(census[kernel][1] / census_steps, 1)
+            bytes_alg = kernel_bytes(kernel, nn, ee, top + 1)
+            if kernel in MFMA_KERNELS:
+                flops = kernel_flops(kernel, nn)
+                tf = flops / (us * 1e-6) / 1e12
+                gbs = bytes_alg / (us * 1e-6) / 1e9
+                line.update({"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": pmc_traffic(a.workload, kernel, kind),
+                             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_alg,
+                             # the product sits at the ridge (32 flop per byte of an [n,128] f32 operand): its memory side
+                             "hbm_achieved_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+                return line
             if kernel == "k_pool_walk" and kind == "fake":
                 # the readout only reads the rows of nodes that carry a level, and on a generated graph that is
                 # the part the repair's walk reaches from the PIs (counters: a fifth of the rows): its
                 # algorithmic bytes are not known on the host, so no fraction is claimed for it
-                return {"kernel": kernel, "graph_kind": kind, "measured": where, "bound": "hbm", "achieved": None,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": pmc_traffic(a.workload, kernel, kind),
-                        "launches": launches, "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": None,
-                        "rocprof_share_of_gpu_time_pct": shares.get(kernel)}
+                line.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                             "traffic": pmc_traffic(a.workload, kernel, kind), "algorithmic_bytes_per_launch": None})
+                return line
             achieved = bytes_alg / (us * 1e-6) / 1e9
-            line = {"kernel": kernel, "graph_kind": kind, "measured": where, "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic(a.workload, kernel, kind), "launches": launches, "avg_launch_us": round(us, 2),
-                    "algorithmic_bytes_per_launch": bytes_alg, "rocprof_share_of_gpu_time_pct": shares.get(kernel)}
+            line.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload, kernel, kind),
+                         "algorithmic_bytes_per_launch": bytes_alg})
             if line["traffic"] and peaks.get("hbm_read_GBs"):
                 # memory-side view: bytes that left the L2 (counters) per second of kernel time, against the read
                 # bandwidth a plain streaming kernel reaches on this GPU (tools/peaks.hip)
@@ -697,19 +794,38 @@ def main():
             return line
 
         roof_all = []
+        every = HBM_KERNELS + MFMA_KERNELS
         if sizes:
             roof_all += [kernel_line(k, "fake", kt_fake, f"events carried by the kernel's own dispatch, eager launches inside a timed region of "
                                      f"{a.steps} steps run with --capture-fake off ({ms_eager_side:.3f} ms/step; the headline loop replays "
                                      "these launches from a recording, which cannot carry events)")
-                         for k in HBM_KERNELS if k in kt_fake]
+                         for k in every if k in kt_fake]
             roof_all += [kernel_line(k, "fake", kt_fake_all, f"events around the kernel, eager launches of {inst_steps} extra "
                                      "instrumented steps outside the timed region")
-                         for k in HBM_KERNELS if k in kt_fake_all and k not in kt_fake]
+                         for k in every if k in kt_fake_all and k not in kt_fake]
             roof_all += [kernel_line(k, "real", kt_real, "events around the kernel, 5 eager critic passes outside the timed region")
-                         for k in HBM_KERNELS if k in kt_real]
-        # the headline entry: the memory-bound kernel with the largest share of the step's GPU time
-        in_region = [r for r in roof_all if r["graph_kind"] == "fake" and r["kernel"] == ROOFLINE_KERNEL and r["kernel"] in kt_fake]
+                         for k in every if k in kt_real]
+        # the headline entry: the kernel with the largest share of the step's kernel time among the kernels with a known
+        # algorithmic cost, by this run's census; its figure comes from the launches inside the timed region above
+        in_region = [r for r in roof_all if r["kernel"] == roofline_kernel and r["kernel"] in kt_fake and r["graph_kind"] == "fake"]
         roof = in_region[0] if in_region else None
+        if roof is not None:
+            roof = dict(roof, chosen_by=f"largest share of the step's kernel time among the kernels with a known algorithmic cost, "
+                                        f"from {census_steps} fully eager steps of this run: " +
+                                        ", ".join(f"{k} {census[k][0] / census_steps:.3f} ms/step" for k in
+                                                  sorted(modelled, key=lambda k: -census[k][0])))
+        # the whole step against the memory and the matrix cores: algorithmic bytes / flops of every pass of the step
+        # (step_cost_model) over the headline step time
+        e_real = edges_rank / max(a.steps, 1) - e_avg if sizes else 0.0
+        sb, sf, items = step_cost_model(int(n_avg) if sizes else nodes_per_iter, int(max(e_real, 0)), int(e_avg), top + 1, 64,
+                                        targs.n_critic)
+        step_s = elapsed / a.steps
+        roofline_step = {"algorithmic_bytes_per_step": int(sb), "flops_per_step": sf, "achieved": round(sb / step_s / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sb / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "achieved_TFLOPs": round(sf / step_s / 1e12, 2), "frac_of_f32_matrix_peak": round(sf / step_s / 1e12 / MFMA_F32_PEAK_TF, 4),
+                         "items": items,
+                         "note": "bytes and flops of the step's passes by the algorithm (bench.py: step_cost_model) over ms_per_step; "
+                                 "the step is the sum of its wide kernels' durations, each at 0.4-0.9 of its own bound"}
         # the dense contraction of the path: node projections of the generator (7 products of
         # [n,128]x[128,128] per sample) on the f32 matrix cores, flops executed / event time
         mfma = None
@@ -751,7 +867,9 @@ def main():
                            f"the rate with {a.sample_in_flight} independent samples in flight "
                            "on as many streams, and the rate of strictly one sample after another",
             "roofline": roof,
+            "roofline_step": roofline_step,
             "roofline_kernels": roof_all,
+            "kernel_census_ms_per_step": {k: round(v[0] / census_steps, 4) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
             "roofline_note": "bytes of the gathers count once per list entry in `achieved` (algorithmic), so a graph whose edges "
                              "hang on a few sources - what the untrained generator wires, kind 'fake' - is served by the caches and "
                              "can exceed what the memory delivers; `traffic` is what left the L2 (counter passes, per kind)",
