@@ -116,8 +116,11 @@ def rocprof_shares():
 # what one launch on a graph of n nodes / e edges / `levels` depth levels costs by the algorithm: bytes for the
 # memory-bound ones (every gathered row counts once per list entry, whether a cache serves it or not), flops for the
 # two dense products (which sit at the ridge: their bytes are given too).
-HBM_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_gat1_fwd", "k_gat1_bwd"]
-MFMA_KERNELS = ["k_linear128", "k_wgrad128"]
+HBM_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_gat1_fwd", "k_gat1_bwd", "k_linear128"]
+MFMA_KERNELS = ["k_wgrad128"]
+# k_linear128 takes its products on the bf16 matrix cores (every f32 operand cut into three bf16 pieces, six piece
+# products: f32 accuracy at 6/16 of the f32 matrix time, csrc/dense6.hip), which leaves it bound by reading X and
+# writing Y: priced against the memory, its f32-equivalent product rate given beside it.
 
 
 def timed_kernel_names(lib):
@@ -158,14 +161,14 @@ def kernel_bytes(kernel: str, n: int, e: int, levels: int) -> int:
         return 552 * n + 32 * e
     if kernel == "k_gat1_bwd":
         return 1064 * n + 32 * e
-    if kernel in MFMA_KERNELS:
+    if kernel in ("k_linear128", "k_wgrad128"):
         return 1024 * n
     raise KeyError(kernel)
 
 
 def kernel_flops(kernel: str, n: int) -> float:
     """[n,128] x [128,128] (k_linear128) and its transpose-side reduction over the nodes (k_wgrad128)."""
-    if kernel in MFMA_KERNELS:
+    if kernel in ("k_linear128", "k_wgrad128"):
         return 2.0 * 128 * 128 * n
     raise KeyError(kernel)
 
@@ -782,6 +785,10 @@ def main():
                              "traffic": pmc_traffic(a.workload, kernel, kind), "algorithmic_bytes_per_launch": None})
                 return line
             achieved = bytes_alg / (us * 1e-6) / 1e9
+            if kernel == "k_linear128":
+                tf = kernel_flops(kernel, nn) / (us * 1e-6) / 1e12
+                line.update({"f32_equivalent_TFLOPs": round(tf, 1), "f32_matrix_peak": MFMA_F32_PEAK_TF,
+                             "arithmetic": "six bf16 piece products per f32 product on the bf16 matrix cores, f32 accumulate"})
             line.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a.workload, kernel, kind),
                          "algorithmic_bytes_per_launch": bytes_alg})

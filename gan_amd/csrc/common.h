@@ -78,6 +78,11 @@ bool kernel_timing_events(int kernel, hipStream_t s, hipEvent_t* start, hipEvent
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
     } while (0)
 
+// y = act(x W^T + bias), x [M,128] f32, on the bf16 matrix cores at f32 accuracy (dense6.hip).  W: [128][ldw] rows =
+// output columns, or (wt) stored [in][out]; act 0 none, 1 ReLU, 2 ELU.
+int launch_linear128_x6(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, const float* bias, int act,
+                        float* out);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not

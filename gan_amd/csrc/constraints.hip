@@ -1587,7 +1587,7 @@ int resync(const GraphSet& gs, const float* x, const int64_t* edge_index, const 
     int* d32 = c.take<int>(N + 2);
     int* q0 = c.take<int>(N + 2);
     int* q1 = c.take<int>(N + 2);
-    int* popped = c.take<int>(N + 2);
+    (void)c.take<int>(N + 2);      // (room the workspace size still counts)
     unsigned* key = c.take<unsigned>(M);
     unsigned* skey = c.take<unsigned>(M);
     int* ids = c.take<int>(M);

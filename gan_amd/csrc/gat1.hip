@@ -19,7 +19,7 @@
 namespace aig {
 namespace {
 
-constexpr int H = GAT_H, HEADS = GAT_HEADS, THREADS = GAT_THREADS, HW_PER_BLOCK = GAT_HW_PER_BLOCK;
+constexpr int H = GAT_H, HEADS = GAT_HEADS, THREADS = GAT_THREADS;
 // coef[0..7] = cs[f][h] (f major), coef[8..15] = cd[f][h], coef[16..19] = ce[h]
 constexpr int COEF = 20;
 // columns of a block's partial row in the backward pass

@@ -919,6 +919,9 @@ extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Chunk ck{w, bias, y, H, w_in_major ? 1 : 0};
     AIG_REQUIRE(act >= 0 && act <= 2, "aig_linear128: act=%d (0 none, 1 ReLU, 2 ELU)", act);
+    // the six-product form on the bf16 matrix cores (dense6.hip) unless AIG_LINEAR128_F32=1 asks for the f32 products
+    static const bool f32_products = [] { const char* e = getenv("AIG_LINEAR128_F32"); return e && e[0] == '1'; }();
+    if (!f32_products) return launch_linear128_x6(s, static_cast<int>(n), x, w, H, w_in_major ? 1 : 0, bias, act, y);
     if (act == 1) return launch_linear<1>(s, static_cast<int>(n), x, ck);
     if (act == 2) return launch_linear<2>(s, static_cast<int>(n), x, ck);
     return launch_linear<0>(s, static_cast<int>(n), x, ck);

@@ -387,6 +387,33 @@ def test_linear128_matches_fp32_matmul(n, in_major):
         assert torch.equal(y2[64], y2[0])
 
 
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear128_six_product_form_is_f32_accurate(act):
+    """aig_linear128 takes its products on the bf16 matrix cores, every f32 operand cut into three bf16 pieces and six
+    of the nine piece products kept: held here to float64 with the error bound of an f32 dot product of 128 terms
+    (a few 2^-24 of sum |x w| per element), on operands whose magnitudes span twelve decades (gradients are tiny,
+    activations are not), with bias and activation; a row of zeros gives exactly the activation of the bias."""
+    gen = torch.Generator().manual_seed(3 + act)
+    n = 20000
+    mag = 10.0 ** torch.randint(-9, 4, (n, 1), generator=gen).float()
+    x = (torch.randn(n, 128, generator=gen) * mag)
+    x[5] = 0.0
+    w = torch.randn(128, 128, generator=gen) / 11.3
+    b = torch.randn(128, generator=gen)
+    y = torch.empty(n, 128, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    _abi.check(_abi.lib().aig_linear128(n, _abi.ptr(xd), _abi.ptr(wd), 0, _abi.ptr(bd), act, _abi.ptr(y), _abi.stream()))
+    pre = x.double() @ w.double().t() + b.double()
+    want = pre if act == 0 else (pre.clamp(min=0) if act == 1 else torch.where(pre > 0, pre, torch.expm1(pre)))
+    bound = 8 * 2.0 ** -24 * (x.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+    err = (y.cpu().double() - want).abs()
+    assert bool((err <= bound).all()), float((err / bound).max())
+    if act < 2:
+        assert torch.equal(y[5].cpu(), b if act == 0 else b.clamp(min=0))
+    else:       # (the device's expm1f and the host's may differ in the last bit)
+        assert torch.allclose(y[5].cpu(), torch.where(b > 0, b, torch.expm1(b)), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 4099, 100003])
 def test_linear_in2_matches_fp32_product(n):
     """aig_linear_in2 (first attention layer's projection of the two node features) against the fp32 product,
