@@ -387,12 +387,18 @@ void* g_scratch_ptr[MAX_DEVICES] = {};   // device address of `scratch` on devic
 
 // Device address of this device's copy of `scratch`.  The array's name is only a host-side handle: the address
 // comes from hipGetSymbolAddress, asked once per device with that device current.
-int scratch_address(void** out) {
+int scratch_address(void** out, hipStream_t stream) {
     int dev = -1;
     AIG_HIP_CHECK(hipGetDevice(&dev));
     AIG_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "aig_level_pool_fwd_noalloc: device index %d beyond %d", dev, MAX_DEVICES);
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
+        // The look-up may load the code object and is no stream operation: not something to do while the caller's
+        // stream is being recorded into a graph.  The first call on a device has to come outside any recording.
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+            return fail(AIG_EINVAL, "aig_level_pool_fwd_noalloc: the first call on a device looks up the scratch array's "
+                        "address and cannot be recorded into a graph - call it once outside the recording first");
         void* p = nullptr;
         AIG_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         AIG_REQUIRE(p != nullptr, "aig_level_pool_fwd_noalloc: no device address for the scratch array");
@@ -413,7 +419,7 @@ extern "C" int aig_level_pool_fwd_noalloc(int64_t n, int64_t nvalid, int64_t L, 
                     "built-in array holds %zu (use aig_level_pool_fwd with a workspace of your own)",
                     (long long)n, (long long)L + 1, need, (size_t)AIG_NOALLOC_SCRATCH_BYTES);
     void* ptr = nullptr;
-    if (int rc = scratch_address(&ptr)) return rc;
+    if (int rc = scratch_address(&ptr, static_cast<hipStream_t>(stream))) return rc;
     // the array keeps the previous call's contents: aig_level_pool_fwd clears the table it carves out of it
     return aig_level_pool_fwd(n, nvalid, L, lvl_meta, h, perm, lvl_ptr, node_level, w, out, argmax, ptr,
                               (size_t)AIG_NOALLOC_SCRATCH_BYTES, stream);

@@ -301,7 +301,9 @@ int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_
  * with up to 2,000 levels, or 100,000 nodes with 3,900); beyond it the call returns AIG_ELIMIT and touches nothing.
  * All calls on one GPU share that GPU's array: it keeps the last call's contents (the call clears what it needs
  * zeroed itself), and two calls whose kernels overlap in time on one GPU - different streams, different host
- * threads - race on it.  Serialise them, or use aig_level_pool_fwd with separate workspaces. */
+ * threads - race on it.  Serialise them, or use aig_level_pool_fwd with separate workspaces.  The FIRST call on a
+ * device looks up the array's device address (hipGetSymbolAddress, kept per device afterwards) and must not come
+ * while `stream` is being recorded into a graph - it is refused there with AIG_EINVAL; later calls can be recorded. */
 int aig_level_pool_fwd_noalloc(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
                                const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
                                float* out, int32_t* argmax, void* stream);

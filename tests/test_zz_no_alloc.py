@@ -56,6 +56,50 @@ def check_case(n, levels, seed, dyn=False):
     np.testing.assert_allclose(out_na[0], ref.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def _args(plan, h, out, argmax):
+    return [plan.n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
+            _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(out), _abi.ptr(argmax)]
+
+
+def test_recorded_into_a_graph_and_replayed():
+    """What the entry point is for: under HIP graph capture.  The very first call of a process on a device looks up
+    the scratch array's address and is refused inside a recording (when this file runs in a process of its own, that
+    is the call made here); after one call outside, the call is recorded and replayed on new rows, bit-equal to the
+    workspace form each time."""
+    lib = _abi.lib()
+    n, levels = 30000, 90
+    g = torch.Generator().manual_seed(11)
+    depth = torch.randint(-1, levels, (n,), generator=g)
+    depth[:levels] = torch.arange(levels)
+    plan = LevelPlan(depth.to(DEV), n, DEV)
+    h = torch.randn((n, H), generator=g).to(DEV)
+    out = torch.zeros((1, 2 * H), device=DEV)
+    argmax = torch.zeros((plan.L + 1, H), dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        first_rc = lib.aig_level_pool_fwd_noalloc(*_args(plan, h, out, argmax), _abi.stream())
+    if first_rc != 0:      # nothing had looked the address up yet: refused, nothing recorded
+        assert first_rc == -1 and "outside the recording" in lib.aig_last_error().decode()
+    del graph
+    _abi.check(lib.aig_level_pool_fwd_noalloc(*_args(plan, h, out, argmax), _abi.stream()))     # outside: allowed
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        _abi.check(lib.aig_level_pool_fwd_noalloc(*_args(plan, h, out, argmax), _abi.stream()))
+    for seed in (21, 22, 23):
+        h.copy_(torch.randn((n, H), generator=torch.Generator().manual_seed(seed)))
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = torch.empty_like(out)
+        am = torch.empty_like(argmax)
+        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), DEV)
+        _abi.check(lib.aig_level_pool_fwd(*_args(plan, h, want, am), _abi.ptr(ws), ws.numel(), _abi.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and torch.equal(argmax, am), seed
+
+
 def test_two_calls_in_a_row_second_smaller_then_larger():
     check_case(n=60000, levels=700, seed=1)
     check_case(n=900, levels=12, seed=2)            # the array still holds the 700-level table of the call before
