@@ -33,7 +33,8 @@ class GenWireSet(C.Structure):
                 [(n, P) for n in ("x", "order", "rank", "want", "cnt", "fb", "eoff", "cand", "proj")] +
                 [("proj_rows", I64)] +
                 [(n, P) for n in ("sc2_w", "sc2_b", "at2_w", "at2_b", "logits", "sel", "edge_index", "edge_attr",
-                                  "ecount", "x_out")])
+                                  "ecount", "x_out")] +
+                [("proj_half", I64)])
 
 
 # name -> (restype, argtypes); every symbol of include/aig_abi.h appears here
@@ -49,6 +50,8 @@ SIGNATURES = {
     "aig_gen_node_proj_bf16_ws_bytes": (SZ, [I64]),
     "aig_gen_node_proj_bf16": (INT, [I64, I64, P, P, C.POINTER(GenWeights), P, P, P, SZ, P]),
     "aig_gen_score": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, P]),
+    "aig_gen_score_half": (INT, [I64, I64, P, P, P, P, P, P, P, P, P, P]),
+    "aig_gen_emit_half": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "aig_topk_select_ws_bytes": (SZ, [I64, I64]),
     "aig_topk_select": (INT, [I64, I64, P, P, P, P, P, SZ, P]),
     "aig_gen_emit": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

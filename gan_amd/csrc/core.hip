@@ -122,6 +122,6 @@ extern "C" int aig_kernel_timing_read(int kernel, double* total_ms, int64_t* lau
     return AIG_OK;
 }
 
-extern "C" int aig_abi_version(void) { return 4; }
+extern "C" int aig_abi_version(void) { return 5; }
 
 extern "C" const char* aig_last_error(void) { return aig::err_buf(); }

@@ -380,11 +380,11 @@ __global__ __launch_bounds__(THREADS) void k_node_proj4(int M, int rpb, Proj4 p)
 // ---------------------------------------------------------------------------------------------
 // The same node pipeline on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, f32 accumulate): inputs of
 // every product - activations and weights - are rounded to bf16 (round to nearest even), sums, biases
-// and activations stay f32, outputs are stored as f32.  One kernel for all seven 128x128 products of a
+// and activations stay f32; h_cond is stored as f32, the four planes as IEEE halfs (clamped to +-32752).  One kernel for all seven 128x128 products of a
 // 64-row tile: a wave owns 32 output columns of every layer and keeps their weights, packed as matrix
-// fragments, in registers (7 x 32 registers); tiles go LDS -> LDS between layers as bf16, an f32 staging
-// tile turns each output into whole 512-byte rows for the store.  Eight products per 32x32 block instead
-// of 64, so the kernel is bound by the 2 KB of output per row, not by the matrix cores.  As in the f32
+// fragments, in registers (7 x 32 registers); tiles go LDS -> LDS between layers as bf16, a staging
+// tile turns each output into whole rows for the store.  Eight products per 32x32 block instead
+// of 64, so the kernel is bound by the 1 KB of output per row, not by the matrix cores.  As in the f32
 // pipeline a result depends on its own input row only (one fixed chain of operations per element), so
 // equal rows give equal bits wherever they sit.
 // Rows may belong to several samples of one template that differ in z alone (bulk sampling): then the
@@ -395,7 +395,13 @@ using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 constexpr int BF_LD = H + 8;    // bf16 elements per LDS row: 272 bytes, rows stay 16-byte aligned
 constexpr int ST_LD = H + 4;    // floats per row of the staging tile
 constexpr int PIPE_LAYERS = 7;  // enc2, proj0 (node half), proj2, scorer src / tgt, attr src / tgt
-constexpr size_t PIPE_LDS = 2 * BM * BF_LD * sizeof(__bf16) + BM * ST_LD * sizeof(float);
+constexpr int SH_LD = H + 8;    // halfs per row of a staging tile of halfs (rows stay 16-byte aligned)
+// two bf16 tiles and the staging area: one f32 tile (h_cond) or two tiles of halfs (the planes, alternating)
+constexpr size_t PIPE_STAGE = BM * ST_LD * sizeof(float) > 2 * BM * SH_LD * 2 ? BM * ST_LD * sizeof(float) : 2 * BM * SH_LD * 2;
+constexpr int PIPE_VEC = PIPE_LAYERS * H;   // floats of one tile's bias vectors
+// ... and, twice (this tile's and the next one's, fetched a tile ahead), the bias vectors and the x rows of a tile
+constexpr size_t PIPE_LDS = 2 * BM * BF_LD * sizeof(__bf16) + PIPE_STAGE + 2 * (PIPE_VEC * sizeof(float) + BM * sizeof(float2));
+static_assert(PIPE_STAGE % 16 == 0, "the bias vectors behind the staging area are read in 16-byte pieces");
 
 struct PipeBf16 {
     const float* x;        // [x_rows][2]
@@ -409,8 +415,9 @@ struct PipeBf16 {
     int x_rows;            // rows of x per sample (a sample's rows past them repeat the last one)
     int x_sample_rows;     // rows of x from one sample to the next (0: all samples read the same x)
     float* h_cond;         // [M][128] or null
-    float* out[4];         // [M][128] each
+    _Float16* out[4];      // [M][128] each, IEEE half
 };
+constexpr float HALF_PLANE_MAX = 32752.f;   // planes are clamped to this: the sum of two entries stays finite in half
 
 // wpack[l][wave][s][lane][j] = bf16(W_l[wave*32 + (lane & 31)][16 s + 8 (lane >> 5) + j])
 struct PackSrc {
@@ -430,7 +437,18 @@ __global__ void k_pack_bf16(PackSrc src, __bf16* __restrict__ wpack) {
 
 // one layer of a 64-row tile: acc = tile W^T (A operand = the wave's weight fragments, B operand = tile rows,
 // so a lane ends up with four groups of four consecutive output columns of tile rows frow and frow + 32)
-template <bool RELU, bool TO_BF16, bool TO_STAGE>
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4_t to_half4(float4 y) {
+    half4_t h;
+    h[0] = (_Float16)__builtin_amdgcn_fmed3f(y.x, -HALF_PLANE_MAX, HALF_PLANE_MAX);
+    h[1] = (_Float16)__builtin_amdgcn_fmed3f(y.y, -HALF_PLANE_MAX, HALF_PLANE_MAX);
+    h[2] = (_Float16)__builtin_amdgcn_fmed3f(y.z, -HALF_PLANE_MAX, HALF_PLANE_MAX);
+    h[3] = (_Float16)__builtin_amdgcn_fmed3f(y.w, -HALF_PLANE_MAX, HALF_PLANE_MAX);
+    return h;
+}
+
+// TO_STAGE 1: the output goes to the staging tile as f32 rows of ST_LD floats; 2: as rows of SH_LD halfs
+template <bool RELU, bool TO_BF16, int TO_STAGE>
 __device__ __forceinline__ void pipe_layer(const __bf16* tin, const bf16x8 (&w)[8], const float* __restrict__ bias,
                                            __bf16* tout, float* stage, int tid) {
     const int lane = tid & 63, wave = tid >> 6, frow = lane & 31, fh = lane >> 5;
@@ -461,9 +479,14 @@ __device__ __forceinline__ void pipe_layer(const __bf16* tin, const bf16x8 (&w)[
             *reinterpret_cast<bf16x4*>(tout + frow * BF_LD + col) = p0;
             *reinterpret_cast<bf16x4*>(tout + (frow + 32) * BF_LD + col) = p1;
         }
-        if (TO_STAGE) {
+        if (TO_STAGE == 1) {
             *reinterpret_cast<float4*>(stage + frow * ST_LD + col) = y0;
             *reinterpret_cast<float4*>(stage + (frow + 32) * ST_LD + col) = y1;
+        }
+        if (TO_STAGE == 2) {
+            _Float16* sh = reinterpret_cast<_Float16*>(stage);
+            *reinterpret_cast<half4_t*>(sh + frow * SH_LD + col) = to_half4(y0);
+            *reinterpret_cast<half4_t*>(sh + (frow + 32) * SH_LD + col) = to_half4(y1);
         }
     }
 }
@@ -499,44 +522,86 @@ __global__ __launch_bounds__(THREADS) void k_node_pipe_bf16(int M, PipeBf16 p) {
                     *reinterpret_cast<const float4*>(stage + row * ST_LD + 4 * c4);
         }
     };
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ... and of a staging tile of halfs: 16 pieces of 16 bytes per row
+    auto drain_half = [&](const float* st, _Float16* gout, int row0) {
+        const _Float16* sh = reinterpret_cast<const _Float16*>(st);
+#pragma unroll
+        for (int q = 0; q < BM / 16; ++q) {
+            const int row = q * 16 + (tid >> 4);
+            if (row0 + row < M)
+                *reinterpret_cast<uint4*>(gout + static_cast<size_t>(row0 + row) * H + 8 * (tid & 15)) =
+                    *reinterpret_cast<const uint4*>(sh + row * SH_LD + 8 * (tid & 15));
+        }
+    };
+    // What a tile needs from memory besides the weights - its seven bias vectors (three of them its sample's) and its
+    // 64 rows of x - is fetched while the tile before it is worked on and handed over through the LDS: with one wave
+    // per SIMD nothing else would cover the latency of a load in front of every layer.
+    float* const vec = reinterpret_cast<float*>(smem_pipe + 2 * BM * BF_LD * sizeof(__bf16) + PIPE_STAGE);   // [2][7][128]
+    float2* const xs = reinterpret_cast<float2*>(vec + 2 * PIPE_VEC);                                        // [2][64]
+    float4 fb = make_float4(0, 0, 0, 0);
+    float2 fx = make_float2(0, 0);
+    auto fetch = [&](int tile) {
         const int row0 = tile * BM;
         const int sample = p.rows_per_sample > 0 ? row0 / p.rows_per_sample : 0;
         const int xrow0 = row0 - sample * p.rows_per_sample;
-        const int xlimit = p.x_rows;
-        const float* bias[PIPE_LAYERS];
+        if (tid < PIPE_LAYERS * 32) {
+            const float* b = p.b[0];
+            bool zd = p.zdep[0];
 #pragma unroll
-        for (int l = 0; l < PIPE_LAYERS; ++l) bias[l] = p.b[l] + (p.zdep[l] ? static_cast<size_t>(sample) * p.zstride : 0);
+            for (int l = 1; l < PIPE_LAYERS; ++l)
+                if ((tid >> 5) == l) { b = p.b[l]; zd = p.zdep[l]; }
+            fb = *reinterpret_cast<const float4*>(b + (zd ? static_cast<size_t>(sample) * p.zstride : 0) + 4 * (tid & 31));
+        }
+        if (tid < BM)
+            fx = *reinterpret_cast<const float2*>(
+                p.x + (static_cast<size_t>(sample) * p.x_sample_rows + min(xrow0 + tid, p.x_rows - 1)) * 2);
+    };
+    auto hand_over = [&](int buf) {
+        if (tid < PIPE_LAYERS * 32) *reinterpret_cast<float4*>(vec + buf * PIPE_VEC + 4 * tid) = fb;
+        if (tid < BM) xs[buf * BM + tid] = fx;
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    fetch(tile);
+    hand_over(0);
+    __syncthreads();
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        const int row0 = tile * BM;
+        const int buf = it & 1;
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (more) fetch(tile + gridDim.x);
+        const float* bias = vec + buf * PIPE_VEC;
         // enc0 = Linear(2,128) + ReLU in f32, rounded to bf16 into t0 (rows past the end repeat the last row)
 #pragma unroll
         for (int q = 0; q < BM / 8; ++q) {
             const int row = q * 8 + (tid >> 5);
-            const float2 xv = *reinterpret_cast<const float2*>(
-                p.x + (static_cast<size_t>(sample) * p.x_sample_rows + min(xrow0 + row, xlimit - 1)) * 2);
+            const float2 xv = xs[buf * BM + row];
             bf16x4 o;
 #pragma unroll
             for (int u = 0; u < 4; ++u) o[u] = (__bf16)fmaxf(fmaf(xv.y, e1[u], xv.x * e0[u]) + eb[u], 0.f);
             *reinterpret_cast<bf16x4*>(t0 + row * BF_LD + 4 * c4) = o;
         }
         __syncthreads();
-        pipe_layer<true, true, false>(t0, wr[0], bias[0], t1, stage, tid);
+        pipe_layer<true, true, 0>(t0, wr[0], bias, t1, stage, tid);
         __syncthreads();
-        pipe_layer<true, true, false>(t1, wr[1], bias[1], t0, stage, tid);
+        pipe_layer<true, true, 0>(t1, wr[1], bias + H, t0, stage, tid);
         __syncthreads();
         if (p.h_cond) {
-            pipe_layer<true, true, true>(t0, wr[2], bias[2], t1, stage, tid);
+            pipe_layer<true, true, 1>(t0, wr[2], bias + 2 * H, t1, stage, tid);
             __syncthreads();
             drain(p.h_cond, row0);
         } else {
-            pipe_layer<true, true, false>(t0, wr[2], bias[2], t1, stage, tid);
+            pipe_layer<true, true, 0>(t0, wr[2], bias + 2 * H, t1, stage, tid);
         }
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            pipe_layer<false, false, true>(t1, wr[3 + o], bias[3 + o], t0, stage, tid);
+            // the two staging tiles alternate: an output is drained while the next one is formed in the other tile
+            float* const st = stage + (o & 1) * (BM * SH_LD / 2);
+            pipe_layer<false, false, 2>(t1, wr[3 + o], bias + (3 + o) * H, t0, st, tid);
+            if (o == 3 && more) hand_over(buf ^ 1);   // (its last readers were the tile before this one)
             __syncthreads();
-            drain(p.out[o], row0);
-            __syncthreads();
+            drain_half(st, p.out[o], row0);
         }
     }
 }
@@ -809,7 +874,7 @@ size_t proj_bf16_ws(int64_t samples) {
 // to one graph), the rows between a graph's last node and the next boundary repeat its last row.  x advances by
 // x_sample_rows rows per graph (0: one template, the graphs differ in z alone).
 int node_proj_bf16(hipStream_t s, int n, int samples, const float* x, int x_sample_rows, const float* z,
-                   const aig_gen_weights* w, float* h_cond, float* proj, void* ws, const char* who, bool tiled = false) {
+                   const aig_gen_weights* w, float* h_cond, void* proj, void* ws, const char* who, bool tiled = false) {
     Carver c(ws);
     __bf16* wpack = c.take<__bf16>(static_cast<size_t>(PIPE_LAYERS) * H * H);
     float* zb = c.take<float>(static_cast<size_t>(samples) * 4 * H);
@@ -845,7 +910,7 @@ int node_proj_bf16(hipStream_t s, int n, int samples, const float* x, int x_samp
     p.x_rows = n;
     p.x_sample_rows = x_sample_rows;
     p.h_cond = h_cond;
-    for (int o = 0; o < 4; ++o) p.out[o] = proj + o * plane;
+    for (int o = 0; o < 4; ++o) p.out[o] = static_cast<_Float16*>(proj) + o * plane;
     const int ntiles = (M + BM - 1) / BM;
     hipLaunchKernelGGL(k_node_pipe_bf16, dim3(ntiles < 256 ? ntiles : 256), dim3(THREADS), PIPE_LDS, s, M, p);
     AIG_LAUNCH_CHECK();
@@ -871,11 +936,11 @@ extern "C" int aig_gen_node_proj(int64_t n, const float* x, const float* z, cons
 extern "C" size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples) { return proj_bf16_ws(samples); }
 
 extern "C" int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w,
-                                      float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream) {
+                                      float* h_cond, void* proj, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n >= 0 && samples >= 1 && n * samples < INT32_MAX, "aig_gen_node_proj_bf16: n=%lld samples=%lld out of range",
                 (long long)n, (long long)samples);
     if (n == 0) return AIG_OK;
-    int rc = check_gen_weights("aig_gen_node_proj_bf16", x, z, w, h_cond, proj, ws);
+    int rc = check_gen_weights("aig_gen_node_proj_bf16", x, z, w, h_cond, static_cast<const float*>(proj), ws);
     if (rc) return rc;
     if (ws_bytes < aig_gen_node_proj_bf16_ws_bytes(samples))
         return fail(AIG_EWORKSPACE, "aig_gen_node_proj_bf16: workspace %zu < %zu", ws_bytes,
@@ -891,11 +956,11 @@ extern "C" size_t aig_gen_node_proj_batch_ws_bytes(int64_t B, int64_t n, int bf1
 }
 
 extern "C" int aig_gen_node_proj_batch(int64_t B, int64_t n, const float* x, int x_shared, const float* z,
-                                       const aig_gen_weights* w, int bf16, float* proj, void* ws, size_t ws_bytes,
+                                       const aig_gen_weights* w, int bf16, void* proj, void* ws, size_t ws_bytes,
                                        void* stream) {
     AIG_REQUIRE(B >= 1 && B <= 65535 && n >= 1 && B * aig_gen_batch_rows(n) < INT32_MAX,
                 "aig_gen_node_proj_batch: B=%lld n=%lld out of range", (long long)B, (long long)n);
-    int rc = check_gen_weights("aig_gen_node_proj_batch", x, z, w, nullptr, proj, ws);
+    int rc = check_gen_weights("aig_gen_node_proj_batch", x, z, w, nullptr, static_cast<const float*>(proj), ws);
     if (rc) return rc;
     if (ws_bytes < aig_gen_node_proj_batch_ws_bytes(B, n, bf16))
         return fail(AIG_EWORKSPACE, "aig_gen_node_proj_batch: workspace %zu < %zu", ws_bytes,
@@ -906,8 +971,8 @@ extern "C" int aig_gen_node_proj_batch(int64_t B, int64_t n, const float* x, int
         return node_proj_bf16(s, static_cast<int>(n), static_cast<int>(B), x, x_shared ? 0 : static_cast<int>(n), z, w,
                               nullptr, proj, ws, "aig_gen_node_proj_batch", true);
     }
-    return node_proj_f32(s, static_cast<int>(B), static_cast<int>(n), x, x_shared ? 0 : 2 * n, z, w, nullptr, proj,
-                         aig_gen_batch_rows(n), ws);
+    return node_proj_f32(s, static_cast<int>(B), static_cast<int>(n), x, x_shared ? 0 : 2 * n, z, w, nullptr,
+                         static_cast<float*>(proj), aig_gen_batch_rows(n), ws);
 }
 
 extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,

@@ -186,7 +186,8 @@ __device__ void nth_element_(RowView<S>& q, int nth, int c) {
     }
 }
 
-// One thread per row.  Rows with k*64 <= c replay std::partial_sort, whose heap of k <= 2 entries
+// One thread per row (fused != 0: rows with k*64 <= c already have their picks, from k_score_tiled).  Rows with
+// k*64 <= c replay std::partial_sort, whose heap of k <= 2 entries
 // fits in registers and whose scan never re-reads a displaced element; shorter rows (c < 128)
 // replay std::nth_element on an LDS copy.
 constexpr int SEL_THREADS = 128;
@@ -195,7 +196,7 @@ constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets
 __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
                                                              const int* __restrict__ cnt,
                                                              const int* __restrict__ want, int* __restrict__ sel,
-                                                             GenSet gs) {
+                                                             int fused, GenSet gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
         const long long g = blockIdx.y;
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, i
     const int my_c = my_r < rows ? cnt[my_r] : 0;
     const int my_k = my_r < rows ? min(want[my_r], my_c) : 0;
     const bool my_need = my_k > 0 && my_k * 64 > my_c;   // replayed on the LDS copy
-    for (int t0 = 0; t0 < 64; t0 += 8) {
+    const bool any_need = __syncthreads_or(my_need);
+    for (int t0 = 0; any_need && t0 < 64; t0 += 8) {
         float v0[8], v1[8];
         int cc[8];
 #pragma unroll
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, i
     int s0 = -1, s1 = -1;
     if (k > 0) {
         if (k * 64 <= c) {
+            if (fused) return;   // picked by the kernel that scored the slot
             const float* row = logits + static_cast<size_t>(r) * ld;
             if (k == 1) {
                 // heap of one: an element replaces the top only when strictly ahead of it
@@ -303,12 +306,44 @@ __device__ __forceinline__ int inv_bit(const float* __restrict__ A2, const float
     return (acc + bias) > 0.f ? 1 : 0;  // sigmoid(l) > 0.5
 }
 
+// Packed IEEE-half arithmetic of the reduced-precision option: planes hold halfs, a sum of two of them is rounded to
+// half (v_pk_add_f16), the products with the half-rounded weights are accumulated in f32 two at a time
+// (v_dot2c_f32_f16), channels ascending.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float term_h(unsigned a, unsigned b, unsigned w, float acc) {
+    half2_t t = __builtin_bit_cast(half2_t, a) + __builtin_bit_cast(half2_t, b);
+    const half2_t zero = {0, 0};
+    t = __builtin_elementwise_max(t, zero);
+    return __builtin_amdgcn_fdot2(t, __builtin_bit_cast(half2_t, w), acc, false);
+}
+__device__ __forceinline__ unsigned pack_h(float lo, float hi) {
+    half2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ int inv_bit_h(const _Float16* __restrict__ A2, const _Float16* __restrict__ B2,
+                                         const float* __restrict__ w, float bias, int s, int v) {
+    const uint4* a = reinterpret_cast<const uint4*>(A2 + static_cast<size_t>(s) * H);
+    const uint4* b = reinterpret_cast<const uint4*>(B2 + static_cast<size_t>(v) * H);
+    const float4* ww = reinterpret_cast<const float4*>(w);
+    float acc = 0.f;
+    for (int j = 0; j < H / 8; ++j) {
+        const uint4 x = a[j], y = b[j];
+        const float4 z0 = ww[2 * j], z1 = ww[2 * j + 1];
+        acc = term_h(x.x, y.x, pack_h(z0.x, z0.y), acc);
+        acc = term_h(x.y, y.y, pack_h(z0.z, z0.w), acc);
+        acc = term_h(x.z, y.z, pack_h(z1.x, z1.y), acc);
+        acc = term_h(x.w, y.w, pack_h(z1.z, z1.w), acc);
+    }
+    return (acc + bias) > 0.f ? 1 : 0;
+}
+
 // E: slots between the source row and the target row of a graph's edge list (its edge count for a single
 // graph, the slot capacity for a set, where graph g's lists start 2 E g slots in and ecount[g] gets its count)
+template <bool HALF>
 __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, const int* __restrict__ order,
                        const int* __restrict__ want, const int* __restrict__ cnt, const int* __restrict__ cand,
                        const int* __restrict__ fb, const int* __restrict__ eoff, const int* __restrict__ sel,
-                       const float* __restrict__ A2, const float* __restrict__ B2, const float* __restrict__ w2a,
+                       const void* __restrict__ A2v, const void* __restrict__ B2v, const float* __restrict__ w2a,
                        const float* __restrict__ b2a, long long* __restrict__ edge_index,
                        long long* __restrict__ edge_attr, float* __restrict__ x_out, GenSet gs,
                        int* __restrict__ ecount) {
@@ -317,10 +352,18 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
     {
         const long long g = blockIdx.y;
         x += g * gs.x; order += g * gs.node; want += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
-        fb += g * gs.node; eoff += g * gs.eoff; sel += g * 2ll * n; A2 += g * gs.proj * H; B2 += g * gs.proj * H;
+        fb += g * gs.node; eoff += g * gs.eoff; sel += g * 2ll * n;
         edge_index += g * 2 * E; edge_attr += g * E; x_out += g * 2ll * n;
         if (ecount && r == 0) ecount[g] = eoff[n];
     }
+    const size_t plane_off = static_cast<size_t>(blockIdx.y) * gs.proj * H;
+    const float* A2 = static_cast<const float*>(A2v) + plane_off;
+    const float* B2 = static_cast<const float*>(B2v) + plane_off;
+    const _Float16* A2h = static_cast<const _Float16*>(A2v) + plane_off;
+    const _Float16* B2h = static_cast<const _Float16*>(B2v) + plane_off;
+    auto bit = [&](int src, int tgt, float bias) {
+        return HALF ? inv_bit_h(A2h, B2h, w2a, bias, src, tgt) : inv_bit(A2, B2, w2a, bias, src, tgt);
+    };
     const int v = order[r];
     const int off = eoff[r], ne = eoff[r + 1] - off;
     int invs = 0;
@@ -333,10 +376,10 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
         } else {
             const float bias = b2a[0];
             s[0] = cand[static_cast<size_t>(r) * K + sel[2 * r]];
-            b[0] = inv_bit(A2, B2, w2a, bias, s[0], v);
+            b[0] = bit(s[0], v, bias);
             if (min(want[r], c) == 2) {
                 s[1] = cand[static_cast<size_t>(r) * K + sel[2 * r + 1]];
-                b[1] = inv_bit(A2, B2, w2a, bias, s[1], v);
+                b[1] = bit(s[1], v, bias);
             } else {  // fewer candidates than fan-ins: the first pick is repeated
                 s[1] = s[0];
                 b[1] = b[0];
@@ -357,31 +400,76 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
 // slot r plus at most the node processed at r, so T consecutive slots only ever touch the rows of
 // cand[r0] and of order[r0 .. r0+T-2]: K+T-1 rows per block instead of K*T gathered rows from L2.
 // A candidate that was processed inside the block's range (rank >= r0, r0 = the block's first scored
-// slot) sits at row K + rank - r0, any other one is found in the ascending id list of slot r0.  Same per-pair arithmetic (one fmaf chain
-// over the 128 channels in order), hence bit-identical logits.
+// slot) sits at row K + rank - r0, any other one at its position in the ascending id list of slot r0.  Same per-pair
+// arithmetic (one fmaf chain over the 128 channels in order), hence bit-identical logits.
 constexpr int SCORE_T = 64;        // slots per block while the window holds at most 128 candidates
 constexpr int SCORE_T_WIDE = 32;   // ... and for windows of up to 256 (the tile must fit the 160 KB of LDS)
 constexpr int SCORE_K_TILED = 256; // wider windows take the gather kernel
 constexpr int SCORE_THREADS = 1024; // sixteen waves share one tile: the per-pair chains are latency-bound
 constexpr int SCORE_LD = H + 4;    // padded row: lanes read different rows at the same column
+constexpr int SCORE_LD_H = H + 8;  // the same padding (16 bytes) for rows of halfs
+constexpr int SCORE_ROUNDS = SCORE_K_TILED / 64;   // a lane scores up to this many candidates of a slot
 
-template <int T>
+// A slot's picks inside the wave that has just scored it: lane j of round q holds the logit of candidate 64 q + j.
+// Replays the heap of k <= 2 entries that std::partial_sort keeps while it scans a row (k_topk_select's register
+// path, taken when k*64 <= c) - a newcomer changes the heap only when it is strictly ahead of the heap's top, so the
+// wave looks for the first such lane, applies that one step, and looks again among the lanes after it with the new top.
+__device__ __forceinline__ float readlane_f(float v, int j) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+__device__ __forceinline__ void wave_partial_sort(const float (&l)[SCORE_ROUNDS], int c, int k, int lane, int& s0, int& s1) {
+    int top = 0, oth = -1;
+    float tv = readlane_f(l[0], 0), ov = 0.f;
+    if (k == 2) {   // make_heap on positions 0, 1
+        const float v1 = readlane_f(l[0], 1);
+        if (gt(v1, tv)) { oth = 1; ov = v1; }
+        else { oth = 0; ov = tv; top = 1; tv = v1; }
+    }
+#pragma unroll
+    for (int q = 0; q < SCORE_ROUNDS; ++q) {
+        if (q * 64 < c) {
+            const int i = q * 64 + lane;
+            const bool in = i >= k && i < c;
+            unsigned long long m = __ballot(in && gt(l[q], tv));
+            while (m) {
+                const int j = __ffsll(static_cast<long long>(m)) - 1;
+                const float v = readlane_f(l[q], j);
+                const int e = q * 64 + j;
+                if (k == 1 || gt(ov, v)) { top = e; tv = v; }
+                else { top = oth; tv = ov; oth = e; ov = v; }   // pop_heap: newcomer and the old `other` re-form the heap
+                m = __ballot(in && lane > j && gt(l[q], tv));
+            }
+        }
+    }
+    if (k == 1) { s0 = top; s1 = -1; }
+    else { s0 = oth; s1 = top; }   // sort_heap moves the top to the back
+}
+
+// HALF: the planes hold IEEE halfs and a pair is scored in packed half arithmetic (term_h), two accumulators for the
+// even and the odd groups of eight channels.  sel != null: the picks of every slot that std::partial_sort would
+// serve (k*64 <= c) are made here and k_topk_select is left with the other slots.
+template <int T, bool HALF>
 __global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, const int* __restrict__ order,
                                                      const int* __restrict__ rank, const int* __restrict__ cnt,
-                                                     const int* __restrict__ cand, const float* __restrict__ A,
-                                                     const float* __restrict__ B, const float* __restrict__ w2,
-                                                     const float* __restrict__ b2, float* __restrict__ logits,
-                                                     GenSet gs) {
+                                                     const int* __restrict__ want, const int* __restrict__ cand,
+                                                     const void* __restrict__ Av, const void* __restrict__ Bv_,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ logits, int* __restrict__ sel, GenSet gs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LD = HALF ? SCORE_LD_H * 2 : SCORE_LD * 4;   // bytes per tile row
+    constexpr int ROWB = HALF ? H * 2 : H * 4;                 // bytes per plane row
+    constexpr int LPR = ROWB / 16;                             // lanes that copy one row
     {
         const long long g = blockIdx.y;
-        order += g * gs.node; rank += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
-        A += g * gs.proj * H; B += g * gs.proj * H; logits += g * (long long)n * K;
+        order += g * gs.node; rank += g * gs.node; cnt += g * gs.node; want += g * gs.node; cand += g * gs.cand;
+        logits += g * (long long)n * K;
+        if (sel) sel += g * 2ll * n;
     }
-    float* tile = reinterpret_cast<float*>(smem);                     // [K + T][SCORE_LD]
-    int* ids = reinterpret_cast<int*>(tile + (size_t)(K + T) * SCORE_LD);   // [K] ascending ids of slot r0
+    const unsigned char* A = static_cast<const unsigned char*>(Av) + static_cast<size_t>(blockIdx.y) * gs.proj * ROWB;
+    const unsigned char* B = static_cast<const unsigned char*>(Bv_) + static_cast<size_t>(blockIdx.y) * gs.proj * ROWB;
+    unsigned char* tile = smem;                                              // [K + T] rows of LD bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = tid & 31, hw = tid >> 5;
+    const int l = tid % LPR, hw = tid / LPR;
     // base slot: the first slot of the block that is scored at all (a slot that is not a target has
     // cnt = 0 and no candidate list)
     __shared__ int s_base;
@@ -396,88 +484,200 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score_tiled(int n, int K, con
     const int r_end = min(n, (int)(blockIdx.x + 1) * T);
     const int c0 = cnt[r0];
     const size_t row00 = (size_t)r0 * K;
-    for (int i = tid; i < c0; i += SCORE_THREADS) ids[i] = cand[row00 + i];
     // rows: [0, c0) = candidates of slot r0, [K, K + T - 1) = nodes processed at r0 .. r0 + T - 2
-    for (int row = hw; row < K + T - 1; row += SCORE_THREADS / 32) {
+    for (int row = hw; row < K + T - 1; row += SCORE_THREADS / LPR) {
         int node = -1;
         if (row < c0) node = cand[row00 + row];
         else if (row >= K && r0 + row - K < r_end) node = order[r0 + row - K];
         if (node >= 0)
-            *reinterpret_cast<float4*>(tile + (size_t)row * SCORE_LD + 4 * l) =
-                reinterpret_cast<const float4*>(A + (size_t)node * H)[l];
+            *reinterpret_cast<uint4*>(tile + (size_t)row * LD + 16 * l) =
+                reinterpret_cast<const uint4*>(A + (size_t)node * ROWB)[l];
+    }
+    // the second layer's weights: f32 through uniform loads, or rounded to half once and kept in registers
+    const float4* W = reinterpret_cast<const float4*>(w2);
+    uint4 wh[HALF ? H / 8 : 1];
+    if (HALF) {
+#pragma unroll
+        for (int j = 0; j < H / 8; ++j) {
+            const float4 z0 = W[2 * j], z1 = W[2 * j + 1];
+            wh[j] = make_uint4(pack_h(z0.x, z0.y), pack_h(z0.z, z0.w), pack_h(z1.x, z1.y), pack_h(z1.z, z1.w));
+        }
     }
     __syncthreads();
-    const float4* W = reinterpret_cast<const float4*>(w2);
     const float bias = b2[0];
     for (int r = r0 + wave; r < r_end; r += SCORE_THREADS / 64) {
         const int c = cnt[r];
         if (c <= 0) continue;
         const int v = __builtin_amdgcn_readfirstlane(order[r]);
-        const float4* Bv = reinterpret_cast<const float4*>(B + (size_t)v * H);
+        const unsigned char* Brow = B + (size_t)v * ROWB;
         const size_t row0 = (size_t)r * K;
-        for (int base = 0; base < c; base += 64) {
-            const int i = base + lane;
-            const bool active = i < c;
-            const int ci = cand[row0 + (active ? i : 0)];
-            const int rk = rank[ci];
-            int row;
-            if (rk >= r0) {
-                row = K + rk - r0;
-            } else {  // first position of the slot-r0 list holding ci
-                int lo = 0, hi = c0;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (ids[mid] < ci) lo = mid + 1; else hi = mid;
-                }
-                row = lo;
+        // Where a candidate's row sits in the tile.  The list of a slot holds the largest ids among the nodes
+        // processed before it (gen_plan.hip), ascending: of slot r0's list a SUFFIX is still there (a newcomer pushes
+        // out the smallest id), in the same order, and the nodes processed since r0 sit between its entries.  So the
+        // j-th entry of this slot's list that was processed before r0 is entry (c0 - olds) + j of slot r0's list, with
+        // `olds` such entries in all; an entry processed at rank >= r0 sits at row K + rank - r0.
+        int rowq[SCORE_ROUNDS];
+        {
+            int rk[SCORE_ROUNDS];
+#pragma unroll
+            for (int q = 0; q < SCORE_ROUNDS; ++q) {
+                const int i = q * 64 + lane;
+                rk[q] = -1;
+                if (q * 64 < c) rk[q] = rank[cand[row0 + (i < c ? i : 0)]];
             }
-            const float4* Ar = reinterpret_cast<const float4*>(tile + (size_t)row * SCORE_LD);
-            float acc = 0.f;
+            int before[SCORE_ROUNDS], olds = 0;
+#pragma unroll
+            for (int q = 0; q < SCORE_ROUNDS; ++q) {
+                const unsigned long long m = __ballot(q * 64 + lane < c && rk[q] < r0);
+                before[q] = olds + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                olds += __popcll(m);
+            }
+#pragma unroll
+            for (int q = 0; q < SCORE_ROUNDS; ++q) {
+                const bool active = q * 64 + lane < c;
+                rowq[q] = !active ? 0 : (rk[q] >= r0 ? K + rk[q] - r0 : c0 - olds + before[q]);
+            }
+        }
+        float lg[SCORE_ROUNDS];
+#pragma unroll
+        for (int q = 0; q < SCORE_ROUNDS; ++q) {
+            lg[q] = 0.f;
+            if (q * 64 < c) {
+                const int i = q * 64 + lane;
+                const bool active = i < c;
+                const int row = rowq[q];
+                float acc = 0.f;
+                if (HALF) {
+                    const uint4* Ar = reinterpret_cast<const uint4*>(tile + (size_t)row * LD);
+                    const uint4* Bq = reinterpret_cast<const uint4*>(Brow);
+                    float acc1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < H / 8; j += 2) {
+                        const uint4 a0 = Ar[j], a1 = Ar[j + 1], b0 = Bq[j], b1 = Bq[j + 1];
+                        acc = term_h(a0.x, b0.x, wh[j].x, acc);
+                        acc1 = term_h(a1.x, b1.x, wh[j + 1].x, acc1);
+                        acc = term_h(a0.y, b0.y, wh[j].y, acc);
+                        acc1 = term_h(a1.y, b1.y, wh[j + 1].y, acc1);
+                        acc = term_h(a0.z, b0.z, wh[j].z, acc);
+                        acc1 = term_h(a1.z, b1.z, wh[j + 1].z, acc1);
+                        acc = term_h(a0.w, b0.w, wh[j].w, acc);
+                        acc1 = term_h(a1.w, b1.w, wh[j + 1].w, acc1);
+                    }
+                    acc += acc1;
+                } else {
+                    const float4* Ar = reinterpret_cast<const float4*>(tile + (size_t)row * LD);
+                    const float4* Bq = reinterpret_cast<const float4*>(Brow);
 #pragma unroll 8
-            for (int j = 0; j < H / 4; ++j) {
-                float4 a = Ar[j], b = Bv[j], w = W[j];
-                acc = fmaf(fmaxf(a.x + b.x, 0.f), w.x, acc);
-                acc = fmaf(fmaxf(a.y + b.y, 0.f), w.y, acc);
-                acc = fmaf(fmaxf(a.z + b.z, 0.f), w.z, acc);
-                acc = fmaf(fmaxf(a.w + b.w, 0.f), w.w, acc);
+                    for (int j = 0; j < H / 4; ++j) {
+                        float4 a = Ar[j], b = Bq[j], w = W[j];
+                        acc = fmaf(fmaxf(a.x + b.x, 0.f), w.x, acc);
+                        acc = fmaf(fmaxf(a.y + b.y, 0.f), w.y, acc);
+                        acc = fmaf(fmaxf(a.z + b.z, 0.f), w.z, acc);
+                        acc = fmaf(fmaxf(a.w + b.w, 0.f), w.w, acc);
+                    }
+                }
+                lg[q] = acc + bias;
+                if (active) logits[row0 + i] = lg[q];
             }
-            if (active) logits[row0 + i] = acc + bias;
+        }
+        if (sel) {
+            const int k = min(want[r], c);
+            if (k > 0 && k * 64 <= c) {
+                int s0, s1;
+                wave_partial_sort(lg, c, k, lane, s0, s1);
+                if (lane == 0) *reinterpret_cast<int2*>(sel + 2 * (size_t)r) = make_int2(s0, s1);
+            }
         }
     }
 }
 
-int launch_score(hipStream_t s, int B, int n, int K, const int* order, const int* rank, const int* cnt, const int* cand,
-                 const float* projA, const float* projB, const float* w2, const float* b2, float* logits,
-                 const GenSet& gs) {
-    if (K <= SCORE_K_TILED) {
-        const int T = K <= 128 ? SCORE_T : SCORE_T_WIDE;
-        const size_t lds = (size_t)(K + T) * SCORE_LD * sizeof(float) + (size_t)K * sizeof(int);
-        const unsigned tb = (unsigned)((n + T - 1) / T);
-        if (K <= 128) {
-            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T>), lds));
-            hipLaunchKernelGGL(k_score_tiled<SCORE_T>, dim3(tb, B), dim3(SCORE_THREADS), lds, s, n, K, order, rank, cnt,
-                               cand, projA, projB, w2, b2, logits, gs);
-        } else {
-            AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<SCORE_T_WIDE>), lds));
-            hipLaunchKernelGGL(k_score_tiled<SCORE_T_WIDE>, dim3(tb, B), dim3(SCORE_THREADS), lds, s, n, K, order, rank,
-                               cnt, cand, projA, projB, w2, b2, logits, gs);
+// half planes with a window the tile does not hold: one wave per slot, candidate rows gathered from memory
+__global__ __launch_bounds__(256) void k_score_h(int n, int K, const int* __restrict__ order, const int* __restrict__ cnt,
+                                                 const int* __restrict__ cand, const _Float16* __restrict__ A,
+                                                 const _Float16* __restrict__ B, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* __restrict__ logits, GenSet gs) {
+    const int lane = threadIdx.x & 63;
+    int r = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (r >= n) return;
+    {
+        const long long g = blockIdx.y;
+        order += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
+        A += g * gs.proj * H; B += g * gs.proj * H; logits += g * (long long)n * K;
+    }
+    const int c = cnt[r];
+    if (c <= 0) return;
+    const int v = __builtin_amdgcn_readfirstlane(order[r]);
+    const uint4* Bq = reinterpret_cast<const uint4*>(B + static_cast<size_t>(v) * H);
+    const float4* W = reinterpret_cast<const float4*>(w2);
+    const float bias = b2[0];
+    const size_t row0 = static_cast<size_t>(r) * K;
+    for (int base = 0; base < c; base += 64) {
+        const int i = base + lane;
+        const bool active = i < c;
+        const int ci = cand[row0 + (active ? i : 0)];
+        const uint4* Ar = reinterpret_cast<const uint4*>(A + static_cast<size_t>(ci) * H);
+        float acc = 0.f, acc1 = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < H / 8; j += 2) {   // the order of k_score_tiled's half form: same bits
+            const uint4 a0 = Ar[j], a1 = Ar[j + 1], b0 = Bq[j], b1 = Bq[j + 1];
+            const float4 z0 = W[2 * j], z1 = W[2 * j + 1], z2 = W[2 * j + 2], z3 = W[2 * j + 3];
+            acc = term_h(a0.x, b0.x, pack_h(z0.x, z0.y), acc);
+            acc1 = term_h(a1.x, b1.x, pack_h(z2.x, z2.y), acc1);
+            acc = term_h(a0.y, b0.y, pack_h(z0.z, z0.w), acc);
+            acc1 = term_h(a1.y, b1.y, pack_h(z2.z, z2.w), acc1);
+            acc = term_h(a0.z, b0.z, pack_h(z1.x, z1.y), acc);
+            acc1 = term_h(a1.z, b1.z, pack_h(z3.x, z3.y), acc1);
+            acc = term_h(a0.w, b0.w, pack_h(z1.z, z1.w), acc);
+            acc1 = term_h(a1.w, b1.w, pack_h(z3.z, z3.w), acc1);
         }
-        AIG_LAUNCH_CHECK();
-        return AIG_OK;
+        if (active) logits[row0 + i] = acc + acc1 + bias;
+    }
+}
+
+template <int T, bool HALF>
+int launch_score_tiled(hipStream_t s, int B, int n, int K, const int* order, const int* rank, const int* cnt,
+                       const int* want, const int* cand, const void* projA, const void* projB, const float* w2,
+                       const float* b2, float* logits, int* sel, const GenSet& gs) {
+    const size_t lds = (size_t)(K + T) * (HALF ? SCORE_LD_H * 2 : SCORE_LD * 4);
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_score_tiled<T, HALF>), lds));
+    hipLaunchKernelGGL((k_score_tiled<T, HALF>), dim3((unsigned)((n + T - 1) / T), B), dim3(SCORE_THREADS), lds, s, n, K,
+                       order, rank, cnt, want, cand, projA, projB, w2, b2, logits, sel, gs);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
+// Scores of B graphs.  half: the planes hold IEEE halfs.  sel and want given: slots that std::partial_sort would serve
+// get their picks here, and *fused says so (then launch_select leaves those slots alone).
+int launch_score(hipStream_t s, int B, int n, int K, const int* order, const int* rank, const int* cnt, const int* want,
+                 const int* cand, const void* projA, const void* projB, bool half, const float* w2, const float* b2,
+                 float* logits, int* sel, bool* fused, const GenSet& gs) {
+    if (fused) *fused = false;
+    if (K <= SCORE_K_TILED) {
+        if (!want) sel = nullptr;
+        if (fused) *fused = sel != nullptr;
+        if (half)   // rows of halfs: 64 slots per tile at every window
+            return launch_score_tiled<SCORE_T, true>(s, B, n, K, order, rank, cnt, want, cand, projA, projB, w2, b2, logits, sel, gs);
+        if (K <= 128) return launch_score_tiled<SCORE_T, false>(s, B, n, K, order, rank, cnt, want, cand, projA, projB, w2, b2, logits, sel, gs);
+        return launch_score_tiled<SCORE_T_WIDE, false>(s, B, n, K, order, rank, cnt, want, cand, projA, projB, w2, b2, logits, sel, gs);
     }
     const unsigned blocks = (unsigned)(((int64_t)n * 64 + 255) / 256);
-    hipLaunchKernelGGL(k_score, dim3(blocks, B), dim3(256), 0, s, n, K, order, cnt, cand, projA, projB, w2, b2, logits, gs);
+    if (half)
+        hipLaunchKernelGGL(k_score_h, dim3(blocks, B), dim3(256), 0, s, n, K, order, cnt, cand,
+                           static_cast<const _Float16*>(projA), static_cast<const _Float16*>(projB), w2, b2, logits, gs);
+    else
+        hipLaunchKernelGGL(k_score, dim3(blocks, B), dim3(256), 0, s, n, K, order, cnt, cand,
+                           static_cast<const float*>(projA), static_cast<const float*>(projB), w2, b2, logits, gs);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
 
 int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, const int* cnt, const int* want, int* sel,
-                  const GenSet& gs) {
+                  bool fused, const GenSet& gs) {
     AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select), (size_t)(SEL_LDS)));
     const unsigned blocks = (unsigned)((rows + SEL_THREADS - 1) / SEL_THREADS);
     const int cap = ld < SEL_CAP ? ld : SEL_CAP;
     hipLaunchKernelGGL(k_topk_select, dim3(blocks, B), dim3(SEL_THREADS), sel_lds(cap), s, rows, ld, cap, logits, cnt,
-                       want, sel, gs);
+                       want, sel, fused ? 1 : 0, gs);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -487,14 +687,51 @@ int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, c
 
 using namespace aig;
 
+namespace {
+int gen_score(const char* who, int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt,
+              const int32_t* cand, const void* projA, const void* projB, bool half, const float* w2, const float* b2,
+              float* logits, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1, "%s: bad sizes n=%lld K=%lld", who, (long long)n, (long long)K);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(order && rank && cnt && cand && projA && projB && w2 && b2 && logits, "%s: null pointer", who);
+    return launch_score(static_cast<hipStream_t>(stream), 1, (int)n, (int)K, order, rank, cnt, nullptr, cand, projA, projB,
+                        half, w2, b2, logits, nullptr, nullptr, GenSet{});
+}
+
+int gen_emit(const char* who, bool half, int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order,
+             const int32_t* want, const int32_t* cnt, const int32_t* cand, const int32_t* fb, const int32_t* eoff,
+             const int32_t* sel, const void* projA2, const void* projB2, const float* w2a, const float* b2a,
+             int64_t* edge_index, int64_t* edge_attr, float* x_out, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1 && E >= 0, "%s: bad sizes", who);
+    if (n == 0) return AIG_OK;
+    AIG_REQUIRE(x && order && want && cnt && cand && fb && eoff && sel && projA2 && projB2 && w2a && b2a && x_out,
+                "%s: null pointer", who);
+    AIG_REQUIRE(E == 0 || (edge_index && edge_attr), "%s: null edge output", who);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    long long* ei = reinterpret_cast<long long*>(edge_index);
+    long long* ea = reinterpret_cast<long long*>(edge_attr);
+    if (half)
+        hipLaunchKernelGGL(k_emit<true>, grid, dim3(256), 0, s, (int)n, (int)K, (long long)E, x, order, want, cnt, cand, fb,
+                           eoff, sel, projA2, projB2, w2a, b2a, ei, ea, x_out, GenSet{}, nullptr);
+    else
+        hipLaunchKernelGGL(k_emit<false>, grid, dim3(256), 0, s, (int)n, (int)K, (long long)E, x, order, want, cnt, cand, fb,
+                           eoff, sel, projA2, projB2, w2a, b2a, ei, ea, x_out, GenSet{}, nullptr);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+}  // namespace
+
 extern "C" int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt,
                              const int32_t* cand, const float* projA, const float* projB, const float* w2,
                              const float* b2, float* logits, void* stream) {
-    AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1, "aig_gen_score: bad sizes n=%lld K=%lld", (long long)n, (long long)K);
-    if (n == 0) return AIG_OK;
-    AIG_REQUIRE(order && rank && cnt && cand && projA && projB && w2 && b2 && logits, "aig_gen_score: null pointer");
-    return launch_score(static_cast<hipStream_t>(stream), 1, (int)n, (int)K, order, rank, cnt, cand, projA, projB, w2, b2,
-                        logits, GenSet{});
+    return gen_score("aig_gen_score", n, K, order, rank, cnt, cand, projA, projB, false, w2, b2, logits, stream);
+}
+
+extern "C" int aig_gen_score_half(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt,
+                                  const int32_t* cand, const void* projA, const void* projB, const float* w2,
+                                  const float* b2, float* logits, void* stream) {
+    return gen_score("aig_gen_score_half", n, K, order, rank, cnt, cand, projA, projB, true, w2, b2, logits, stream);
 }
 
 extern "C" size_t aig_topk_select_ws_bytes(int64_t, int64_t) { return 256; }
@@ -505,7 +742,7 @@ extern "C" int aig_topk_select(int64_t rows, int64_t ld, const float* logits, co
                 (long long)rows, (long long)ld);
     if (rows == 0) return AIG_OK;
     AIG_REQUIRE(logits && cnt && want && sel, "aig_topk_select: null pointer");
-    return launch_select(static_cast<hipStream_t>(stream), 1, (int)rows, (int)ld, logits, cnt, want, sel, GenSet{});
+    return launch_select(static_cast<hipStream_t>(stream), 1, (int)rows, (int)ld, logits, cnt, want, sel, false, GenSet{});
 }
 
 extern "C" int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order,
@@ -513,18 +750,17 @@ extern "C" int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, con
                             const int32_t* eoff, const int32_t* sel, const float* projA2, const float* projB2,
                             const float* w2a, const float* b2a, int64_t* edge_index, int64_t* edge_attr,
                             float* x_out, void* stream) {
-    AIG_REQUIRE(n >= 0 && n < INT_MAX && K >= 1 && E >= 0, "aig_gen_emit: bad sizes");
-    if (n == 0) return AIG_OK;
-    AIG_REQUIRE(x && order && want && cnt && cand && fb && eoff && sel && projA2 && projB2 && w2a && b2a && x_out,
-                "aig_gen_emit: null pointer");
-    AIG_REQUIRE(E == 0 || (edge_index && edge_attr), "aig_gen_emit: null edge output");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int)n, (int)K, (long long)E, x,
-                       order, want, cnt, cand, fb, eoff, sel, projA2, projB2, w2a, b2a,
-                       reinterpret_cast<long long*>(edge_index), reinterpret_cast<long long*>(edge_attr), x_out, GenSet{},
-                       nullptr);
-    AIG_LAUNCH_CHECK();
-    return AIG_OK;
+    return gen_emit("aig_gen_emit", false, n, K, E, x, order, want, cnt, cand, fb, eoff, sel, projA2, projB2, w2a, b2a,
+                    edge_index, edge_attr, x_out, stream);
+}
+
+extern "C" int aig_gen_emit_half(int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order,
+                                 const int32_t* want, const int32_t* cnt, const int32_t* cand, const int32_t* fb,
+                                 const int32_t* eoff, const int32_t* sel, const void* projA2, const void* projB2,
+                                 const float* w2a, const float* b2a, int64_t* edge_index, int64_t* edge_attr,
+                                 float* x_out, void* stream) {
+    return gen_emit("aig_gen_emit_half", true, n, K, E, x, order, want, cnt, cand, fb, eoff, sel, projA2, projB2, w2a, b2a,
+                    edge_index, edge_attr, x_out, stream);
 }
 
 extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
@@ -544,15 +780,25 @@ extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
     if (!a->plan_shared) { gs.node = n; gs.eoff = n + 1; gs.cand = (long long)n * K; }
     gs.x = a->x_shared ? 0 : 2ll * n;
     gs.proj = a->proj_rows;
-    const size_t plane = (size_t)a->B * a->proj_rows * H;
-    int rc = launch_score(s, B, n, K, a->order, a->rank, a->cnt, a->cand, a->proj, a->proj + plane, a->sc2_w, a->sc2_b,
-                          a->logits, gs);
+    const bool half = a->proj_half != 0;
+    const size_t plane = (size_t)a->B * a->proj_rows * H * (half ? 2 : 4);   // bytes
+    const unsigned char* proj = static_cast<const unsigned char*>(a->proj);
+    bool fused = false;
+    int rc = launch_score(s, B, n, K, a->order, a->rank, a->cnt, a->want, a->cand, proj, proj + plane, half, a->sc2_w,
+                          a->sc2_b, a->logits, a->sel, &fused, gs);
     if (rc) return rc;
-    if ((rc = launch_select(s, B, n, K, a->logits, a->cnt, a->want, a->sel, gs))) return rc;
-    hipLaunchKernelGGL(k_emit, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, n, K, (long long)a->ecap, a->x,
-                       a->order, a->want, a->cnt, a->cand, a->fb, a->eoff, a->sel, a->proj + 2 * plane,
-                       a->proj + 3 * plane, a->at2_w, a->at2_b, reinterpret_cast<long long*>(a->edge_index),
-                       reinterpret_cast<long long*>(a->edge_attr), a->x_out, gs, a->ecount);
+    if ((rc = launch_select(s, B, n, K, a->logits, a->cnt, a->want, a->sel, fused, gs))) return rc;
+    const dim3 grid((unsigned)((n + 255) / 256), B);
+    long long* ei = reinterpret_cast<long long*>(a->edge_index);
+    long long* ea = reinterpret_cast<long long*>(a->edge_attr);
+    if (half)
+        hipLaunchKernelGGL(k_emit<true>, grid, dim3(256), 0, s, n, K, (long long)a->ecap, a->x, a->order, a->want, a->cnt,
+                           a->cand, a->fb, a->eoff, a->sel, proj + 2 * plane, proj + 3 * plane, a->at2_w, a->at2_b, ei, ea,
+                           a->x_out, gs, a->ecount);
+    else
+        hipLaunchKernelGGL(k_emit<false>, grid, dim3(256), 0, s, n, K, (long long)a->ecap, a->x, a->order, a->want, a->cnt,
+                           a->cand, a->fb, a->eoff, a->sel, proj + 2 * plane, proj + 3 * plane, a->at2_w, a->at2_b, ei, ea,
+                           a->x_out, gs, a->ecount);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

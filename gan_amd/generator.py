@@ -80,7 +80,8 @@ class AIGGenerator(nn.Module):
         super().__init__()
         if score_dtype not in ("fp32", "bf16"):
             raise ValueError("score_dtype is 'fp32' (the reference's arithmetic) or 'bf16'")
-        # "bf16": the node projections behind the scores run on the bf16 matrix cores with f32 accumulation
+        # "bf16": the node projections behind the scores run on the bf16 matrix cores with f32 accumulation, their
+        # planes are stored as IEEE halfs and the pairs are scored in packed half arithmetic
         # (an extension for bulk sampling; candidate windows, tie handling and assembly are unchanged)
         self.score_dtype = score_dtype
         self.hidden_dim = hidden_dim
@@ -170,7 +171,7 @@ class AIGGenerator(nn.Module):
         K, E = plan.K, plan.E
         st = _abi.stream()
         n64 = (n + 63) // 64 * 64
-        proj = torch.empty((4, S * n64, 128), dtype=torch.float32, device=dev)
+        proj = torch.empty((4, S * n64, 128), dtype=torch.float16, device=dev)
         ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(S), dev)
         w = self._weights()
         _abi.check(_abi.timed("aig_gen_node_proj_bf16", lib.aig_gen_node_proj_bf16, n, S, _abi.ptr(x_in), _abi.ptr(zs),
@@ -253,7 +254,7 @@ class AIGGenerator(nn.Module):
         bf16 = 1 if self.score_dtype == "bf16" else 0
         stream = _abi.stream()
         rows = int(lib.aig_gen_batch_rows(n))
-        proj = torch.empty((4, B * rows, 128), dtype=torch.float32, device=dev)
+        proj = torch.empty((4, B * rows, 128), dtype=torch.float16 if bf16 else torch.float32, device=dev)
         ws = _abi.workspace(lib.aig_gen_node_proj_batch_ws_bytes(B, n, bf16), dev)
         w = self._weights()
         _abi.check(_abi.timed("aig_gen_node_proj_batch", lib.aig_gen_node_proj_batch, B, n, _abi.ptr(x_all), int(shared),
@@ -265,7 +266,7 @@ class AIGGenerator(nn.Module):
         a.x = _abi.ptr(x_all)
         for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
             setattr(a, name, _abi.ptr(arrays[name]))
-        a.proj, a.proj_rows = _abi.ptr(proj), rows
+        a.proj, a.proj_rows, a.proj_half = _abi.ptr(proj), rows, bf16
         a.sc2_w, a.sc2_b = _abi.ptr(self.edge_scorer[2].weight), _abi.ptr(self.edge_scorer[2].bias)
         a.at2_w, a.at2_b = _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias)
         logits = torch.empty((B, n, K), dtype=torch.float32, device=dev)
@@ -283,27 +284,30 @@ class AIGGenerator(nn.Module):
         return out
 
     def _wire(self, plan, x_in, x_src, nd, pa, pb, pa2, pb2, n, K, E, dev, debug=None) -> Data:
-        """Scores, tie-exact selection and edge assembly from the four projection planes (generator.py:139-209)."""
+        """Scores, tie-exact selection and edge assembly from the four projection planes (generator.py:139-209);
+        planes of halfs (the bf16 pipeline's) take the packed-half forms of the two entry points that read them."""
         lib = _abi.lib()
         st = _abi.stream()
+        half = pa.dtype == torch.float16
+        score_name, emit_name = ("aig_gen_score_half", "aig_gen_emit_half") if half else ("aig_gen_score", "aig_gen_emit")
         logits = torch.empty((max(n, 1), K), dtype=torch.float32, device=dev)
         if debug is not None:
             logits.fill_(float("nan"))
-        _abi.check(_abi.timed("aig_gen_score", lib.aig_gen_score, n, K, _abi.ptr(plan.order), _abi.ptr(plan.rank), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
+        _abi.check(_abi.timed(score_name, getattr(lib, score_name), n, K, _abi.ptr(plan.order), _abi.ptr(plan.rank), _abi.ptr(plan.cnt), _abi.ptr(plan.cand),
                                      _abi.ptr(pa), _abi.ptr(pb), _abi.ptr(self.edge_scorer[2].weight),
-                                     _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), "aig_gen_score")
+                                     _abi.ptr(self.edge_scorer[2].bias), _abi.ptr(logits), st), score_name)
         sel = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dev)
         _abi.check(_abi.timed("aig_topk_select", lib.aig_topk_select, n, K, _abi.ptr(logits), _abi.ptr(plan.cnt), _abi.ptr(plan.want),
                                        _abi.ptr(sel), None, 0, st), "aig_topk_select")
         edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
         edge_attr = torch.empty((E, 1), dtype=torch.int64, device=dev)
         x_out = torch.empty((n, 2), dtype=torch.float32, device=dev)
-        _abi.check(_abi.timed("aig_gen_emit", lib.aig_gen_emit, n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
+        _abi.check(_abi.timed(emit_name, getattr(lib, emit_name), n, K, E, _abi.ptr(x_in), _abi.ptr(plan.order), _abi.ptr(plan.want),
                                     _abi.ptr(plan.cnt), _abi.ptr(plan.cand), _abi.ptr(plan.fb), _abi.ptr(plan.eoff),
                                     _abi.ptr(sel), _abi.ptr(pa2), _abi.ptr(pb2),
                                     _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias),
                                     _abi.ptr(edge_index) if E else None, _abi.ptr(edge_attr) if E else None,
-                                    _abi.ptr(x_out), st), "aig_gen_emit")
+                                    _abi.ptr(x_out), st), emit_name)
         if x_src.dtype != torch.float32:
             x_out = x_out.to(x_src.dtype)
         out = Data(x=x_out, edge_index=edge_index, edge_attr=edge_attr,
@@ -332,7 +336,8 @@ class AIGGenerator(nn.Module):
         st = _abi.stream()
         f32 = dict(dtype=torch.float32, device=dev)
 
-        proj = torch.empty((4, max(n, 1), 128), **f32)
+        proj = torch.empty((4, max(n, 1), 128), dtype=torch.float16 if self.score_dtype == "bf16" else torch.float32,
+                           device=dev)
         h_cond = torch.empty((max(n, 1), 128), **f32) if return_debug else None
         w = self._weights()
         if self.score_dtype == "bf16":

@@ -25,7 +25,7 @@ from .data import Data
 
 class GraphSet:
     __slots__ = ("B", "n", "ecap", "x", "edge_index", "edge_attr", "count", "node_depth", "_counts_host", "x_dtype",
-                 "order_hint")
+                 "order_hint", "_views")
 
     def __init__(self, B: int, n: int, ecap: int, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor,
                  count: Optional[torch.Tensor], node_depth: Optional[torch.Tensor] = None,
@@ -38,6 +38,7 @@ class GraphSet:
         # earlier to later nodes - the generator leaves its processing rank here; the penalties use it as a
         # (device-checked) shortcut for their reachability term
         self.order_hint = None
+        self._views = None
 
     # ------------------------------------------------------------------ host side of the counts
     def counts(self) -> List[int]:
@@ -56,11 +57,14 @@ class GraphSet:
         the set's tensors instead of tensors of its own (``edge_index`` is then a strided ``[2, E]`` view)."""
         m = self.counts()[g]
         n = self.n
-        x = self.x[g * n:(g + 1) * n]
-        nd = self.node_depth
-        if nd is not None and nd.numel() != n:
-            nd = nd[g * n:(g + 1) * n]
-        ei, ea = self.edge_index[g, :, :m], self.edge_attr[g, :m].reshape(-1, 1)
+        if self._views is None:      # per-graph views of the node and slot arrays, cut once for the whole set
+            nd = self.node_depth
+            self._views = (self.x.view(self.B, n, -1).unbind(0), self.edge_index.unbind(0), self.edge_attr.unbind(0),
+                           None if nd is None or nd.numel() == n else nd.view(self.B, n).unbind(0))
+        xs, eis, eas, nds = self._views
+        x = xs[g]
+        nd = self.node_depth if nds is None else nds[g]
+        ei, ea = eis[g].narrow(1, 0, m), eas[g].narrow(0, 0, m).unsqueeze(1)
         if copy:
             x, ei, ea = x.clone(), ei.contiguous(), ea.clone()
             nd = None if nd is None else nd.clone()

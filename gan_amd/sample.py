@@ -96,37 +96,70 @@ def block_size(n: int, batch: int) -> int:
     return max(1, min(int(batch), SET_NODES // max(int(n), 1)))
 
 
-def sample_sets(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 2) -> Iterator[GraphSet]:
+_SET_STREAMS: dict = {}
+
+
+def _set_streams(device: torch.device, count: int) -> List[torch.cuda.Stream]:
+    """The streams blocks alternate over, kept per device: the allocator keeps a pool per stream, and a fresh stream
+    per call would have every call start from an empty pool (a block's scratch is a few hundred megabytes)."""
+    have = _SET_STREAMS.setdefault(device.index, [])
+    while len(have) < count:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:count]
+
+
+def sample_sets(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 3) -> Iterator[GraphSet]:
     """Bulk sampling from ONE template: every element of ``z_batches`` is a ``[S, z_dim]`` block of draws that
     goes through generator, repair and resync as one set of graphs (``AIGGenerator.forward_set``,
     ``repair_and_resync_set``): about forty launches per block whatever its size, and one host read (the
     repaired edge counts) that is only awaited once ``in_flight - 1`` younger blocks have been enqueued.
-    Yields one ``GraphSet`` per block; its graph ``i`` equals ``sample_one(G, tpl, zs[i])``."""
+    Block ``i`` runs on stream ``i % in_flight`` (``in_flight`` 1: the caller's stream): the narrow kernels of one
+    block's repair and selection run beside the wide scoring kernels of the next.  Blocks are independent, so the
+    results do not depend on ``in_flight``.  Yields one ``GraphSet`` per block, in block order, which the caller's
+    stream has been made to wait for; its graph ``i`` equals ``sample_one(G, tpl, zs[i])``."""
     if in_flight < 1:
         raise ValueError("in_flight must be at least 1")
+    cur = torch.cuda.current_stream()
+    streams = _set_streams(cur.device, in_flight) if in_flight > 1 else [cur]
     pending: deque = deque()
+    if len(streams) > 1 and tpl.x.is_cuda and tpl.x.dtype == torch.float32 and tpl.x.is_contiguous():
+        # the template's plan is shared by all blocks: built here, on the caller's stream, which every block's stream
+        # waits for (built inside the first block it would be read by the second without any ordering)
+        nd = getattr(tpl, "node_depth", None)
+        with torch.no_grad():
+            G.plan_for(tpl, tpl.x, nd.to(tpl.x.device) if nd is not None else None)
 
     def finish() -> GraphSet:
-        gset, counts_host, ready = pending.popleft()
+        gset, counts_host, ready, st = pending.popleft()
         ready.synchronize()
         gset._counts_host = [int(c) for c in counts_host.tolist()]
+        if st is not cur:
+            cur.wait_stream(st)
+            for v in (getattr(gset, name, None) for name in type(gset).__slots__):   # allocated under st, used by the caller's stream from here on
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
         return gset
 
-    for zs in z_batches:
-        with torch.no_grad():
+    for i, zs in enumerate(z_batches):
+        st = streams[i % len(streams)]
+        if st is not cur:
+            st.wait_stream(cur)                # the draws (and the template) come from the caller's stream
+        with torch.cuda.stream(st), torch.no_grad():
             gset = repair_and_resync_set(G.forward_set(tpl, zs))
-        counts_host = torch.empty(gset.B, dtype=torch.int32, pin_memory=True)
-        counts_host.copy_(gset.count, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
-        pending.append((gset, counts_host, ready))
+            counts_host = torch.empty(gset.B, dtype=torch.int32, pin_memory=True)
+            counts_host.copy_(gset.count, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+        if st is not cur and torch.is_tensor(zs) and zs.is_cuda:
+            zs.record_stream(st)
+        pending.append((gset, counts_host, ready, st))
         if len(pending) >= in_flight:
             yield finish()
     while pending:
         yield finish()
 
 
-def sample_bulk(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 2) -> Iterator[Data]:
+def sample_bulk(G: AIGGenerator, tpl: Data, z_batches: Iterable[torch.Tensor], in_flight: int = 3) -> Iterator[Data]:
     """``sample_sets`` handed out graph by graph, in draw order: the same tensors ``sample_one(G, tpl, z)``
     returns for every z, as views of the block's tensors."""
     for gset in sample_sets(G, tpl, z_batches, in_flight):

@@ -95,10 +95,12 @@ int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_w
                       float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream);
 
 /* The same node pipeline with the inputs of its seven 128x128 products - activations and weights - rounded to bf16
- * (round to nearest even) and multiplied on the bf16 matrix cores with f32 accumulation; biases, activations and the
- * stored outputs stay f32 (the reference computes in f32 throughout, models/generator.py:115-117,94-98: this is the
- * reduced-precision option of bulk sampling, off by default).  Results differ from aig_gen_node_proj by bf16 rounding
- * (about 2^-8 relative per product input); like it, a result depends on its own input row only, so equal rows give
+ * (round to nearest even) and multiplied on the bf16 matrix cores with f32 accumulation; biases and activations stay
+ * f32, h_cond is stored as f32 and the four planes of proj as IEEE halfs, clamped to +-32752 so that the sum of two
+ * entries stays finite (the reference computes in f32 throughout, models/generator.py:115-117,94-98: this is the
+ * reduced-precision option of bulk sampling, off by default; its planes are read by aig_gen_score_half and
+ * aig_gen_emit_half).  Results differ from aig_gen_node_proj by bf16 rounding (about 2^-8 relative per product
+ * input) and the 2^-11 of the stored halfs; like it, a result depends on its own input row only, so equal rows give
  * bit-equal outputs and candidates with equal features still tie exactly.
  *   samples > 1: `samples` draws of z for ONE template in one call - z [samples,128], x [n,2] shared, rows laid out
  *   sample after sample, each sample starting on a multiple of 64 rows: with n64 = n rounded up to a multiple of 64,
@@ -106,13 +108,20 @@ int aig_gen_node_proj(int64_t n, const float* x, const float* z, const aig_gen_w
  *   the next sample repeat its last row). */
 size_t aig_gen_node_proj_bf16_ws_bytes(int64_t samples);
 int aig_gen_node_proj_bf16(int64_t n, int64_t samples, const float* x, const float* z, const aig_gen_weights* w_host,
-                           float* h_cond, float* proj, void* ws, size_t ws_bytes, void* stream);
+                           float* h_cond, void* proj, void* ws, size_t ws_bytes, void* stream);
 
 /* Candidate scores - models/generator.py:84-99 (_score_candidates + edge_scorer):
  *   logits[r*K + i] = w2 . relu(projA[cand[r*K+i]] + projB[order[r]]) + b2,   i < cnt[r] */
 int aig_gen_score(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt, const int32_t* cand,
                   const float* projA, const float* projB, const float* w2, const float* b2,
                   float* logits, void* stream);
+/* The same scores from planes of IEEE halfs (aig_gen_node_proj_bf16), in packed half arithmetic: a sum
+ * projA[..][j] + projB[..][j] is rounded to half, w2 is rounded to half, the products are accumulated in f32 two
+ * channels at a time, channels ascending in two interleaved chains (groups of eight channels alternate between them).
+ * One fixed sequence per pair, so equal candidate rows give bit-equal logits here too. */
+int aig_gen_score_half(int64_t n, int64_t K, const int32_t* order, const int32_t* rank, const int32_t* cnt,
+                       const int32_t* cand, const void* projA, const void* projB, const float* w2, const float* b2,
+                       float* logits, void* stream);
 
 /* Tie-exact top-k - torch.topk(logits, k, largest=True, sorted=True) as called at
  * models/generator.py:162-168, i.e. ATen's CPU kernel (native/TopKImpl.h: partial_sort when
@@ -131,6 +140,11 @@ int aig_gen_emit(int64_t n, int64_t K, int64_t E, const float* x, const int32_t*
                  const int32_t* cnt, const int32_t* cand, const int32_t* fb, const int32_t* eoff,
                  const int32_t* sel, const float* projA2, const float* projB2, const float* w2a, const float* b2a,
                  int64_t* edge_index, int64_t* edge_attr, float* x_out, void* stream);
+/* ... with the inversion bit from planes of IEEE halfs, in the arithmetic of aig_gen_score_half (one chain) */
+int aig_gen_emit_half(int64_t n, int64_t K, int64_t E, const float* x, const int32_t* order, const int32_t* want,
+                      const int32_t* cnt, const int32_t* cand, const int32_t* fb, const int32_t* eoff,
+                      const int32_t* sel, const void* projA2, const void* projB2, const float* w2a, const float* b2a,
+                      int64_t* edge_index, int64_t* edge_attr, float* x_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Critic: graph attention layer (torch_geometric.nn.GATConv(in, 32, heads=4, edge_dim=1) as called at
@@ -474,15 +488,17 @@ const char* aig_kernel_timing_name(int kernel);
 
 /* Node projections (aig_gen_node_proj) of B graphs in one call: x holds 2n floats per graph, or one
  * template's when x_shared (then only z differs between the graphs); z [B][128]; bf16 != 0 takes the bf16
- * matrix-core pipeline of aig_gen_node_proj_bf16.  proj [4][B rows][128] with rows =
- * aig_gen_batch_rows(n) rows per graph (n rounded up to the 64-row tile; rows past n are unspecified). */
+ * matrix-core pipeline of aig_gen_node_proj_bf16, whose planes are IEEE halfs (f32 otherwise).  proj [4][B rows][128]
+ * with rows = aig_gen_batch_rows(n) rows per graph (n rounded up to the 64-row tile; rows past n are unspecified). */
 int64_t aig_gen_batch_rows(int64_t n);
 size_t aig_gen_node_proj_batch_ws_bytes(int64_t B, int64_t n, int bf16);
 int aig_gen_node_proj_batch(int64_t B, int64_t n, const float* x, int x_shared, const float* z,
-                            const aig_gen_weights* w, int bf16, float* proj, void* ws, size_t ws_bytes, void* stream);
+                            const aig_gen_weights* w, int bf16, void* proj, void* ws, size_t ws_bytes, void* stream);
 
 /* Scores, tie-exact selection and edge assembly (aig_gen_score, aig_topk_select, aig_gen_emit) of B graphs:
- * three launches for the set.  Plan arrays are [B][...] back to back, or one plan when plan_shared. */
+ * three launches for the set.  Plan arrays are [B][...] back to back, or one plan when plan_shared.  With windows of
+ * up to 256 candidates the wave that scores a slot also makes its picks when torch.topk would take its
+ * partial_sort path (k*64 <= cnt), same picks as aig_topk_select's. */
 typedef struct aig_gen_wire_set {
     int64_t B, n, K;
     int64_t ecap;             /* edge slots per graph in the outputs (>= every graph's eoff[n]) */
@@ -492,7 +508,7 @@ typedef struct aig_gen_wire_set {
     const int32_t *order, *rank, *want, *cnt, *fb;   /* [B][n] or [n] */
     const int32_t* eoff;      /* [B][n+1] or [n+1] */
     const int32_t* cand;      /* [B][n][K] or [n][K] */
-    const float* proj;        /* [4][B proj_rows][128] from aig_gen_node_proj_batch */
+    const void* proj;         /* [4][B proj_rows][128] from aig_gen_node_proj_batch: f32, or IEEE halfs (proj_half) */
     int64_t proj_rows;
     const float *sc2_w, *sc2_b, *at2_w, *at2_b;      /* edge_scorer.2 / edge_attr_pred.2 */
     float* logits;            /* scratch [B][n][K] */
@@ -501,6 +517,7 @@ typedef struct aig_gen_wire_set {
     int64_t* edge_attr;       /* out [B][ecap] */
     int32_t* ecount;          /* out [B] */
     float* x_out;             /* out [B n][2] */
+    int64_t proj_half;        /* 1: proj holds halfs (the bf16 pipeline's planes), scored as aig_gen_score_half does */
 } aig_gen_wire_set;
 int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream);
 

@@ -160,9 +160,10 @@ def generator_forward_canonical(state: Dict[str, torch.Tensor], x: torch.Tensor,
 def node_proj_bf16(state: Dict[str, torch.Tensor], x: torch.Tensor, z: torch.Tensor):
     """The node pipeline of the bf16 scoring option (an extension of this repository, no counterpart in the
     reference): activations and weights entering each of the seven 128x128 products rounded to bf16 (nearest
-    even), products summed exactly (float64 here; the matrix cores accumulate in f32), biases, ReLU and outputs
-    in f32.  -> (h_cond [n,128], proj [4,n,128]).  Checked to a tolerance, not bit for bit: the order in which
-    the hardware adds the sixteen products of an instruction is not documented."""
+    even), products summed exactly (float64 here; the matrix cores accumulate in f32), biases and ReLU in f32;
+    h_cond stays f32, the four planes are clamped to +-32752 and rounded to IEEE half (returned as the f32 values
+    of those halfs).  -> (h_cond [n,128], proj [4,n,128]).  Checked to a tolerance, not bit for bit: the order in
+    which the hardware adds the sixteen products of an instruction is not documented."""
     def bf(t):
         return t.to(torch.bfloat16).to(torch.float64)
 
@@ -183,7 +184,28 @@ def node_proj_bf16(state: Dict[str, torch.Tensor], x: torch.Tensor, z: torch.Ten
         zb = (w[:, 256:].double() @ z.double()).float() + b
         outs.append(lin(h_cond, w[:, :128], torch.zeros(128)))
         outs.append(lin(h_cond, w[:, 128:256], zb))
-    return h_cond, torch.stack(outs)
+    return h_cond, torch.stack(outs).clamp(-32752.0, 32752.0).to(torch.float16).to(torch.float32)
+
+
+def score_half(proj_a_rows: torch.Tensor, proj_b_row: torch.Tensor, w2: torch.Tensor, b2: float) -> torch.Tensor:
+    """Logits of the packed-half scoring that follows the bf16 pipeline (same extension): ``proj_a_rows`` [c,128]
+    candidate rows and ``proj_b_row`` [128] the target's row, both holding half values; every sum a+b is rounded
+    to half, ReLU, w2 rounded to half, products exact, accumulated in f32 two channels at a time in two chains
+    (groups of eight channels alternate between them), chains added, then the bias.  The hardware instruction's
+    own rounding of "two products plus accumulator" is not documented: one rounding per instruction is assumed
+    here and the comparison is made at a tolerance."""
+    import numpy as np
+    a = proj_a_rows.detach().cpu().to(torch.float16).double().numpy()
+    b = proj_b_row.detach().cpu().to(torch.float16).double().numpy()
+    w = w2.detach().cpu().reshape(-1).to(torch.float16).double().numpy()
+    t = np.maximum((a + b[None, :]).astype(np.float16).astype(np.float64), 0.0)       # exact sum, one rounding
+    prod = t * w[None, :]
+    acc = [np.zeros(a.shape[0], dtype=np.float32), np.zeros(a.shape[0], dtype=np.float32)]
+    for g in range(16):                       # group of eight channels -> chain g & 1, four instructions
+        for i in range(4):
+            j = 8 * g + 2 * i
+            acc[g & 1] = (acc[g & 1].astype(np.float64) + prod[:, j] + prod[:, j + 1]).astype(np.float32)
+    return torch.from_numpy(((acc[0] + acc[1]).astype(np.float32) + np.float32(b2)).astype(np.float32))
 
 
 # ------------------------------------------------------------------------------------ critic

@@ -325,8 +325,9 @@ def test_bulk_sampler_matches_one_at_a_time():
 
 
 # ------------------------------------------------------------------------------------------------------
-# bf16 scoring option (bulk sampling): node projections on the bf16 matrix cores.  Stated tolerance: every
-# logit within BF16_TOL of the f32 path's, relative to the largest logit of its row.
+# bf16 scoring option (bulk sampling): node projections on the bf16 matrix cores, planes stored as halfs, pairs
+# scored in packed half arithmetic.  Stated tolerance: every logit within BF16_TOL of the f32 path's, relative to
+# the largest logit of its row.
 BF16_TOL = 3e-2
 
 
@@ -354,7 +355,9 @@ def test_bf16_scoring_against_the_f32_path(case):
         assert torch.equal(getattr(p32, name), getattr(p16, name)), name
     # projections against the restated bf16 pipeline (exact sums of bf16-rounded inputs)
     h_ref, proj_ref = omodel.node_proj_bf16(gen_state(), x, z)
-    h16, proj16 = out16._debug["h_cond"].cpu()[:n], out16._debug["proj"].cpu()[:, :n]
+    h16, proj16h = out16._debug["h_cond"].cpu()[:n], out16._debug["proj"].cpu()[:, :n]
+    assert proj16h.dtype == torch.float16
+    proj16 = proj16h.float()
     scale = float(proj_ref.abs().max())
     assert float((h16 - h_ref).abs().max()) <= 1e-2 * float(h_ref.abs().max())
     assert float((proj16 - proj_ref).abs().max()) <= 1e-2 * scale
@@ -364,12 +367,26 @@ def test_bf16_scoring_against_the_f32_path(case):
     inv = inv.reshape(-1)
     first = {int(g): int(np.flatnonzero(inv == g)[0]) for g in np.unique(inv)}
     rep = torch.tensor([first[int(g)] for g in inv])
-    assert torch.equal(proj16.view(torch.int32), proj16[:, rep].view(torch.int32))
+    assert torch.equal(proj16h.view(torch.int16), proj16h[:, rep].view(torch.int16))
     # logits within the stated tolerance of the f32 path's; picks identical wherever f32 separates the
     # chosen candidates from the rest (and from each other) by more than twice that
     l32, l16 = out32._debug["logits"].cpu().numpy(), out16._debug["logits"].cpu().numpy()
     s32, s16 = out32._debug["sel"].cpu().numpy(), out16._debug["sel"].cpu().numpy()
     cnt, want = p32.cnt.cpu().numpy(), p32.want.cpu().numpy()
+    # the packed-half scoring itself, from the planes the device made: against its restatement
+    st = gen_state()
+    order_h, cand_h = p32.order.cpu().numpy(), p32.cand.cpu().numpy()
+    w2, b2 = st["edge_scorer.2.weight"], float(st["edge_scorer.2.bias"])
+    checked = 0
+    for r in range(0, n, max(1, n // 40)):
+        c = int(cnt[r])
+        if c == 0:
+            continue
+        ref = omodel.score_half(proj16h[0][cand_h[r, :c]], proj16h[1][order_h[r]], w2, b2).numpy()
+        got = out16._debug["logits"].cpu().numpy()[r, :c]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * max(float(np.abs(ref).max()), 1.0), err_msg=f"{case} {r}")
+        checked += 1
+    assert checked > 0
     compared = decided = 0
     for r in range(n):
         c = int(cnt[r])
@@ -410,13 +427,13 @@ def test_bf16_projection_of_several_samples_in_one_call():
     x = g.x.to(DEV).contiguous()
     zs = torch.randn(S, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
     w = G._weights()
-    proj = torch.empty((4, S * n64, 128), device=DEV)
+    proj = torch.empty((4, S * n64, 128), dtype=torch.float16, device=DEV)
     h = torch.empty((S * n64, 128), device=DEV)
     ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(S), x.device)
     _abi.check(lib.aig_gen_node_proj_bf16(n, S, _abi.ptr(x), _abi.ptr(zs), C.byref(w), _abi.ptr(h), _abi.ptr(proj),
                                           _abi.ptr(ws), ws.numel(), _abi.stream()))
     for i in range(S):
-        p1 = torch.empty((4, n, 128), device=DEV)
+        p1 = torch.empty((4, n, 128), dtype=torch.float16, device=DEV)
         h1 = torch.empty((n, 128), device=DEV)
         ws1 = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(1), x.device)
         _abi.check(lib.aig_gen_node_proj_bf16(n, 1, _abi.ptr(x), _abi.ptr(zs[i].contiguous()), C.byref(w), _abi.ptr(h1),
@@ -440,3 +457,62 @@ def test_bulk_sampling_in_blocks_equals_one_sample_at_a_time():
             ref = sample_one(G, tpl, zs[i])
             for name in ("x", "edge_index", "edge_attr", "node_depth"):
                 assert torch.equal(getattr(d, name), getattr(ref, name)), (dtype, i, name)
+
+
+@pytest.mark.parametrize("K,half", [(256, False), (256, True), (128, False), (192, True)])
+def test_picks_made_while_scoring_equal_the_selection_kernel(K, half):
+    """With windows of up to 256 candidates aig_gen_wire_batch lets the wave that scores a slot pick for it when
+    torch.topk would run partial_sort (k*64 <= cnt); those picks against aig_topk_select on the logits the same
+    call wrote.  The planes are made so that the logits are long runs of equal values, +-inf and NaN: a logit is
+    relu(a0) - relu(a1) + 0 * relu(a2), with a2 = inf where a NaN is wanted."""
+    import ctypes as C
+    lib = _abi.lib()
+    g = synth_aig(40, 900, 20, seed=K + half, window=K + 50)
+    x = g.x.to(DEV).float().contiguous()
+    n = x.size(0)
+    G = golden_generator(K)
+    plan = G.plan_for(Data(x=x), x, None)
+    gen = torch.Generator().manual_seed(K * 2 + half)
+    B = 3
+    rows = int(lib.aig_gen_batch_rows(n))
+    levels = torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0, 2.5, 7.0, float("inf")])
+    a0 = levels[torch.randint(0, len(levels), (B * rows,), generator=gen)]
+    a1 = levels[torch.randint(0, len(levels), (B * rows,), generator=gen)]
+    a1[torch.rand(B * rows, generator=gen) < 0.5] = 0.0
+    a2 = torch.where(torch.rand(B * rows, generator=gen) < 0.03, torch.tensor(float("inf")), torch.tensor(0.0))
+    a1[a0 == float("inf")] = 0.0                       # (inf - inf is a NaN of its own; keep the two kinds apart)
+    dt = torch.float16 if half else torch.float32
+    proj = torch.zeros((4, B * rows, 128), dtype=dt)
+    proj[0, :, 0], proj[0, :, 1], proj[0, :, 2] = a0.to(dt), a1.to(dt), a2.to(dt)
+    proj = proj.to(DEV)
+    w2 = torch.zeros((1, 128)); w2[0, 0], w2[0, 1] = 1.0, -1.0
+    w2, b2 = w2.to(DEV), torch.zeros(1, device=DEV)
+    E = max(plan.E, 1)
+    a = _abi.GenWireSet()
+    a.B, a.n, a.K, a.ecap, a.plan_shared, a.x_shared = B, n, K, E, 1, 1
+    a.x = _abi.ptr(x)
+    for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
+        setattr(a, name, _abi.ptr(getattr(plan, name)))
+    a.proj, a.proj_rows, a.proj_half = _abi.ptr(proj), rows, int(half)
+    a.sc2_w, a.sc2_b, a.at2_w, a.at2_b = _abi.ptr(w2), _abi.ptr(b2), _abi.ptr(w2), _abi.ptr(b2)
+    logits = torch.full((B, n, K), float("nan"), device=DEV)
+    sel = torch.full((B, n, 2), -9, dtype=torch.int32, device=DEV)
+    ei = torch.empty((B, 2, E), dtype=torch.int64, device=DEV)
+    ea = torch.empty((B, E), dtype=torch.int64, device=DEV)
+    ecount = torch.empty(B, dtype=torch.int32, device=DEV)
+    x_out = torch.empty((B * n, 2), device=DEV)
+    a.logits, a.sel, a.edge_index, a.edge_attr, a.ecount, a.x_out = (_abi.ptr(t) for t in (logits, sel, ei, ea, ecount, x_out))
+    _abi.check(lib.aig_gen_wire_batch(C.byref(a), _abi.stream()), "aig_gen_wire_batch")
+    torch.cuda.synchronize()
+    cnt, want = plan.cnt.cpu().numpy(), plan.want.cpu().numpy()
+    k = np.minimum(want, cnt)
+    fused_rows = (k > 0) & (k * 64 <= cnt)
+    assert fused_rows.sum() > 100 and (~fused_rows & (k > 0)).sum() > 10       # both kinds of slot occur
+    lg = logits.cpu().numpy()
+    assert np.isnan(lg[0][fused_rows][:, :64]).any() and np.isinf(lg[0][fused_rows][:, :64]).any()
+    for b in range(B):
+        alone = torch.full((n, 2), -9, dtype=torch.int32, device=DEV)
+        _abi.check(lib.aig_topk_select(n, K, _abi.ptr(logits[b]), _abi.ptr(plan.cnt), _abi.ptr(plan.want), _abi.ptr(alone),
+                                       None, 0, _abi.stream()), "aig_topk_select")
+        torch.cuda.synchronize()
+        assert torch.equal(sel[b], alone), (b, np.flatnonzero((sel[b] != alone).any(1).cpu().numpy())[:10])
