@@ -7,7 +7,9 @@ The JSON is what bench.py reports as `traffic` (profiles/pmc_traffic.json): FETC
 import csv, glob, json, re, sys
 from collections import defaultdict
 
-KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_linear128", "k_wgrad128"]
+KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_linear128", "k_wgrad128", "k_gat1_fwd",
+           "k_gat1_bwd"]
+ALIAS = {"k_linear128_x6": "k_linear128"}      # the kernel behind aig_linear128
 
 
 def read(dirs):
@@ -17,6 +19,7 @@ def read(dirs):
             for r in csv.DictReader(open(f)):
                 name = re.sub(r"^(void )?(aig::\(anonymous namespace\)::)?", "", r["Kernel_Name"])
                 name = re.sub(r"[(<].*", "", name)
+                name = ALIAS.get(name, name)
                 vals[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     return vals
 
