@@ -68,7 +68,9 @@ SIGNATURES = {
     "aig_level_pool_bwd": (INT, [I64, I64, P, P, P, P, P, P, P]),
     "aig_level_pool_bwd_adj_ws_bytes": (SZ, [I64]),
     "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
-    "aig_gp_forward": (INT, [I64] + [P] * 10 + [P]),
+    "aig_gp_rows_ws_bytes": (SZ, [I64, I64]),
+    "aig_gp_rows": (INT, [I64, I64] + [P] * 10 + [P, SZ, P]),
+    "aig_gp_forward": (INT, [I64, P] + [P] * 10 + [P]),
     "aig_gp_scalars": (INT, [P, C.c_float, P, P]),
     "aig_adam_chunk_elems": (INT, []),
     "aig_adam_sum3": (INT, [I64, P, I64, P, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float,
@@ -77,9 +79,9 @@ SIGNATURES = {
     "aig_sort_pairs_ws_bytes": (SZ, [I64, INT, INT]),
     "aig_sort_pairs": (INT, [I64, INT, INT, P, P, P, P, P, SZ, P]),
     "aig_gp_input_grad_ws_bytes": (SZ, [I64]),
-    "aig_gp_input_grad": (INT, [I64, I64] + [P] * 14 + [P, SZ, P]),
+    "aig_gp_input_grad": (INT, [I64, P, I64] + [P] * 14 + [P, SZ, P]),
     "aig_gp_param_grad_ws_bytes": (SZ, [I64]),
-    "aig_gp_param_grad": (INT, [I64, I64] + [P] * 20 + [P, SZ, P]),
+    "aig_gp_param_grad": (INT, [I64, P, I64] + [P] * 20 + [P, SZ, P]),
     "aig_linear128": (INT, [I64, P, P, INT, P, INT, P, P]),
     "aig_linear_in2": (INT, [I64, P, P, P, P]),
     "aig_head_fwd": (INT, [P] * 9 + [P]),

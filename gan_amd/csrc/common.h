@@ -78,6 +78,17 @@ bool kernel_timing_events(int kernel, hipStream_t s, hipEvent_t* start, hipEvent
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
     } while (0)
 
+// A row count that only the device knows.  An entry point whose caller sizes the launches by a capacity (rows past the
+// real count hold neutral values) sets this pointer for the calls it makes; the launchers of aig_linear128 and
+// aig_wgrad pass it on and their kernels work on min(host count, *limit) rows.  Null: the host count stands.
+extern thread_local const int* g_row_limit;
+struct RowLimitScope {
+    const int* prev;
+    explicit RowLimitScope(const int* p) : prev(g_row_limit) { g_row_limit = p; }
+    ~RowLimitScope() { g_row_limit = prev; }
+};
+__device__ __forceinline__ int limited_rows(int n, const int* __restrict__ limit) { return limit ? min(n, limit[0]) : n; }
+
 // y = act(x W^T + bias), x [M,128] f32, on the bf16 matrix cores at f32 accuracy (dense6.hip).  W: [128][ldw] rows =
 // output columns, or (wt) stored [in][out]; act 0 none, 1 ReLU, 2 ELU.
 int launch_linear128_x6(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, const float* bias, int act,

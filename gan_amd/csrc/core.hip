@@ -7,6 +7,7 @@
 namespace aig {
 
 static thread_local char g_err[512] = "";
+thread_local const int* g_row_limit = nullptr;
 
 char* err_buf() { return g_err; }
 

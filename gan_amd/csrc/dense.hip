@@ -32,9 +32,11 @@ constexpr int WG_SMALL_BLOCKS_MAX = 512;   // small F: partials are at most 2 KB
 constexpr int TILE = 64;
 constexpr size_t WGRAD_LDS = (size_t)2 * 2 * TILE * H * sizeof(float);
 
-__global__ __launch_bounds__(512, 1) void k_wgrad128(int n, const float* __restrict__ g, const float* __restrict__ x,
+__global__ __launch_bounds__(512, 1) void k_wgrad128(int n, const int* __restrict__ row_limit, const float* __restrict__ g,
+                                                     const float* __restrict__ x,
                                                      float* __restrict__ partial /*[grid][128][128]*/) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [buf][g|x][TILE][H]
+    n = limited_rows(n, row_limit);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int rw = w & 3, ch = w >> 2;
     const int col = lane & 31, kh = lane >> 5;
@@ -110,10 +112,11 @@ __global__ __launch_bounds__(512, 1) void k_wgrad128(int n, const float* __restr
 // small F (the first layer has F = 2): half-wave per node row, 16-byte loads of g, the F inputs of
 // the row broadcast; the eight row groups of a block are added in fixed order through LDS
 template <int F>
-__global__ __launch_bounds__(256) void k_wgrad_small(int n, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void k_wgrad_small(int n, const int* __restrict__ row_limit, const float* __restrict__ g,
                                                      const float* __restrict__ x,
                                                      float* __restrict__ partial /*[grid][128][F]*/) {
     __shared__ float4 red[8][F][32];
+    n = limited_rows(n, row_limit);
     const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     const int chunk = (n + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * chunk, n1 = min(n, n0 + chunk);
@@ -248,16 +251,16 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
     if (F == 128) {
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wgrad128), (size_t)(WGRAD_LDS)));
         nb = wg_blocks(n, 2 * TILE, WG_BLOCKS_MAX);
-        AIG_LAUNCH_TIMED(AIG_KT_WGRAD128, k_wgrad128, dim3(nb), dim3(512), WGRAD_LDS, s, (int)n, g, x, partial);
+        AIG_LAUNCH_TIMED(AIG_KT_WGRAD128, k_wgrad128, dim3(nb), dim3(512), WGRAD_LDS, s, (int)n, g_row_limit, g, x, partial);
     } else if (F == 1) {
         nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
-        hipLaunchKernelGGL(k_wgrad_small<1>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
+        hipLaunchKernelGGL(k_wgrad_small<1>, dim3(nb), dim3(256), 0, s, (int)n, g_row_limit, g, x, partial);
     } else if (F == 2) {
         nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
-        hipLaunchKernelGGL(k_wgrad_small<2>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
+        hipLaunchKernelGGL(k_wgrad_small<2>, dim3(nb), dim3(256), 0, s, (int)n, g_row_limit, g, x, partial);
     } else {
         nb = wg_blocks(n, 64, WG_SMALL_BLOCKS_MAX);
-        hipLaunchKernelGGL(k_wgrad_small<4>, dim3(nb), dim3(256), 0, s, (int)n, g, x, partial);
+        hipLaunchKernelGGL(k_wgrad_small<4>, dim3(nb), dim3(256), 0, s, (int)n, g_row_limit, g, x, partial);
     }
     AIG_LAUNCH_CHECK();
     const int elems = (int)(H * F);

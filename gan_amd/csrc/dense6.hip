@@ -73,10 +73,13 @@ __device__ __forceinline__ float act1(float y) {
 }
 
 template <int ACT>
-__global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const float* __restrict__ X,
+__global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const int* __restrict__ row_limit,
+                                                            const float* __restrict__ X,
                                                             const float* __restrict__ W, int ldw, int wt,
                                                             const float* __restrict__ bias, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    M = limited_rows(M, row_limit);
+    if (M <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cw = wave & 3, uh = wave >> 2, frow = lane & 31, fh = lane >> 5;
     const int G = gridDim.x;
@@ -225,7 +228,7 @@ int launch(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt
     AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128_x6<ACT>), X6_LDS));
     const int tiles = (M + BM - 1) / BM;
     const int gx = tiles < 256 ? tiles : 256;      // one workgroup of eight waves per CU
-    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128_x6<ACT>), dim3(gx), dim3(THREADS), X6_LDS, s, M, X, W, ldw, wt, bias, out);
+    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128_x6<ACT>), dim3(gx), dim3(THREADS), X6_LDS, s, M, g_row_limit, X, W, ldw, wt, bias, out);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

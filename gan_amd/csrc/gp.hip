@@ -36,7 +36,8 @@ __device__ __forceinline__ float halfwave_sum(float v) {
 struct Rows {
     int begin, end;
 };
-__device__ __forceinline__ Rows block_rows(int n) {
+__device__ __forceinline__ Rows block_rows(int n, const int* __restrict__ row_limit = nullptr) {
+    n = limited_rows(n, row_limit);
     const int chunk = (n + gridDim.x - 1) / gridDim.x;
     const int b = blockIdx.x * chunk;
     return {b, min(n, b + chunk)};
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_sum_cols(int nb, int width, const float
 }
 
 // x^ = alpha xr + (1 - alpha) xf,  h1 = elu(x^ W1^T + b1)
-__global__ __launch_bounds__(THREADS) void k_gp_enc(int n, const float* __restrict__ xr, const float* __restrict__ xf,
+__global__ __launch_bounds__(THREADS) void k_gp_enc(int n, const int* __restrict__ row_limit, const float* __restrict__ xr, const float* __restrict__ xf,
                                                     const float* __restrict__ alpha, const float* __restrict__ W1,
                                                     const float* __restrict__ b1, float* __restrict__ xhat,
                                                     float* __restrict__ h1) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_enc(int n, const float* __restri
         w1[u] = W1[2 * (4 * l + u) + 1];
         bb[u] = b1[4 * l + u];
     }
-    const Rows r = block_rows(n);
+    const Rows r = block_rows(n, row_limit);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float2 pr = reinterpret_cast<const float2*>(xr)[i], pf = reinterpret_cast<const float2*>(xf)[i];
         const float x0 = a * pr.x + (1.f - a) * pf.x, x1 = a * pr.y + (1.f - a) * pf.y;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_enc(int n, const float* __restri
 }
 
 // g_z2 = (P^T g_r) * elu'(z2)
-__global__ __launch_bounds__(THREADS) void k_gp_gz2(int n, int L, const int* __restrict__ meta, const float* __restrict__ g_r,
+__global__ __launch_bounds__(THREADS) void k_gp_gz2(int n, const int* __restrict__ row_limit, int L, const int* __restrict__ meta, const float* __restrict__ g_r,
                                                     const int* __restrict__ node_level, const float* __restrict__ w,
                                                     const int* __restrict__ argmax, const float* __restrict__ h2,
                                                     float* __restrict__ g_z2) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_gz2(int n, int L, const int* __r
     const float4 g_mean = reinterpret_cast<const float4*>(g_r)[l], g_max = reinterpret_cast<const float4*>(g_r + H)[l];
     const float inv_levels = 1.f / (float)(level_count(L, meta));
     const int4* argmax4 = reinterpret_cast<const int4*>(argmax);
-    const Rows r = block_rows(n);
+    const Rows r = block_rows(n, row_limit);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float4 hv = reinterpret_cast<const float4*>(h2 + (size_t)i * H)[l];
         float4 gh = readout_pull(i, node_level[i], w[i], inv_levels, g_mean, g_max, argmax4, l);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_gz2(int n, int L, const int* __r
 }
 
 // g_z1 = g_h1 * elu'(z1) (in place over g_h1's copy `g_z1`),  g_x = g_z1 W1,  partial sums of |g_x|^2
-__global__ __launch_bounds__(THREADS) void k_gp_gx(int n, const float* __restrict__ g_h1, const float* __restrict__ h1,
+__global__ __launch_bounds__(THREADS) void k_gp_gx(int n, const int* __restrict__ row_limit, const float* __restrict__ g_h1, const float* __restrict__ h1,
                                                    const float* __restrict__ W1, float* __restrict__ g_z1,
                                                    float* __restrict__ g_x, float* __restrict__ partial /*[grid]*/) {
     __shared__ float red[HW_PER_BLOCK];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_gx(int n, const float* __restric
         w1[u] = W1[2 * (4 * l + u) + 1];
     }
     float acc = 0.f;
-    const Rows r = block_rows(n);
+    const Rows r = block_rows(n, row_limit);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float4 gv = reinterpret_cast<const float4*>(g_h1 + (size_t)i * H)[l];
         const float4 hv = reinterpret_cast<const float4*>(h1 + (size_t)i * H)[l];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_gx(int n, const float* __restric
 }
 
 // u = coef g_x;  ubar_gz1 = u W1^T;  ubar_gh1 = ubar_gz1 * elu'(z1);  dz1a = ubar_gz1 * g_h1 * elu''(z1)
-__global__ __launch_bounds__(THREADS) void k_gp_back1(int n, const float* __restrict__ coef,
+__global__ __launch_bounds__(THREADS) void k_gp_back1(int n, const int* __restrict__ row_limit, const float* __restrict__ coef,
                                                       const float* __restrict__ g_x, const float* __restrict__ W1,
                                                       const float* __restrict__ h1, const float* __restrict__ g_h1,
                                                       float* __restrict__ u, float* __restrict__ ubar_gh1,
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_back1(int n, const float* __rest
         w0[k] = W1[2 * (4 * l + k)];
         w1[k] = W1[2 * (4 * l + k) + 1];
     }
-    const Rows r = block_rows(n);
+    const Rows r = block_rows(n, row_limit);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float2 gx = reinterpret_cast<const float2*>(g_x)[i];
         const float u0 = c * gx.x, u1 = c * gx.y;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_back1(int n, const float* __rest
 
 // ubar_gh2 = ubar_gz2 * elu'(z2);  dz2 = ubar_gz2 * g_h2 * elu''(z2)  (g_h2 = P^T g_r, recomputed);
 // block partials of [ colsum(dz2) | sum_i w_i ubar_gh2 | sum_i [argmax == i] ubar_gh2 / (L+1) ]
-__global__ __launch_bounds__(THREADS) void k_gp_back2(int n, int L, const int* __restrict__ meta,
+__global__ __launch_bounds__(THREADS) void k_gp_back2(int n, const int* __restrict__ row_limit, int L, const int* __restrict__ meta,
                                                       const float* __restrict__ ubar_gz2,
                                                       const float* __restrict__ h2, const float* __restrict__ g_r,
                                                       const int* __restrict__ node_level, const float* __restrict__ w,
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_back2(int n, int L, const int* _
     const int4* argmax4 = reinterpret_cast<const int4*>(argmax);
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sb = zero, sm = zero, sx = zero;
-    const Rows r = block_rows(n);
+    const Rows r = block_rows(n, row_limit);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float4 zv = reinterpret_cast<const float4*>(ubar_gz2 + (size_t)i * H)[l];
         const float4 hv = reinterpret_cast<const float4*>(h2 + (size_t)i * H)[l];
@@ -259,12 +260,12 @@ __global__ __launch_bounds__(THREADS) void k_gp_back2(int n, int L, const int* _
 }
 
 // dz1 = dz1a + dh1 * elu'(z1) (in place over dz1a); block partials of colsum(dz1)
-__global__ __launch_bounds__(THREADS) void k_gp_back3(int n, const float* __restrict__ dh1, const float* __restrict__ h1,
+__global__ __launch_bounds__(THREADS) void k_gp_back3(int n, const int* __restrict__ row_limit, const float* __restrict__ dh1, const float* __restrict__ h1,
                                                       float* __restrict__ dz1, float* __restrict__ partial /*[grid][128]*/) {
     __shared__ float red[HW_PER_BLOCK][H];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float4 sb = make_float4(0.f, 0.f, 0.f, 0.f);
-    const Rows r = block_rows(n);
+    const Rows r = block_rows(n, row_limit);
     for (int i = r.begin + hw; i < r.end; i += HW_PER_BLOCK) {
         const float4 dv = reinterpret_cast<const float4*>(dh1 + (size_t)i * H)[l];
         const float4 hv = reinterpret_cast<const float4*>(h1 + (size_t)i * H)[l];
@@ -333,14 +334,15 @@ extern "C" int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_m
 }
 
 // --------------------------------------------------------------------------------------------- gradient penalty
-extern "C" int aig_gp_forward(int64_t n, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
+extern "C" int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
                               const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2,
                               void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX, "aig_gp_forward: n=%lld out of range", (long long)n);
     AIG_REQUIRE(x_real && x_fake && alpha && W1 && b1 && W2 && b2 && xhat && h1 && h2, "aig_gp_forward: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_gp_enc, dim3(gp_blocks(n)), dim3(THREADS), 0, s, (int)n, x_real, x_fake, alpha, W1, b1, xhat, h1);
+    hipLaunchKernelGGL(k_gp_enc, dim3(gp_blocks(n)), dim3(THREADS), 0, s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, xhat, h1);
     AIG_LAUNCH_CHECK();
+    RowLimitScope limit(n_rows_dev);
     return aig_linear128(n, h1, W2, 0, b2, 2, h2, stream);
 }
 
@@ -364,7 +366,7 @@ extern "C" size_t aig_gp_input_grad_ws_bytes(int64_t n) {
     return align_up((size_t)GP_BLOCKS_MAX * 4) + 256;
 }
 
-extern "C" int aig_gp_input_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g_r,
+extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r,
                                  const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1,
                                  const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
                                  void* ws, size_t ws_bytes, void* stream) {
@@ -373,14 +375,15 @@ extern "C" int aig_gp_input_grad(int64_t n, int64_t L, const int32_t* lvl_meta, 
                 "aig_gp_input_grad: null pointer");
     if (ws_bytes < aig_gp_input_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_input_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    RowLimitScope limit(n_rows_dev);
     const int g = gp_blocks(n);
-    hipLaunchKernelGGL(k_gp_gz2, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, lvl_meta, g_r, node_level, w, argmax, h2,
-                       g_z2);
+    hipLaunchKernelGGL(k_gp_gz2, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w, argmax,
+                       h2, g_z2);
     AIG_LAUNCH_CHECK();
     int rc = aig_linear128(n, g_z2, W2, 1, nullptr, 0, g_h1, stream);
     if (rc) return rc;
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(k_gp_gx, dim3(g), dim3(THREADS), 0, s, (int)n, g_h1, h1, W1, g_z1, g_x, partial);
+    hipLaunchKernelGGL(k_gp_gx, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, g_h1, h1, W1, g_z1, g_x, partial);
     hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(256), 0, s, g, 1, partial, norm_sq);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
@@ -393,7 +396,8 @@ extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
            align_up((size_t)H * H * 4) + align_up(wg > wg2 ? wg : wg2) + 1024;
 }
 
-extern "C" int aig_gp_param_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* coef, const float* g_r,
+extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
+                                 const float* g_r,
                                  const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2,
                                  const float* xhat, const float* h1, const float* h2, const float* g_z2,
                                  const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1,
@@ -418,12 +422,14 @@ extern "C" int aig_gp_param_grad(int64_t n, int64_t L, const int32_t* lvl_meta, 
     void* wg = c.base + c.off;
     const int g = gp_blocks(n);
     int rc;
+    RowLimitScope limit(n_rows_dev);
 
-    hipLaunchKernelGGL(k_gp_back1, dim3(g), dim3(THREADS), 0, s, (int)n, coef, g_x, W1, h1, g_h1, u, ubar_gh1, dz1);
+    hipLaunchKernelGGL(k_gp_back1, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, coef, g_x, W1, h1, g_h1, u, ubar_gh1,
+                       dz1);
     AIG_LAUNCH_CHECK();
     if ((rc = aig_linear128(n, ubar_gh1, W2, 0, nullptr, 0, ubar_gz2, stream))) return rc;
-    hipLaunchKernelGGL(k_gp_back2, dim3(g), dim3(THREADS), 0, s, (int)n, (int)L, lvl_meta, ubar_gz2, h2, g_r, node_level, w,
-                       argmax, dz2, partial);
+    hipLaunchKernelGGL(k_gp_back2, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, (int)L, lvl_meta, ubar_gz2, h2, g_r,
+                       node_level, w, argmax, dz2, partial);
     // columns 0..127 -> db2, 128..383 -> ubar_gr
     hipLaunchKernelGGL(k_sum_cols, dim3(H), dim3(256), 0, s, g, 3 * H, partial, db2);
     hipLaunchKernelGGL(k_sum_cols, dim3(2 * H), dim3(256), 0, s, g, 3 * H, partial + H, ubar_gr);
@@ -435,7 +441,7 @@ extern "C" int aig_gp_param_grad(int64_t n, int64_t L, const int32_t* lvl_meta, 
     AIG_LAUNCH_CHECK();
     // dz1 = dz1a + (dz2 W2) * elu'(z1)
     if ((rc = aig_linear128(n, dz2, W2, 1, nullptr, 0, dh1, stream))) return rc;
-    hipLaunchKernelGGL(k_gp_back3, dim3(g), dim3(THREADS), 0, s, (int)n, dh1, h1, dz1, partial);
+    hipLaunchKernelGGL(k_gp_back3, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, dh1, h1, dz1, partial);
     hipLaunchKernelGGL(k_sum_cols, dim3(H), dim3(256), 0, s, g, H, partial, db1);
     AIG_LAUNCH_CHECK();
     // dW1 = g_z1^T u + dz1^T x^

@@ -148,6 +148,37 @@ class DynLevelPlan:
         return bool(int(self.meta[2].item()) & 2)
 
 
+class GpRows:
+    """The distinct rows of the closed-form gradient penalty (``aig_gp_rows``): nodes of one level with the same
+    (real, generated) features are one row with a multiplicity, kept in buffers of fixed address so that the
+    penalty can be recorded once and replayed over whatever ``rebuild`` last left in them.  ``rebuild`` sorts and
+    scans (library routines), so it runs eagerly, before the replay - once per (real, generated) pair, the random
+    ``alpha`` of a critic iteration does not enter."""
+
+    def __init__(self, n: int, level_cap: int, device):
+        self.n, self.L = int(n), int(level_cap)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_real, self.x_fake = torch.zeros((n, 2), **f32), torch.zeros((n, 2), **f32)
+        self.depth = torch.full((n,), -1, dtype=torch.int64, device=device)
+        self.w_fwd, self.w_bwd = torch.zeros(n, **f32), torch.zeros(n, **f32)
+        self.n_rows = torch.zeros(1, dtype=torch.int32, device=device)
+        self.plan = DynLevelPlan(n, self.L, device)
+
+    def rebuild(self, x_real: torch.Tensor, x_fake: torch.Tensor, plan) -> None:
+        """Rows of the penalty between ``x_real`` and ``x_fake`` ([n,2] f32) whose nodes have the levels of ``plan``
+        (a ``LevelPlan`` / ``DynLevelPlan`` of the same n with at most this object's level capacity)."""
+        lib = _abi.lib()
+        if int(x_real.size(0)) != self.n or int(x_fake.size(0)) != self.n or plan.n != self.n or plan.L > self.L:
+            raise _abi.AigAbiError("GpRows.rebuild: sizes differ from the planned ones")
+        xr, xf = x_real.float().contiguous(), x_fake.float().contiguous()
+        ws = _abi.workspace(lib.aig_gp_rows_ws_bytes(self.n, self.L), xr.device)
+        _abi.check(lib.aig_gp_rows(self.n, self.L, _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+                                   _abi.ptr(self.x_real), _abi.ptr(self.x_fake), _abi.ptr(self.depth), _abi.ptr(self.w_fwd),
+                                   _abi.ptr(self.w_bwd), _abi.ptr(self.n_rows), _abi.ptr(ws), ws.numel(), _abi.stream()),
+                   "aig_gp_rows")
+        self.plan.rebuild(self.depth)
+
+
 class _GATAggregate(torch.autograd.Function):
     """softmax-attention aggregation + bias + ELU over a GraphCSR (first-order differentiable)."""
 
@@ -599,7 +630,8 @@ class AIGDiscriminator(nn.Module):
         return self._lvl_cache.lookup(key, lambda: (LevelPlan(node_depth, n, device), node_depth))[0]
 
     def gradient_penalty_closed_form(self, x_real: torch.Tensor, x_fake: torch.Tensor, alpha: torch.Tensor,
-                                     node_depth: Optional[torch.Tensor], plan=None, grad_scale: float = 1.0):
+                                     node_depth: Optional[torch.Tensor], plan=None, grad_scale: float = 1.0,
+                                     rows: Optional["GpRows"] = None):
         """``gradient_penalty(use_edges=False)`` of train.py:133-152 and its gradient w.r.t. the critic's
         parameters without autograd on the node tensors: on an empty edge list each attention layer
         is ``elu(x W^T + b)``, which makes the penalty a closed form (four [n,128]x[128,128]
@@ -607,12 +639,21 @@ class AIGDiscriminator(nn.Module):
         gradient and its second-order share come from the head kernels).  Returns ``(gp, grad_norm, grads)`` with ``grads`` a dict
         parameter -> gradient of ``gp`` (parameters the edge-free pass never touches are absent).  ``plan``: a
         level plan of ``node_depth`` the caller already holds (else it is looked up / built here); ``grad_scale``
-        multiplies every returned gradient (the loss weights the penalty by gp_lambda)."""
+        multiplies every returned gradient (the loss weights the penalty by gp_lambda).  ``rows``: a ``GpRows``
+        whose last ``rebuild`` was made for these very features and levels - the computation then runs over its
+        distinct rows (same numbers up to the order of the sums); ``x_real`` / ``x_fake`` / ``plan`` are not read."""
         lib = _abi.lib()
         dev = x_real.device
         n = int(x_real.size(0))
         f32 = dict(dtype=torch.float32, device=dev)
         xr, xf = x_real.float().contiguous(), x_fake.float().contiguous()
+        n_dev = None
+        if rows is not None:
+            if rows.n != n:
+                raise _abi.AigAbiError("gradient_penalty_closed_form: rows were planned for another node count")
+            xr, xf, plan, n_dev = rows.x_real, rows.x_fake, rows.plan, rows.n_rows
+        w_fwd = rows.w_fwd if rows is not None else None
+        w_bwd = rows.w_bwd if rows is not None else None
         al = alpha.reshape(-1)[:1].float().contiguous()
         W1, b1 = self.gat1.lin.weight.detach().contiguous(), self.gat1.bias.detach().contiguous()
         W2, b2 = self.gat2.lin.weight.detach().contiguous(), self.gat2.bias.detach().contiguous()
@@ -623,14 +664,16 @@ class AIGDiscriminator(nn.Module):
         st = _abi.stream()
         xhat = torch.empty((n, 2), **f32)
         h1, h2 = torch.empty((n, HIDDEN), **f32), torch.empty((n, HIDDEN), **f32)
-        _abi.check(lib.aig_gp_forward(n, _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(al), _abi.ptr(W1), _abi.ptr(b1),
+        if w_fwd is None:
+            w_fwd = w_bwd = plan.w
+        _abi.check(lib.aig_gp_forward(n, _abi.ptr(n_dev), _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(al), _abi.ptr(W1), _abi.ptr(b1),
                                       _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(xhat), _abi.ptr(h1), _abi.ptr(h2), st),
                    "aig_gp_forward")
         r = torch.empty((1, 2 * HIDDEN), **f32)
         argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
         ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(n, plan.L), dev)
         _abi.check(lib.aig_level_pool_fwd(n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
-                                          _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(r), _abi.ptr(argmax),
+                                          _abi.ptr(plan.node_level), _abi.ptr(w_fwd), _abi.ptr(r), _abi.ptr(argmax),
                                           _abi.ptr(ws), ws.numel(), st), "aig_level_pool_fwd")
         # head: s = out(mlp(r)), g_r = ds/dr (the backward kernel of the head with ds = 1)
         hw1, hb1 = self.mlp[0].weight.detach().contiguous(), self.mlp[0].bias.detach().contiguous()
@@ -646,7 +689,7 @@ class AIGDiscriminator(nn.Module):
         g_z2, g_h1, g_z1 = (torch.empty((n, HIDDEN), **f32) for _ in range(3))
         g_x, norm_sq = torch.empty((n, 2), **f32), torch.empty(1, **f32)
         ws = _abi.workspace(lib.aig_gp_input_grad_ws_bytes(n), dev)
-        _abi.check(lib.aig_gp_input_grad(n, plan.L, _abi.ptr(plan.meta), _abi.ptr(g_r_c), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+        _abi.check(lib.aig_gp_input_grad(n, _abi.ptr(n_dev), plan.L, _abi.ptr(plan.meta), _abi.ptr(g_r_c), _abi.ptr(plan.node_level), _abi.ptr(w_bwd),
                                          _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(h1), _abi.ptr(h2),
                                          _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(norm_sq),
                                          _abi.ptr(ws), ws.numel(), st), "aig_gp_input_grad")
@@ -660,8 +703,8 @@ class AIGDiscriminator(nn.Module):
         dW2, db2 = torch.empty((HIDDEN, HIDDEN), **f32), torch.empty(HIDDEN, **f32)
         u_gr = torch.empty((1, 2 * HIDDEN), **f32)
         ws = _abi.workspace(lib.aig_gp_param_grad_ws_bytes(n), dev)
-        _abi.check(lib.aig_gp_param_grad(n, plan.L, _abi.ptr(plan.meta), _abi.ptr(coef), _abi.ptr(g_r_c), _abi.ptr(plan.node_level),
-                                         _abi.ptr(plan.w), _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(xhat),
+        _abi.check(lib.aig_gp_param_grad(n, _abi.ptr(n_dev), plan.L, _abi.ptr(plan.meta), _abi.ptr(coef), _abi.ptr(g_r_c), _abi.ptr(plan.node_level),
+                                         _abi.ptr(w_bwd), _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(xhat),
                                          _abi.ptr(h1), _abi.ptr(h2), _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1),
                                          _abi.ptr(g_x), _abi.ptr(dW1), _abi.ptr(db1), _abi.ptr(dW2), _abi.ptr(db2),
                                          _abi.ptr(u_gr), _abi.ptr(ws), ws.numel(), st), "aig_gp_param_grad")

@@ -383,17 +383,38 @@ int aig_sort_pairs(int64_t items, int key_bytes, int bits, const void* keys_in, 
  *                      (the caller back-propagates ubar_gr through its head to get the head's weight gradients).
  * W1/b1 = gat1.lin.weight / gat1.bias, W2/b2 = gat2.lin.weight / gat2.bias; alpha, norm_sq, coef are device scalars;
  * lvl_meta = header of a plan from aig_level_plan_dyn, or NULL when L is the plan's deepest level itself.
+ * n_rows_dev (may be NULL): a device int holding the number of rows really present, for callers whose row count
+ * only the device knows (aig_gp_rows): buffers and launches are sized by n, the kernels work on min(n, *n_rows_dev)
+ * rows, and rows past that count must hold neutral values (no level, weight 0) - results do not depend on it.
+ *
+ *   aig_gp_rows        the DISTINCT rows of this computation (no counterpart in the reference: train.py:133-152 runs
+ *                      the critic over every node).  Nodes of one level with the same (x_real, x_fake) features go
+ *                      through both layers as identical rows, and only the first of them (lowest id) can hold one of
+ *                      its level's maxima.  Per such cell this emits its first node as a row of multiplicity 1 and,
+ *                      for cells of m > 1 nodes, its second node as a row standing for the other m - 1; rows come in
+ *                      node order: xr_rows / xf_rows [n,2], depth_rows int64 [n] (the row's level; -1 past the last
+ *                      row - feed it to aig_level_plan_dyn), w_fwd = m w and w_bwd = sqrt(m) w with w the node's
+ *                      weight in the FULL plan (node_level, w: that plan's arrays; L: its level capacity), *n_rows.
+ *                      With w_fwd as the readout's weights in aig_level_pool_fwd and w_bwd as `w` of
+ *                      aig_gp_input_grad / aig_gp_param_grad the penalty, its norm and every gradient equal those of
+ *                      the run over all nodes (a row's backward chain is linear in the readout's gradient, so it
+ *                      carries sqrt(m) and every sum over rows of a product of two chains carries m).  More than 256
+ *                      distinct feature pairs: the surplus nodes stay rows of their own.
  * ------------------------------------------------------------------------------------------- */
-int aig_gp_forward(int64_t n, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
+size_t aig_gp_rows_ws_bytes(int64_t n, int64_t L);
+int aig_gp_rows(int64_t n, int64_t L, const float* x_real, const float* x_fake, const int32_t* node_level, const float* w,
+                float* xr_rows, float* xf_rows, int64_t* depth_rows, float* w_fwd, float* w_bwd, int32_t* n_rows,
+                void* ws, size_t ws_bytes, void* stream);
+int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
                    const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2, void* stream);
 int aig_gp_scalars(const float* norm_sq, float scale, float* out3, void* stream);
 size_t aig_gp_input_grad_ws_bytes(int64_t n);
-int aig_gp_input_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* g_r, const int32_t* node_level,
+int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r, const int32_t* node_level,
                       const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1, const float* h2,
                       float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
                       void* ws, size_t ws_bytes, void* stream);
 size_t aig_gp_param_grad_ws_bytes(int64_t n);
-int aig_gp_param_grad(int64_t n, int64_t L, const int32_t* lvl_meta, const float* coef, const float* g_r,
+int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef, const float* g_r,
                       const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* xhat,
                       const float* h1, const float* h2, const float* g_z2, const float* g_h1, const float* g_z1,
                       const float* g_x, float* dW1, float* db1, float* dW2, float* db2, float* ubar_gr,

@@ -466,6 +466,72 @@ def test_closed_form_gradient_penalty_matches_autograd(case):
         assert err <= 1e-4, (tuple(p.shape), err)
 
 
+@pytest.mark.parametrize("case", ["aig_features", "negative_depths", "no_depth", "many_pairs", "all_distinct", "bench_100k"])
+def test_gradient_penalty_over_distinct_rows(case):
+    """The closed-form penalty over the distinct (level, feature pair) rows of aig_gp_rows against the same entry
+    points run over every node: gp, norm and every parameter gradient within 2e-5 (the sums run in another order),
+    and the row count is what a host-side count of the cells gives.  `many_pairs`: more distinct pairs than the
+    256-slot table holds (the surplus nodes stay rows of their own); `all_distinct`: continuous features, nothing
+    to merge."""
+    from gan_amd.discriminator import GpRows, LevelPlan
+    torch.manual_seed(11)
+    big = case == "bench_100k"
+    g = (synth_aig(1000, 98000, 1000, seed=3, window=4096, orientation="dataset") if big
+         else synth_aig(12, 2500, 9, seed=8, window=60, orientation="dataset"))
+    n = g.x.size(0)
+    gen = torch.Generator().manual_seed(5)
+    xr = g.x.clone().float()
+    xf = xr.clone()
+    xf[:, 1] = torch.randint(0, 3, (n,), generator=gen).float()        # what a generated graph changes: the inverted count
+    nd = g.node_depth.clone().long()
+    if case == "negative_depths":
+        nd[::7] = -1
+    if case == "no_depth":
+        nd = torch.zeros_like(nd)
+    if case == "many_pairs":
+        xf[:, 1] = torch.randint(0, 700, (n,), generator=gen).float()
+    if case == "all_distinct":
+        xf = xf + torch.rand(xf.shape, generator=gen)
+    D = AIGDiscriminator().to(DEV)
+    with torch.no_grad():
+        for p in D.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    xr, xf, nd = xr.to(DEV), xf.to(DEV), nd.to(DEV)
+    alpha = torch.tensor([[0.37]], device=DEV)
+    plan = LevelPlan(nd, n, DEV)
+    gp0, gn0, gr0 = D.gradient_penalty_closed_form(xr, xf, alpha, nd, plan=plan)
+    rows = GpRows(n, plan.L + 3, DEV)
+    rows.rebuild(xr, xf, plan)
+    gp1, gn1, gr1 = D.gradient_penalty_closed_form(xr, xf, alpha, nd, plan=plan, rows=rows)
+    torch.cuda.synchronize()
+    # the row count against a host-side count of the cells
+    keys = torch.cat([xr, xf, nd.float().unsqueeze(1)], 1).cpu().numpy()
+    keys = keys[nd.cpu().numpy() >= 0]
+    _, counts = np.unique(keys, axis=0, return_counts=True)
+    want_rows = int(len(counts) + (counts > 1).sum())
+    got_rows = int(rows.n_rows.item())
+    if case == "many_pairs":
+        assert want_rows <= got_rows <= int((nd >= 0).sum())
+    else:
+        assert got_rows == want_rows, (got_rows, want_rows)
+    if case == "bench_100k":
+        assert got_rows < n // 3
+    assert abs(float(gp1) - float(gp0)) <= 2e-5 * max(abs(float(gp0)), 1e-6), (float(gp0), float(gp1))
+    assert abs(float(gn1) - float(gn0)) <= 2e-5 * abs(float(gn0))
+    assert set(gr0) == set(gr1)
+    for p in gr0:
+        scale = float(gr0[p].abs().max())
+        assert float((gr1[p] - gr0[p]).abs().max()) <= 2e-5 * max(scale, 1e-9), (tuple(p.shape), scale)
+    # a second rebuild into the same buffers with other features (fewer rows): nothing of the first one is left behind
+    xf2 = xr.clone()
+    rows.rebuild(xr, xf2, plan)
+    gp2, gn2, gr2 = D.gradient_penalty_closed_form(xr, xf2, alpha, nd, plan=plan, rows=rows)
+    gp3, gn3, gr3 = D.gradient_penalty_closed_form(xr, xf2, alpha, nd, plan=plan)
+    assert abs(float(gp2) - float(gp3)) <= 2e-5 * max(abs(float(gp3)), 1e-6)
+    for p in gr3:
+        assert float((gr2[p] - gr3[p]).abs().max()) <= 2e-5 * max(float(gr3[p].abs().max()), 1e-9), tuple(p.shape)
+
+
 def test_fused_head_matches_torch_modules():
     """One-launch head (forward, backward, input gradient, second-order weight gradient) against the
     same three Linear layers run by torch."""
