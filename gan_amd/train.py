@@ -48,7 +48,7 @@ from .constraints import (aig_constraint_penalties, clean_depth_set, enforce_aig
 from .data import Batch, Data, GraphLoader
 from .graphset import GraphSet
 from .dataset import load_pt_dataset, pad_data, save_data_list_as_pt, unpad_data
-from .discriminator import AIGDiscriminator, DynLevelPlan, GraphCSR
+from .discriminator import AIGDiscriminator, DynLevelPlan, GpRows, GraphCSR
 from .generator import AIGGenerator
 
 METRIC_FIELDS = ["step", "epoch", "D_real", "D_fake", "gap", "grad_norm", "loss_D", "loss_G", "gp", "pen"]
@@ -282,7 +282,7 @@ class CapturedCriticTerms:
 
     def __init__(self, D: AIGDiscriminator, params: List[torch.Tensor], example: Batch, level_cap: int,
                  gp_lambda: float, device: torch.device, closed_form_gp: bool = True, fake_side: bool = False,
-                 fake_level_cap: int = 0, raw_side: bool = False, raw_grads: bool = True):
+                 fake_level_cap: int = 0, raw_side: bool = False, raw_grads: bool = True, gp_rows: bool = True):
         n = int(example.x.size(0))
         e_cols = 0 if example.edge_index is None else int(example.edge_index.size(1))
         self.n, self.e_cols, self.level_cap = n, e_cols, int(level_cap)
@@ -302,6 +302,11 @@ class CapturedCriticTerms:
         self._params = params
         self.load(example)
         self.x_fake.copy_(self.x_real)
+        # the penalty over its distinct rows (nodes of one level with equal features are one row, see GpRows): the
+        # rows are rebuilt, eagerly, whenever one of the three buffers they are made of has been written since
+        self.gp_rows = GpRows(n, self.level_cap, device) if (closed_form_gp and gp_rows) else None
+        self._rows_key = None
+        self._refresh_rows()
         # the generated side: score of a generated minibatch (the critic's repaired fakes, the generator step's
         # raw graphs - same shapes as the real minibatch) and its gradient, over buffers of its own
         self.fake_side = bool(fake_side)
@@ -324,7 +329,7 @@ class CapturedCriticTerms:
         def compute_gp():
             if closed_form_gp:
                 gp, gn, gp_grads = D.gradient_penalty_closed_form(self.x_real, self.x_fake, self.alpha, self.depth,
-                                                                  plan=self.plan)
+                                                                  plan=self.plan, rows=self.gp_rows)
                 # (scaled after the fact, not through ``grad_scale``: the same roundings as lambda * autograd's
                 #  gradient - Adam turns a last-bit difference in a near-zero gradient element into a full step)
                 scaled = dict(zip([p for p in params if p in gp_grads],
@@ -452,9 +457,18 @@ class CapturedCriticTerms:
         if ps:
             torch._foreach_add_([p.grad for p in ps], gs, alpha=sign)
 
+    def _refresh_rows(self) -> None:
+        if self.gp_rows is None:
+            return
+        key = (self.x_real._version, self.x_fake._version, self.depth._version)      # (every write is a torch copy)
+        if key != self._rows_key:
+            self.gp_rows.rebuild(self.x_real, self.x_fake, self.plan)
+            self._rows_key = key
+
     def replay_gp(self, alpha: torch.Tensor) -> None:
         """The penalty term between the real minibatch and the generated one of the last ``load_generated``."""
         self.alpha.copy_(alpha.reshape(1, 1))
+        self._refresh_rows()
         if self.graph_gp is not None:
             self.graph_gp.replay()
         else:
@@ -595,6 +609,8 @@ class Trainer:
         # one launch per critic iteration for zero_grad + the three gradient sums + Adam (FusedCriticUpdate) whenever
         # all three terms of the iteration are recorded and no gradient exchange stands between them and the update
         self.fused_update = not bool(getattr(args, "no_fused_update", False))
+        # the recorded penalty term over its distinct rows (same numbers up to the order of the sums)
+        self.gp_rows = not bool(getattr(args, "gp_all_nodes", False))
         self._d_updates = 0      # updates opt_D has made (its step counters hold the same number)
         self._fake_caps: Dict[tuple, int] = {}   # by minibatch shape: level cap the generated side was found to need
         self.marks: Optional[list] = None   # tuning aid: [(label, event on the main stream, host time)] of the last step
@@ -660,7 +676,7 @@ class Trainer:
                                     closed_form_gp=self.closed_form_gp, fake_side=fake_side,
                                     fake_level_cap=self._fake_caps.get(key, 0),
                                     raw_side=fake_side and self.overlap_fakes and self.use_sets,
-                                    raw_grads=not self.skip_unused_backward)
+                                    raw_grads=not self.skip_unused_backward, gp_rows=self.gp_rows)
         self.captures += 1
         self._captured[key] = terms
         if len(self._captured) > 4:       # every entry pins the activations of one minibatch shape
@@ -1210,6 +1226,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-fused-update", dest="no_fused_update", action="store_true",
                    help="zero the critic's gradients, add the recorded terms' gradients and step its optimizer as separate "
                         "launches instead of one")
+    p.add_argument("--gp-all-nodes", dest="gp_all_nodes", action="store_true",
+                   help="run the recorded gradient-penalty term over every node instead of over the distinct rows "
+                        "(nodes of one level with equal features are one row with a multiplicity)")
     p.add_argument("--skip-unused-backward", dest="skip_unused_backward", action="store_true",
                    help="leave out the backward pass of the generator step: it only reaches the critic's gradients, which "
                         "are zeroed before their next use (weights, metrics and samples are unchanged)")

@@ -203,7 +203,7 @@ def test_generated_side_deeper_than_its_recording_is_scored_eagerly_then_recorde
 
 @pytest.mark.parametrize("name", ["bs1", "bs3"])
 @pytest.mark.parametrize("mode", ["hip_graph", "hip_graph_eager_fakes", "eager", "autograd_gp", "skip_unused",
-                                  "eager_skip_unused", "separate_update"])
+                                  "eager_skip_unused", "separate_update", "gp_all_nodes"])
 def test_training_follows_reference_run(name, mode):
     """A whole ``train(args)`` run recorded from the reference's own train.py (tests/golden/make_golden_critic.py;
     its attention layer is the restated one): the same dataset, initial critic, draws and raw generator outputs
@@ -220,7 +220,9 @@ def test_training_follows_reference_run(name, mode):
              "eager_skip_unused": ["--no-graph-capture", "--skip-unused-backward"],
              # zero_grad, the gradient sums and torch's own Adam as separate launches instead of aig_adam_sum3: the
              # two forms differ in last bits, both follow the recorded run to the same bound
-             "separate_update": ["--no-fused-update"]}[mode]
+             "separate_update": ["--no-fused-update"],
+             # the recorded penalty term over every node instead of over its distinct rows (the default)
+             "gp_all_nodes": ["--gp-all-nodes"]}[mode]
     args = build_parser().parse_args(["--dataset-dir", "unused"] + run.argv + extra)
     tr = Trainer(args, mn, me, DEV)
     tr.G.load_state_dict(gen_state())

@@ -1,5 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 400 python -u -m pytest tests/test_discriminator_gpu.py -x -q -m gpu --timeout 180 --timeout-method thread -p no:cacheprovider -k "gradient_penalty or closed_form" > gpurun_out/r3_gp_tests.log 2>&1; rc=$?
-tail -30 gpurun_out/r3_gp_tests.log
-exit $rc
+timeout -k 10 900 python -u -m pytest tests/test_discriminator_gpu.py tests/test_train_gpu.py tests/test_parallel_gpu.py -x -q -m gpu --timeout 300 --timeout-method thread -p no:cacheprovider > gpurun_out/r3_gp_tests.log 2>&1; rc=$?
+tail -12 gpurun_out/r3_gp_tests.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r3_bench_e.json 2> gpurun_out/r3_bench_e.err || { tail -5 gpurun_out/r3_bench_e.err; exit 1; }
+cut -c1-330 gpurun_out/r3_bench_e.json
