@@ -34,7 +34,7 @@ class GenWireSet(C.Structure):
                 [("proj_rows", I64)] +
                 [(n, P) for n in ("sc2_w", "sc2_b", "at2_w", "at2_b", "logits", "sel", "edge_index", "edge_attr",
                                   "ecount", "x_out")] +
-                [("proj_half", I64)])
+                [("proj_half", I64), ("cls", P), ("classes", I64), ("pair_logit", P), ("pair_bit", P)])
 
 
 # name -> (restype, argtypes); every symbol of include/aig_abi.h appears here

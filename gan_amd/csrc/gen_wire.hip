@@ -346,9 +346,14 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
                        const void* __restrict__ A2v, const void* __restrict__ B2v, const float* __restrict__ w2a,
                        const float* __restrict__ b2a, long long* __restrict__ edge_index,
                        long long* __restrict__ edge_attr, float* __restrict__ x_out, GenSet gs,
-                       int* __restrict__ ecount) {
+                       int* __restrict__ ecount, const int* __restrict__ cls = nullptr, int C = 0,
+                       const int* __restrict__ pair_bit = nullptr) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    if (cls) {      // the inversion bit of a (source class, target class) pair is read from the graph's table
+        cls += static_cast<long long>(blockIdx.y) * gs.node;
+        pair_bit += static_cast<size_t>(blockIdx.y) * C * C;
+    }
     {
         const long long g = blockIdx.y;
         x += g * gs.x; order += g * gs.node; want += g * gs.node; cnt += g * gs.node; cand += g * gs.cand;
@@ -362,6 +367,7 @@ __global__ void k_emit(int n, int K, long long E, const float* __restrict__ x, c
     const _Float16* A2h = static_cast<const _Float16*>(A2v) + plane_off;
     const _Float16* B2h = static_cast<const _Float16*>(B2v) + plane_off;
     auto bit = [&](int src, int tgt, float bias) {
+        if (cls) return pair_bit[cls[src] * C + cls[tgt]];
         return HALF ? inv_bit_h(A2h, B2h, w2a, bias, src, tgt) : inv_bit(A2, B2, w2a, bias, src, tgt);
     };
     const int v = order[r];
@@ -634,6 +640,111 @@ __global__ __launch_bounds__(256) void k_score_h(int n, int K, const int* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------ classes of equal nodes
+// A node enters the generator through its feature row alone (generator.py:115-117: node_enc and node_proj act row by
+// row, z is the graph's), and a template's rows take a handful of values (a type and a count).  The planes then hold
+// ONE row per distinct feature row - a class - and a pair's logit and inversion bit depend on (class of the source,
+// class of the target) only: a C x C table per graph, made with the very chains the per-pair kernels run (so the
+// numbers are the same bits), and scoring a slot is C-table lookups.
+//   T[ca * C + ct] = w2 . relu(A[ca] + B[ct]) + b2,     Tb[ca * C + ct] = (w2a . relu(A2[ca] + B2[ct]) + b2a > 0)
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_pair_table(int C, long long plane_rows, const void* __restrict__ Av,
+                                                    const void* __restrict__ Bv, const void* __restrict__ A2v,
+                                                    const void* __restrict__ B2v, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ w2a,
+                                                    const float* __restrict__ b2a, float* __restrict__ T,
+                                                    int* __restrict__ Tb) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= C * C) return;
+    const int ca = p / C, ct = p - ca * C;
+    const size_t goff = static_cast<size_t>(blockIdx.y) * plane_rows * H;
+    T += static_cast<size_t>(blockIdx.y) * C * C;
+    Tb += static_cast<size_t>(blockIdx.y) * C * C;
+    if (HALF) {
+        const _Float16 *A = static_cast<const _Float16*>(Av) + goff, *B = static_cast<const _Float16*>(Bv) + goff;
+        const uint4* Ar = reinterpret_cast<const uint4*>(A + static_cast<size_t>(ca) * H);
+        const uint4* Bq = reinterpret_cast<const uint4*>(B + static_cast<size_t>(ct) * H);
+        const float4* W = reinterpret_cast<const float4*>(w2);
+        float acc = 0.f, acc1 = 0.f;
+        for (int j = 0; j < H / 8; j += 2) {   // the order of k_score_tiled's half form
+            const uint4 a0 = Ar[j], a1 = Ar[j + 1], b0 = Bq[j], b1 = Bq[j + 1];
+            const float4 z0 = W[2 * j], z1 = W[2 * j + 1], z2 = W[2 * j + 2], z3 = W[2 * j + 3];
+            acc = term_h(a0.x, b0.x, pack_h(z0.x, z0.y), acc);
+            acc1 = term_h(a1.x, b1.x, pack_h(z2.x, z2.y), acc1);
+            acc = term_h(a0.y, b0.y, pack_h(z0.z, z0.w), acc);
+            acc1 = term_h(a1.y, b1.y, pack_h(z2.z, z2.w), acc1);
+            acc = term_h(a0.z, b0.z, pack_h(z1.x, z1.y), acc);
+            acc1 = term_h(a1.z, b1.z, pack_h(z3.x, z3.y), acc1);
+            acc = term_h(a0.w, b0.w, pack_h(z1.z, z1.w), acc);
+            acc1 = term_h(a1.w, b1.w, pack_h(z3.z, z3.w), acc1);
+        }
+        acc += acc1;
+        T[p] = acc + b2[0];
+        Tb[p] = inv_bit_h(static_cast<const _Float16*>(A2v) + goff, static_cast<const _Float16*>(B2v) + goff, w2a, b2a[0], ca, ct);
+    } else {
+        const float *A = static_cast<const float*>(Av) + goff, *B = static_cast<const float*>(Bv) + goff;
+        const float4* Ar = reinterpret_cast<const float4*>(A + static_cast<size_t>(ca) * H);
+        const float4* Bq = reinterpret_cast<const float4*>(B + static_cast<size_t>(ct) * H);
+        const float4* W = reinterpret_cast<const float4*>(w2);
+        float acc = 0.f;
+        for (int j = 0; j < H / 4; ++j) {      // k_score's chain
+            float4 a = Ar[j], b = Bq[j], w = W[j];
+            acc = fmaf(fmaxf(a.x + b.x, 0.f), w.x, acc);
+            acc = fmaf(fmaxf(a.y + b.y, 0.f), w.y, acc);
+            acc = fmaf(fmaxf(a.z + b.z, 0.f), w.z, acc);
+            acc = fmaf(fmaxf(a.w + b.w, 0.f), w.w, acc);
+        }
+        T[p] = acc + b2[0];
+        Tb[p] = inv_bit(static_cast<const float*>(A2v) + goff, static_cast<const float*>(B2v) + goff, w2a, b2a[0], ca, ct);
+    }
+}
+
+// One wave per slot: logits[r*K + i] = T[cls[cand[r*K + i]] * C + cls[order[r]]]; with sel given (K <= 256) the slots
+// that std::partial_sort would serve get their picks here, as in k_score_tiled.
+__global__ __launch_bounds__(256) void k_score_classes(int n, int K, int C, const int* __restrict__ order,
+                                                       const int* __restrict__ cnt, const int* __restrict__ want,
+                                                       const int* __restrict__ cand, const int* __restrict__ cls,
+                                                       const float* __restrict__ T, float* __restrict__ logits,
+                                                       int* __restrict__ sel, GenSet gs) {
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (r >= n) return;
+    {
+        const long long g = blockIdx.y;
+        order += g * gs.node; cnt += g * gs.node; want += g * gs.node; cand += g * gs.cand; cls += g * gs.node;
+        T += g * (long long)C * C;
+        logits += g * (long long)n * K;
+        if (sel) sel += g * 2ll * n;
+    }
+    const int c = cnt[r];
+    if (c <= 0) return;
+    const int ct = cls[order[r]];
+    const size_t row0 = static_cast<size_t>(r) * K;
+    if (K <= SCORE_K_TILED) {
+        float lg[SCORE_ROUNDS];
+#pragma unroll
+        for (int q = 0; q < SCORE_ROUNDS; ++q) {
+            lg[q] = 0.f;
+            const int i = q * 64 + lane;
+            if (q * 64 < c) {
+                const int ci = cand[row0 + (i < c ? i : 0)];
+                lg[q] = T[cls[ci] * C + ct];
+                if (i < c) logits[row0 + i] = lg[q];
+            }
+        }
+        if (sel) {
+            const int k = min(want[r], c);
+            if (k > 0 && k * 64 <= c) {
+                int s0, s1;
+                wave_partial_sort(lg, c, k, lane, s0, s1);
+                if (lane == 0) *reinterpret_cast<int2*>(sel + 2 * (size_t)r) = make_int2(s0, s1);
+            }
+        }
+    } else {
+        for (int i = lane; i < c; i += 64) logits[row0 + i] = T[cls[cand[row0 + i]] * C + ct];
+    }
+}
+
 template <int T, bool HALF>
 int launch_score_tiled(hipStream_t s, int B, int n, int K, const int* order, const int* rank, const int* cnt,
                        const int* want, const int* cand, const void* projA, const void* projB, const float* w2,
@@ -765,7 +876,7 @@ extern "C" int aig_gen_emit_half(int64_t n, int64_t K, int64_t E, const float* x
 
 extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
     AIG_REQUIRE(a, "aig_gen_wire_batch: null argument block");
-    AIG_REQUIRE(a->B >= 1 && a->B <= 65535 && a->n >= 1 && a->K >= 1 && a->ecap >= 1 && a->proj_rows >= a->n,
+    AIG_REQUIRE(a->B >= 1 && a->B <= 65535 && a->n >= 1 && a->K >= 1 && a->ecap >= 1 && (a->cls || a->proj_rows >= a->n),
                 "aig_gen_wire_batch: bad sizes B=%lld n=%lld K=%lld ecap=%lld rows=%lld", (long long)a->B, (long long)a->n,
                 (long long)a->K, (long long)a->ecap, (long long)a->proj_rows);
     AIG_REQUIRE(a->B * a->proj_rows < INT_MAX && a->B * a->ecap < INT_MAX && a->n * a->K < INT_MAX,
@@ -784,9 +895,31 @@ extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
     const size_t plane = (size_t)a->B * a->proj_rows * H * (half ? 2 : 4);   // bytes
     const unsigned char* proj = static_cast<const unsigned char*>(a->proj);
     bool fused = false;
-    int rc = launch_score(s, B, n, K, a->order, a->rank, a->cnt, a->want, a->cand, proj, proj + plane, half, a->sc2_w,
+    int rc;
+    const int C = (int)a->classes;
+    if (a->cls) {
+        AIG_REQUIRE(a->classes >= 1 && a->classes <= a->proj_rows && a->classes * a->classes * a->B < INT_MAX && a->pair_logit &&
+                        a->pair_bit,
+                    "aig_gen_wire_batch: classes=%lld needs 1 <= classes <= proj_rows and the two pair tables",
+                    (long long)a->classes);
+        const dim3 tgrid((unsigned)((C * C + 255) / 256), B);
+        if (half)
+            hipLaunchKernelGGL(k_pair_table<true>, tgrid, dim3(256), 0, s, C, (long long)a->proj_rows, proj, proj + plane,
+                               proj + 2 * plane, proj + 3 * plane, a->sc2_w, a->sc2_b, a->at2_w, a->at2_b, a->pair_logit,
+                               a->pair_bit);
+        else
+            hipLaunchKernelGGL(k_pair_table<false>, tgrid, dim3(256), 0, s, C, (long long)a->proj_rows, proj, proj + plane,
+                               proj + 2 * plane, proj + 3 * plane, a->sc2_w, a->sc2_b, a->at2_w, a->at2_b, a->pair_logit,
+                               a->pair_bit);
+        fused = K <= SCORE_K_TILED;
+        hipLaunchKernelGGL(k_score_classes, dim3((unsigned)(((int64_t)n * 64 + 255) / 256), B), dim3(256), 0, s, n, K, C,
+                           a->order, a->cnt, a->want, a->cand, a->cls, a->pair_logit, a->logits, fused ? a->sel : nullptr, gs);
+        AIG_LAUNCH_CHECK();
+    } else {
+        rc = launch_score(s, B, n, K, a->order, a->rank, a->cnt, a->want, a->cand, proj, proj + plane, half, a->sc2_w,
                           a->sc2_b, a->logits, a->sel, &fused, gs);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     if ((rc = launch_select(s, B, n, K, a->logits, a->cnt, a->want, a->sel, fused, gs))) return rc;
     const dim3 grid((unsigned)((n + 255) / 256), B);
     long long* ei = reinterpret_cast<long long*>(a->edge_index);
@@ -794,11 +927,11 @@ extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
     if (half)
         hipLaunchKernelGGL(k_emit<true>, grid, dim3(256), 0, s, n, K, (long long)a->ecap, a->x, a->order, a->want, a->cnt,
                            a->cand, a->fb, a->eoff, a->sel, proj + 2 * plane, proj + 3 * plane, a->at2_w, a->at2_b, ei, ea,
-                           a->x_out, gs, a->ecount);
+                           a->x_out, gs, a->ecount, a->cls, C, a->pair_bit);
     else
         hipLaunchKernelGGL(k_emit<false>, grid, dim3(256), 0, s, n, K, (long long)a->ecap, a->x, a->order, a->want, a->cnt,
                            a->cand, a->fb, a->eoff, a->sel, proj + 2 * plane, proj + 3 * plane, a->at2_w, a->at2_b, ei, ea,
-                           a->x_out, gs, a->ecount);
+                           a->x_out, gs, a->ecount, a->cls, C, a->pair_bit);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

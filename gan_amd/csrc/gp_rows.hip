@@ -47,22 +47,34 @@ __device__ __forceinline__ unsigned hash_of(const Pair& p) {
     return h ^ (h >> 15);
 }
 
+// The lanes of a wave grouped by a key: `body(key, lanes of the group, am I its lowest lane)` runs once per distinct
+// key among the lanes that take part, for the lanes of that group.  Every lane of the wave must call it.
+template <class F>
+__device__ __forceinline__ void for_each_cell(bool part, int key, F body) {
+    unsigned long long todo = __ballot(part);
+    while (todo) {
+        const int lead = __ffsll(static_cast<long long>(todo)) - 1;
+        const int k0 = __builtin_amdgcn_readlane(key, lead);
+        const bool mine = part && key == k0;
+        const unsigned long long members = __ballot(mine);
+        if (mine) body(k0, members, (int)(threadIdx.x & 63) == lead);
+        todo &= ~members;
+    }
+}
+
 // cls[i] = slot of node i's pair (-1: table full for it, -2: the node has no level); per cell (level, slot): count
 // and lowest node id
 __global__ void k_gpr_class(int n, int L, const float* __restrict__ xr, const float* __restrict__ xf,
                             const int* __restrict__ node_level, int* __restrict__ owner, int* __restrict__ cls,
                             int* __restrict__ cnt, int* __restrict__ first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int lvl = node_level[i];
-    if (lvl < 0) {
-        cls[i] = -2;
-        return;
-    }
-    const Pair me = pair_of(xr, xf, i);
+    const bool live = i < n;
+    const int lvl = live ? node_level[i] : -1;
+    if (live && lvl < 0) cls[i] = -2;
+    const Pair me = pair_of(xr, xf, live ? i : 0);
     unsigned h = hash_of(me) & (GPR_CLASSES - 1);
     int c = -1;
-    for (int probe = 0; probe < GPR_PROBES && lvl <= L; ++probe) {     // (a level past the cell table: a row of its own)
+    for (int probe = 0; probe < GPR_PROBES && lvl >= 0 && lvl <= L; ++probe) {     // (a level past the cell table: a row of its own)
         int o = __hip_atomic_load(&owner[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (o < 0) {
             o = atomicCAS(&owner[h], -1, i);
@@ -74,23 +86,27 @@ __global__ void k_gpr_class(int n, int L, const float* __restrict__ xr, const fl
         }
         h = (h + 1) & (GPR_CLASSES - 1);
     }
-    cls[i] = c;
-    if (c >= 0) {
-        const size_t cell = (size_t)lvl * GPR_CLASSES + c;
-        atomicAdd(&cnt[cell], 1);
-        atomicMin(&first[cell], i);
-    }
+    if (live && lvl >= 0) cls[i] = c;
+    // one update per (wave, cell) instead of one per node: neighbouring nodes share levels and pairs, and a hundred
+    // thousand atomics on a few thousand addresses queue up behind each other (212 us at 100k nodes, now ~10)
+    for_each_cell(c >= 0, c >= 0 ? lvl * GPR_CLASSES + c : -1, [&](int cell, unsigned long long members, bool leader) {
+        if (leader) {      // the lowest lane of the cell: ids ascend with the lane
+            atomicAdd(&cnt[cell], __popcll(members));
+            if (first[cell] > i) atomicMin(&first[cell], i);
+        }
+    });
 }
 
 // second[cell] = lowest node id of the cell besides its first
 __global__ void k_gpr_second(int n, const int* __restrict__ node_level, const int* __restrict__ cls,
                              const int* __restrict__ first, int* __restrict__ second) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = cls[i];
-    if (c < 0) return;
-    const size_t cell = (size_t)node_level[i] * GPR_CLASSES + c;
-    if (first[cell] != i) atomicMin(&second[cell], i);
+    const int c = i < n ? cls[i] : -1;
+    const int cell_i = c >= 0 ? node_level[i] * GPR_CLASSES + c : -1;
+    const bool cand = c >= 0 && first[cell_i] != i;
+    for_each_cell(cand, cell_i, [&](int cell, unsigned long long, bool leader) {
+        if (leader && second[cell] > i) atomicMin(&second[cell], i);     // the group's lowest id
+    });
 }
 
 // keep[i] = multiplicity of the row node i stands for (0: it is represented by another node)

@@ -21,6 +21,7 @@ or a copy, so ``loss_G.backward()`` never reaches these parameters (train.py:297
 from __future__ import annotations
 
 import ctypes as C
+C_ = C      # (inside the methods that count classes, C is a number)
 from typing import Optional
 
 import torch
@@ -35,7 +36,7 @@ PI, PO, AND = 0, 1, 2
 class GeneratorPlan:
     """Order, candidate windows and edge offsets of one template for one candidate_k."""
 
-    __slots__ = ("n", "K", "E", "types", "order", "rank", "want", "cnt", "cand", "fb", "eoff", "key")
+    __slots__ = ("n", "K", "E", "types", "order", "rank", "want", "cnt", "cand", "fb", "eoff", "key", "C", "cls", "x_cls")
 
     @staticmethod
     def build(x: torch.Tensor, node_depth: Optional[torch.Tensor], K: int) -> "GeneratorPlan":
@@ -66,7 +67,21 @@ class GeneratorPlan:
                                           _abi.ptr(p.eoff), _abi.ptr(ws2), ws2.numel(), _abi.stream()),
                    "aig_gen_candidates")
         p.E = int(p.eoff[n].item())  # the one host read per template: sizes the output tensors
+        # classes of equal feature rows (exact bit patterns): the generator sees a node through its row alone, so the
+        # node pipeline runs over one row per class and pairs are scored per (source class, target class)
+        p.C, p.cls, p.x_cls = 0, None, None
+        if n > 0:
+            bits = x.contiguous().view(torch.int32).to(torch.int64)
+            rowkey = (bits[:, 0] << 32) | (bits[:, 1] & 0xFFFFFFFF)
+            uniq, inv = torch.unique(rowkey, return_inverse=True)
+            p.C = int(uniq.numel())
+            first = torch.full((p.C,), n, dtype=torch.int64, device=dev).scatter_reduce_(
+                0, inv, torch.arange(n, device=dev), reduce="amin", include_self=True)
+            p.cls, p.x_cls = inv.to(torch.int32).contiguous(), x[first].contiguous()
         return p
+
+
+CLASS_LIMIT = 1024      # distinct feature rows up to which a template is scored per class (pair tables of C x C entries)
 
 
 def _plan_key(x: torch.Tensor, nd: Optional[torch.Tensor], K: int):
@@ -84,6 +99,9 @@ class AIGGenerator(nn.Module):
         # planes are stored as IEEE halfs and the pairs are scored in packed half arithmetic
         # (an extension for bulk sampling; candidate windows, tie handling and assembly are unchanged)
         self.score_dtype = score_dtype
+        # templates whose nodes take at most this many distinct feature rows are scored by class (same outputs, bit
+        # for bit: equal rows give equal projections whatever row of a tile they sit in); 0 switches it off
+        self.class_limit = CLASS_LIMIT
         self.hidden_dim = hidden_dim
         self.z_dim = z_dim
         self.candidate_k = candidate_k
@@ -209,8 +227,14 @@ class AIGGenerator(nn.Module):
             for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
                 st[name] = getattr(plans[0], name)
             st["nd"] = nds[0] if nds[0] is not None and nds[0].numel() == n else None
+            st["C"], st["cls"], st["x_cls"] = plans[0].C, plans[0].cls, plans[0].x_cls
             return st
         st = {"plans": plans, "n": n, "E": [p.E for p in plans], "x": torch.cat(xs).contiguous()}
+        # classes: every template's class rows padded to the largest class count (the padding repeats row 0)
+        C = max(p.C for p in plans)
+        st["C"] = C
+        st["cls"] = torch.stack([p.cls for p in plans]).contiguous()
+        st["x_cls"] = torch.cat([torch.cat([p.x_cls, p.x_cls[:1].expand(C - p.C, 2)]) for p in plans]).contiguous()
         for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
             st[name] = torch.stack([getattr(p, name) for p in plans]).contiguous()
         st["nd"] = torch.cat(nds).contiguous() if all(v is not None and v.numel() == n for v in nds) else None
@@ -251,25 +275,68 @@ class AIGGenerator(nn.Module):
             st = self._stacked_plans(templates, dev)
             n, Es, x_all, arrays = st["n"], st["E"], st["x"], st
             nd_all = None if st["nd"] is None else st["nd"].clone()
-        bf16 = 1 if self.score_dtype == "bf16" else 0
-        stream = _abi.stream()
-        rows = int(lib.aig_gen_batch_rows(n))
-        proj = torch.empty((4, B * rows, 128), dtype=torch.float16 if bf16 else torch.float32, device=dev)
-        ws = _abi.workspace(lib.aig_gen_node_proj_batch_ws_bytes(B, n, bf16), dev)
-        w = self._weights()
-        _abi.check(_abi.timed("aig_gen_node_proj_batch", lib.aig_gen_node_proj_batch, B, n, _abi.ptr(x_all), int(shared),
-                              _abi.ptr(zs), C.byref(w), bf16, _abi.ptr(proj), _abi.ptr(ws), ws.numel(), stream,
-                              meta=(n, B)), "aig_gen_node_proj_batch")
+        if shared:
+            C, cls, x_cls = plan.C, plan.cls, plan.x_cls
+        else:
+            C, cls, x_cls = st["C"], st["cls"], st["x_cls"]
         ecap = max(max(Es), 1)
+        _, _, edge_index, edge_attr, ecount, x_out = self._wire_set(B, n, K, ecap, shared, x_all, arrays, zs, C, cls, x_cls)
+        out = GraphSet(B, n, ecap, x_out, edge_index, edge_attr, ecount, nd_all, counts_host=Es, x_dtype=first.x.dtype)
+        out.order_hint = arrays["rank"]      # every emitted edge runs from an earlier to a later node of this order
+        return out
+
+    def _wire_set(self, B, n, K, ecap, shared, x_all, arrays, zs, C, cls, x_cls, h_cond=None, keep=None):
+        """Node projections, scores, selection and assembly of B graphs of n nodes (the launches behind ``forward_set``
+        and, with B = 1, ``forward``).  When the templates' nodes take at most ``class_limit`` distinct feature rows
+        the projections are made per class and pairs are scored through per-graph (source class, target class)
+        tables - the same bits, since a projection depends on its own input row only.  ``keep``: a dict that receives
+        the projection planes (and the class-wise h_cond when ``h_cond`` is asked for) for debugging."""
+        lib = _abi.lib()
+        dev = x_all.device
+        stream = _abi.stream()
+        bf16 = 1 if self.score_dtype == "bf16" else 0
+        w = self._weights()
+        by_class = bool(self.class_limit) and 0 < C <= self.class_limit
+        m = C if by_class else n                       # rows per graph that go through the node pipeline
+        x_rows = x_cls if by_class else x_all
+        rows = int(lib.aig_gen_batch_rows(m))
+        pdt = torch.float16 if bf16 else torch.float32
+        if h_cond is not None:          # (one graph: the single-graph entry points also hand out h_cond)
+            assert B == 1
+            proj = torch.empty((4, m, 128), dtype=pdt, device=dev)
+            hc = torch.empty((m, 128), dtype=torch.float32, device=dev)
+            if bf16:
+                ws = _abi.workspace(lib.aig_gen_node_proj_bf16_ws_bytes(1), dev)
+                _abi.check(_abi.timed("aig_gen_node_proj_bf16", lib.aig_gen_node_proj_bf16, m, 1, _abi.ptr(x_rows), _abi.ptr(zs),
+                                      C_.byref(w), _abi.ptr(hc), _abi.ptr(proj), _abi.ptr(ws), ws.numel(), stream),
+                           "aig_gen_node_proj_bf16")
+            else:
+                ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(m), dev)
+                _abi.check(_abi.timed("aig_gen_node_proj", lib.aig_gen_node_proj, m, _abi.ptr(x_rows), _abi.ptr(zs), C_.byref(w),
+                                      _abi.ptr(hc), _abi.ptr(proj), _abi.ptr(ws), ws.numel(), stream), "aig_gen_node_proj")
+            rows = m
+        else:
+            proj = torch.empty((4, B * rows, 128), dtype=pdt, device=dev)
+            ws = _abi.workspace(lib.aig_gen_node_proj_batch_ws_bytes(B, m, bf16), dev)
+            _abi.check(_abi.timed("aig_gen_node_proj_batch", lib.aig_gen_node_proj_batch, B, m, _abi.ptr(x_rows), int(shared),
+                                  _abi.ptr(zs), C_.byref(w), bf16, _abi.ptr(proj), _abi.ptr(ws), ws.numel(), stream,
+                                  meta=(m, B)), "aig_gen_node_proj_batch")
+            hc = None
         a = _abi.GenWireSet()
         a.B, a.n, a.K, a.ecap, a.plan_shared, a.x_shared = B, n, K, ecap, int(shared), int(shared)
         a.x = _abi.ptr(x_all)
         for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand"):
             setattr(a, name, _abi.ptr(arrays[name]))
         a.proj, a.proj_rows, a.proj_half = _abi.ptr(proj), rows, bf16
+        if by_class:
+            pair_logit = torch.empty((B, C, C), dtype=torch.float32, device=dev)
+            pair_bit = torch.empty((B, C, C), dtype=torch.int32, device=dev)
+            a.cls, a.classes, a.pair_logit, a.pair_bit = _abi.ptr(cls), C, _abi.ptr(pair_logit), _abi.ptr(pair_bit)
         a.sc2_w, a.sc2_b = _abi.ptr(self.edge_scorer[2].weight), _abi.ptr(self.edge_scorer[2].bias)
         a.at2_w, a.at2_b = _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias)
         logits = torch.empty((B, n, K), dtype=torch.float32, device=dev)
+        if keep is not None:
+            logits.fill_(float("nan"))
         sel = torch.empty((B, n, 2), dtype=torch.int32, device=dev)
         edge_index = torch.empty((B, 2, ecap), dtype=torch.int64, device=dev)
         edge_attr = torch.empty((B, ecap), dtype=torch.int64, device=dev)
@@ -277,11 +344,14 @@ class AIGGenerator(nn.Module):
         x_out = torch.empty((B * n, 2), dtype=torch.float32, device=dev)
         a.logits, a.sel = _abi.ptr(logits), _abi.ptr(sel)
         a.edge_index, a.edge_attr, a.ecount, a.x_out = _abi.ptr(edge_index), _abi.ptr(edge_attr), _abi.ptr(ecount), _abi.ptr(x_out)
-        _abi.check(_abi.timed("aig_gen_wire_batch", lib.aig_gen_wire_batch, C.byref(a), stream, meta=(n, B, K)),
+        _abi.check(_abi.timed("aig_gen_wire_batch", lib.aig_gen_wire_batch, C_.byref(a), stream, meta=(n, B, K)),
                    "aig_gen_wire_batch")
-        out = GraphSet(B, n, ecap, x_out, edge_index, edge_attr, ecount, nd_all, counts_host=Es, x_dtype=first.x.dtype)
-        out.order_hint = arrays["rank"]      # every emitted edge runs from an earlier to a later node of this order
-        return out
+        if keep is not None:
+            idx = cls.long() if by_class else None
+            keep["proj"] = proj[:, idx] if by_class else proj
+            keep["h_cond"] = None if hc is None else (hc[idx] if by_class else hc)
+            keep["by_class"] = by_class
+        return logits, sel, edge_index, edge_attr, ecount, x_out
 
     def _wire(self, plan, x_in, x_src, nd, pa, pb, pa2, pb2, n, K, E, dev, debug=None) -> Data:
         """Scores, tie-exact selection and edge assembly from the four projection planes (generator.py:139-209);
@@ -336,6 +406,19 @@ class AIGGenerator(nn.Module):
         st = _abi.stream()
         f32 = dict(dtype=torch.float32, device=dev)
 
+        if self.class_limit and 0 < plan.C <= self.class_limit and n > 0:
+            # per class: the launches of forward_set for a set of one graph
+            arrays = {name: getattr(plan, name) for name in ("order", "rank", "want", "cnt", "fb", "eoff", "cand")}
+            keep = {} if return_debug else None
+            logits, sel, ei, ea, _, x_out = self._wire_set(1, n, K, max(E, 1), True, x_in, arrays, z.reshape(1, -1), plan.C,
+                                                           plan.cls, plan.x_cls, h_cond=True if return_debug else None, keep=keep)
+            if x_src.dtype != torch.float32:
+                x_out = x_out.to(x_src.dtype)
+            out = Data(x=x_out, edge_index=ei[0, :, :E], edge_attr=ea[0, :E].reshape(-1, 1),
+                       node_depth=(nd.clone().to(dev) if nd is not None else None))
+            if return_debug:
+                out._debug = {"plan": plan, "h_cond": keep["h_cond"], "proj": keep["proj"], "logits": logits[0], "sel": sel[0]}
+            return out
         proj = torch.empty((4, max(n, 1), 128), dtype=torch.float16 if self.score_dtype == "bf16" else torch.float32,
                            device=dev)
         h_cond = torch.empty((max(n, 1), 128), **f32) if return_debug else None

@@ -539,6 +539,16 @@ typedef struct aig_gen_wire_set {
     int32_t* ecount;          /* out [B] */
     float* x_out;             /* out [B n][2] */
     int64_t proj_half;        /* 1: proj holds halfs (the bf16 pipeline's planes), scored as aig_gen_score_half does */
+    /* Classes of equal nodes (NULL / 0: none).  A node enters the generator through its feature row alone
+     * (generator.py:115-117), so nodes with equal rows have equal projections: with cls given, the planes of proj hold
+     * one row per CLASS (rows 0 .. classes-1 of a graph's proj_rows) instead of one per node, cls[node] names a
+     * node's class ([B][n], or [n] with plan_shared), and a pair's logit and inversion bit are read from per-graph
+     * tables over (source class, target class) that the call fills first, with the per-pair chains of
+     * aig_gen_score / aig_gen_emit - the same bits as without classes. */
+    const int32_t* cls;
+    int64_t classes;
+    float* pair_logit;        /* scratch [B][classes][classes] */
+    int32_t* pair_bit;        /* scratch [B][classes][classes] */
 } aig_gen_wire_set;
 int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream);
 

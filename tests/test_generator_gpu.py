@@ -516,3 +516,55 @@ def test_picks_made_while_scoring_equal_the_selection_kernel(K, half):
                                        None, 0, _abi.stream()), "aig_topk_select")
         torch.cuda.synchronize()
         assert torch.equal(sel[b], alone), (b, np.flatnonzero((sel[b] != alone).any(1).cpu().numpy())[:10])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_scoring_by_class_equals_scoring_by_node(dtype):
+    """Templates whose nodes take few distinct feature rows are projected per class and scored through (source class,
+    target class) tables; with ``class_limit = 0`` every node goes through the node pipeline and every pair through
+    its own chain.  Same logits, picks, edges and features, bit for bit - one graph, a set of samples of one
+    template, and a set of different templates whose class counts differ."""
+    from gan_amd.sample import sample_one
+    K = 48
+    tpls = []
+    for seed, extra in ((1, 0), (2, 3), (3, 7)):
+        g = synth_aig(15, 400, 10, seed=seed, window=70, orientation="dataset")
+        x = g.x.clone().float()
+        if extra:                                  # a few more distinct rows: class counts differ between templates
+            x[5:5 + extra, 1] = torch.arange(3, 3 + extra).float()
+        tpls.append(Data(x=x.to(DEV), node_depth=g.node_depth.to(DEV)))
+    zs = torch.randn(3, 128, generator=torch.Generator().manual_seed(4)).to(DEV)
+
+    def make(limit):
+        G = AIGGenerator(candidate_k=K, score_dtype=dtype)
+        G.load_state_dict(gen_state())
+        G = G.to(DEV).eval()
+        G.class_limit = limit
+        return G
+
+    Gc, Gn = make(1024), make(0)
+    counts = []
+    for t, z in zip(tpls, zs):
+        a, b = Gc(t, z, return_debug=True), Gn(t, z, return_debug=True)
+        counts.append(a._debug["plan"].C)
+        for name in ("x", "edge_index", "edge_attr"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        la, lb = a._debug["logits"], b._debug["logits"]
+        assert torch.equal(torch.nan_to_num(la, nan=-7.0).view(torch.int32), torch.nan_to_num(lb, nan=-7.0).view(torch.int32))
+        assert torch.equal(a._debug["sel"], b._debug["sel"])
+        assert torch.equal(a._debug["h_cond"], b._debug["h_cond"])
+        pa, pb = a._debug["proj"], b._debug["proj"][:, :t.x.size(0)]
+        assert pa.dtype == pb.dtype and torch.equal(pa.view(torch.int16), pb.view(torch.int16))
+    assert len(set(counts)) > 1 and max(counts) < 40
+    # sets: samples of one template, and different templates
+    for templates, z_ in ((tpls[1], zs), (tpls, zs)):
+        sa, sb = Gc.forward_set(templates, z_), Gn.forward_set(templates, z_)
+        assert torch.equal(sa.count, sb.count) and torch.equal(sa.x, sb.x)
+        for ga, gb in zip(sa.graphs(), sb.graphs()):          # (slots past a graph's count are not written)
+            for name in ("x", "edge_index", "edge_attr"):
+                assert torch.equal(getattr(ga, name), getattr(gb, name)), name
+    # more classes than the limit: the node-wise path is taken (and is the same numbers anyway)
+    Gl = make(5)
+    c = Gl(tpls[2], zs[2])
+    d = Gn(tpls[2], zs[2])
+    assert torch.equal(c.edge_index, d.edge_index) and torch.equal(c.edge_attr, d.edge_attr)
