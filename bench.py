@@ -174,7 +174,8 @@ def kernel_flops(kernel: str, n: int) -> float:
     raise KeyError(kernel)
 
 
-def step_cost_model(n: int, e_real: int, e_fake: int, levels: int, K: int, n_critic: int = 3):
+def step_cost_model(n: int, e_real: int, e_fake: int, levels: int, K: int, n_critic: int = 3, gp_rows: int = 0,
+                    classes: int = 0):
     """Algorithmic HBM bytes and flops of ONE training step on a minibatch of n nodes, itemised: what the step's kernels
     read and write by the algorithm (arrays streamed once per kernel that takes them; gathered rows once per list
     entry), summed over the step's passes.  [n,128] f32 arrays are counted in units of A = 512 n bytes.
@@ -185,7 +186,10 @@ def step_cost_model(n: int, e_real: int, e_fake: int, levels: int, K: int, n_cri
       penalty term (closed-form gradient penalty, n_critic per step): 32 A (20 array reads, 12 writes over its eleven
       row passes, four products and four node-dimension reductions)
       generator pass (2 per step): node pipeline 8 n + 5 A, scoring (K + 127 staged rows of 512 B per 64 targets and
-      4 K bytes of logits per target), selection (4 K per target), emission (~1.5 KB per target)"""
+      4 K bytes of logits per target), selection (4 K per target), emission (~1.5 KB per target)
+    gp_rows > 0: the penalty term runs over that many distinct rows instead of n (plus 64 n bytes to find them, once per
+    step); classes > 0: the generator projects one row per class of equal feature rows and scores a slot by table
+    lookups - 8 K bytes per target (candidate ids read, logits written) + selection + 60 B of emission."""
     A = 512 * n
 
     def edge_pass(e):
@@ -195,10 +199,17 @@ def step_cost_model(n: int, e_real: int, e_fake: int, levels: int, K: int, n_cri
         return b, 3 * 2.0 * 128 * 128 * n
     real_b, real_f = edge_pass(e_real)
     fake_b, fake_f = edge_pass(e_fake)
-    gp_b, gp_f = 32 * A, 9 * 2.0 * 128 * 128 * n           # 4 products + 2 weight gradients over 128 columns (+ small ones)
+    gp_n = gp_rows if gp_rows > 0 else n
+    gp_b, gp_f = 32 * 512 * gp_n, 9 * 2.0 * 128 * 128 * gp_n   # 4 products + 2 weight gradients over 128 columns (+ small ones)
+    if gp_rows > 0:
+        gp_b += 64 * n // n_critic
     targets = n
-    gen_b = 8 * n + 5 * A + targets * ((K + 127) * 512 // 64 + 4 * K) + targets * 4 * K + targets * 1536
-    gen_f = 7 * 2.0 * 128 * 128 * n + 3.0 * 128 * K * targets
+    if classes > 0:
+        gen_b = targets * (8 * K + 4 * K + 60) + classes * 5 * 512
+        gen_f = 7 * 2.0 * 128 * 128 * classes + 3.0 * 128 * classes * classes
+    else:
+        gen_b = 8 * n + 5 * A + targets * ((K + 127) * 512 // 64 + 4 * K) + targets * 4 * K + targets * 1536
+        gen_f = 7 * 2.0 * 128 * 128 * n + 3.0 * 128 * K * targets
     items = {"critic_pass_real": (n_critic, real_b, real_f), "critic_pass_generated": (n_critic + 1, fake_b, fake_f),
              "penalty_term": (n_critic, gp_b, gp_f), "generator_pass": (2, gen_b, gen_f)}
     total_b = sum(c * b for c, b, _ in items.values())
@@ -400,7 +411,11 @@ def bulk_sampling(a, rank, world, dev):
     _abi.timeline.reset()
     _abi.timeline.only = {entry}
     _abi.timeline.enabled = True
-    run([block(a.warmup + a.steps + k) for k in range(2)], in_flight=1)     # (alone on the GPU: one block at a time)
+    # (alone on the GPU, one block at a time, with one row per NODE forced: the timed blocks above project one row per
+    #  class of equal feature rows, a handful per template, which says nothing about the kernel)
+    limit_was, G.class_limit = G.class_limit, 0
+    run([block(a.warmup + a.steps + k) for k in range(2)], in_flight=1)
+    G.class_limit = limit_was
     barrier()
     _abi.timeline.enabled = False
     ms, launches = _abi.timeline.totals_ms().get(entry, (0.0, 0))
@@ -423,6 +438,11 @@ def bulk_sampling(a, rank, world, dev):
         plane_row = 256 if a.score_dtype == "bf16" else 512      # bytes of one plane's row: halfs or f32
         bytes_out = rows * (8 + 4 * plane_row)     # x read, four output rows written
         peak = MFMA_BF16_PEAK_TF if a.score_dtype == "bf16" else MFMA_F32_PEAK_TF
+        plan_c = getattr(tpl.__dict__.get("_gen_plan"), "C", None)
+        out["config"]["classes_of_equal_feature_rows"] = plan_c
+        out["roofline_note"] = ("the timed blocks project one row per class of equal feature rows and score pairs through "
+                                "(class, class) tables; roofline / roofline_mfma are the node-projection kernel's own rates from "
+                                "two extra blocks with one row per node forced (class_limit = 0)")
         out["roofline_mfma"] = {"kernel": f"node projections of one block ({entry})", "bound": "mfma",
                                 "achieved": round(flops / (us * 1e-6) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                                 "frac": round(flops / (us * 1e-6) / 1e12 / peak, 4), "launches": launches,
@@ -733,6 +753,18 @@ def main():
     _abi.timeline.enabled = True
     sample_nodes_per_sec_single = sample_rate(one_at_a_time)
     _abi.timeline.enabled = False
+    # ... with one row per NODE forced: the sampling and training paths project one row per class of equal feature rows
+    # (a handful per template), which says nothing about the kernel
+    _abi.timeline.reset()
+    _abi.timeline.only = {"aig_gen_node_proj"}
+    _abi.timeline.enabled = True
+    limit_was, trainer.G.class_limit = trainer.G.class_limit, 0
+    for _ in range(max(a.sample_iters, 2)):
+        for t in templates:
+            trainer.G(t, draw_z())
+    trainer.G.class_limit = limit_was
+    barrier()
+    _abi.timeline.enabled = False
     tl_proj = _abi.timeline.totals_ms()
     sample_nodes_per_sec_streams = sample_rate(in_flight)
     sample_nodes_per_sec = sample_rate(as_sets, S_set) if S_set > 1 else sample_nodes_per_sec_streams
@@ -829,14 +861,22 @@ def main():
         # the whole step against the memory and the matrix cores: algorithmic bytes / flops of every pass of the step
         # (step_cost_model) over the headline step time
         e_real = edges_rank / max(a.steps, 1) - e_avg if sizes else 0.0
+        # what the penalty term and the generator really ran over in the last step: distinct rows, classes of equal nodes
+        terms_now = next(iter(trainer._captured.values()), None) if getattr(trainer, "_captured", None) else None
+        gp_rows = int(terms_now.gp_rows.n_rows.item()) if terms_now is not None and terms_now.gp_rows is not None else 0
+        plan_cs = [getattr(t.__dict__.get("_gen_plan"), "C", 0) for t in templates]
+        classes = max(plan_cs) if plan_cs and trainer.G.class_limit and 0 < max(plan_cs) <= trainer.G.class_limit else 0
         sb, sf, items = step_cost_model(int(n_avg) if sizes else nodes_per_iter, int(max(e_real, 0)), int(e_avg), top + 1, 64,
-                                        targs.n_critic)
+                                        targs.n_critic, gp_rows=gp_rows, classes=classes)
         step_s = elapsed / a.steps
         roofline_step = {"algorithmic_bytes_per_step": int(sb), "flops_per_step": sf, "achieved": round(sb / step_s / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sb / step_s / 1e9 / HBM_PEAK_GBS, 4),
                          "achieved_TFLOPs": round(sf / step_s / 1e12, 2), "frac_of_f32_matrix_peak": round(sf / step_s / 1e12 / MFMA_F32_PEAK_TF, 4),
-                         "items": items,
+                         "items": items, "penalty_rows": gp_rows or None, "generator_classes": classes or None,
                          "note": "bytes and flops of the step's passes by the algorithm (bench.py: step_cost_model) over ms_per_step; "
+                                 "the penalty term is counted over its distinct rows and the generator over its classes of equal "
+                                 "feature rows (penalty_rows, generator_classes: what the last step ran over) - bytes the reference's "
+                                 "formulation would move over every node are not credited; "
                                  "the step is the sum of its wide kernels' durations, each at 0.4-0.9 of its own bound"}
         # the dense contraction of the path: node projections of the generator (7 products of
         # [n,128]x[128,128] per sample) on the f32 matrix cores, flops executed / event time
@@ -845,7 +885,9 @@ def main():
         if n_proj:
             flops = 7 * 2.0 * 128 * 128 * nodes_per_iter * (n_proj / max(len(templates), 1))   # one launch per template
             tf = flops / (ms_proj * 1e-3) / 1e12
-            mfma = {"kernel": "k_node_mlp3 + k_node_proj4 (entry point aig_gen_node_proj)", "bound": "mfma", "achieved": round(tf, 1),
+            mfma = {"kernel": "k_node_mlp3 + k_node_proj4 (entry point aig_gen_node_proj) with one row per node forced "
+                              "(class_limit = 0): the kernel's own rate, outside the timed region - the step and the sampling "
+                              "rates project one row per class of equal feature rows", "bound": "mfma", "achieved": round(tf, 1),
                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                     "launches": n_proj, "avg_launch_us": round(ms_proj * 1e3 / n_proj, 2)}
             if measured_peaks().get("mfma_f32_TFs"):

@@ -641,13 +641,24 @@ class AIGDiscriminator(nn.Module):
         level plan of ``node_depth`` the caller already holds (else it is looked up / built here); ``grad_scale``
         multiplies every returned gradient (the loss weights the penalty by gp_lambda).  ``rows``: a ``GpRows``
         whose last ``rebuild`` was made for these very features and levels - the computation then runs over its
-        distinct rows (same numbers up to the order of the sums); ``x_real`` / ``x_fake`` / ``plan`` are not read."""
+        distinct rows (same numbers up to the order of the sums); ``x_real`` / ``x_fake`` / ``plan`` are not read.
+        ``rows=True``: the rows are built here, for this call."""
         lib = _abi.lib()
         dev = x_real.device
         n = int(x_real.size(0))
         f32 = dict(dtype=torch.float32, device=dev)
         xr, xf = x_real.float().contiguous(), x_fake.float().contiguous()
         n_dev = None
+        if rows is True:        # rows of this very call, in buffers kept per (n, level capacity)
+            if plan is None:
+                plan = self.level_plan(node_depth, n, dev)
+            cache = self.__dict__.setdefault("_gp_rows_cache", {})
+            rows = cache.get((n, plan.L))
+            if rows is None:
+                if len(cache) >= 4:
+                    cache.pop(next(iter(cache)))
+                rows = cache[(n, plan.L)] = GpRows(n, plan.L, dev)
+            rows.rebuild(xr, xf, plan)
         if rows is not None:
             if rows.n != n:
                 raise _abi.AigAbiError("gradient_penalty_closed_form: rows were planned for another node count")

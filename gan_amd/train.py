@@ -966,7 +966,8 @@ class Trainer:
                         gap = D_real_mean - D_fake_mean
                         if self.closed_form_gp:
                             gp_term, grad_norm, gp_grads = D.gradient_penalty_closed_form(
-                                real_padded.x, fake_padded.x, self.draw_alpha(), real_padded.node_depth)
+                                real_padded.x, fake_padded.x, self.draw_alpha(), real_padded.node_depth,
+                                rows=True if self.gp_rows else None)
                             (D_fake_mean - D_real_mean).backward()
                             for p_, g_ in gp_grads.items():
                                 p_.grad = a.gp_lambda * g_ if p_.grad is None else p_.grad.add_(g_, alpha=a.gp_lambda)
