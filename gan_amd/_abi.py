@@ -69,7 +69,7 @@ SIGNATURES = {
     "aig_level_pool_bwd_adj_ws_bytes": (SZ, [I64]),
     "aig_level_pool_bwd_adj": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_gp_rows_ws_bytes": (SZ, [I64, I64]),
-    "aig_gp_rows": (INT, [I64, I64] + [P] * 10 + [P, SZ, P]),
+    "aig_gp_rows": (INT, [I64, I64, I64] + [P] * 12 + [P, SZ, P]),
     "aig_gp_forward": (INT, [I64, P] + [P] * 10 + [P]),
     "aig_gp_scalars": (INT, [P, C.c_float, P, P]),
     "aig_adam_chunk_elems": (INT, []),

@@ -47,6 +47,12 @@ __device__ __forceinline__ unsigned hash_of(const Pair& p) {
     return h ^ (h >> 15);
 }
 
+// a node's level in the plan: its entry of node_level, or 0 for every node when the plan's header says that no node
+// carried a valid depth (all nodes are then pooled in one level, discriminator.py:68-72)
+__device__ __forceinline__ int level_of(const int* __restrict__ node_level, const int* __restrict__ meta, int i) {
+    return (meta && (meta[2] & 1)) ? 0 : node_level[i];
+}
+
 // The lanes of a wave grouped by a key: `body(key, lanes of the group, am I its lowest lane)` runs once per distinct
 // key among the lanes that take part, for the lanes of that group.  Every lane of the wave must call it.
 template <class F>
@@ -64,14 +70,19 @@ __device__ __forceinline__ void for_each_cell(bool part, int key, F body) {
 
 // cls[i] = slot of node i's pair (-1: table full for it, -2: the node has no level); per cell (level, slot): count
 // and lowest node id
-__global__ void k_gpr_class(int n, int L, const float* __restrict__ xr, const float* __restrict__ xf,
+// Nodes are taken in the order of the plan's `perm` (by level, ids ascending within a level): the lanes of a wave then
+// share a level or two and a handful of cells, so the per-wave merging of the atomics below has something to merge
+// (in node order a wave of the 100k-node workload holds sixty different cells and the kernel took 120 us).
+__global__ void k_gpr_class(int nvalid, const int* __restrict__ meta, const int* __restrict__ perm, int L,
+                            const float* __restrict__ xr, const float* __restrict__ xf,
                             const int* __restrict__ node_level, int* __restrict__ owner, int* __restrict__ cls,
                             int* __restrict__ cnt, int* __restrict__ first) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    const int lvl = live ? node_level[i] : -1;
-    if (live && lvl < 0) cls[i] = -2;
-    const Pair me = pair_of(xr, xf, live ? i : 0);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (meta) nvalid = min(nvalid, meta[1]);      // (nodes with a level: the plan's header)
+    const bool live = t < nvalid;
+    const int i = live ? perm[t] : 0;
+    const int lvl = live ? level_of(node_level, meta, i) : -1;
+    const Pair me = pair_of(xr, xf, i);
     unsigned h = hash_of(me) & (GPR_CLASSES - 1);
     int c = -1;
     for (int probe = 0; probe < GPR_PROBES && lvl >= 0 && lvl <= L; ++probe) {     // (a level past the cell table: a row of its own)
@@ -86,7 +97,7 @@ __global__ void k_gpr_class(int n, int L, const float* __restrict__ xr, const fl
         }
         h = (h + 1) & (GPR_CLASSES - 1);
     }
-    if (live && lvl >= 0) cls[i] = c;
+    if (live) cls[i] = c;
     // one update per (wave, cell) instead of one per node: neighbouring nodes share levels and pairs, and a hundred
     // thousand atomics on a few thousand addresses queue up behind each other (212 us at 100k nodes, now ~10)
     for_each_cell(c >= 0, c >= 0 ? lvl * GPR_CLASSES + c : -1, [&](int cell, unsigned long long members, bool leader) {
@@ -98,11 +109,14 @@ __global__ void k_gpr_class(int n, int L, const float* __restrict__ xr, const fl
 }
 
 // second[cell] = lowest node id of the cell besides its first
-__global__ void k_gpr_second(int n, const int* __restrict__ node_level, const int* __restrict__ cls,
+__global__ void k_gpr_second(int nvalid, const int* __restrict__ meta, const int* __restrict__ perm,
+                             const int* __restrict__ node_level, const int* __restrict__ cls,
                              const int* __restrict__ first, int* __restrict__ second) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = i < n ? cls[i] : -1;
-    const int cell_i = c >= 0 ? node_level[i] * GPR_CLASSES + c : -1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (meta) nvalid = min(nvalid, meta[1]);
+    const int i = t < nvalid ? perm[t] : 0;
+    const int c = t < nvalid ? cls[i] : -1;
+    const int cell_i = c >= 0 ? level_of(node_level, meta, i) * GPR_CLASSES + c : -1;
     const bool cand = c >= 0 && first[cell_i] != i;
     for_each_cell(cand, cell_i, [&](int cell, unsigned long long, bool leader) {
         if (leader && second[cell] > i) atomicMin(&second[cell], i);     // the group's lowest id
@@ -110,17 +124,18 @@ __global__ void k_gpr_second(int n, const int* __restrict__ node_level, const in
 }
 
 // keep[i] = multiplicity of the row node i stands for (0: it is represented by another node)
-__global__ void k_gpr_keep(int n, const int* __restrict__ node_level, const int* __restrict__ cls,
+__global__ void k_gpr_keep(int n, const int* __restrict__ meta, const int* __restrict__ node_level, const int* __restrict__ cls,
                            const int* __restrict__ cnt, const int* __restrict__ first, const int* __restrict__ second,
                            int* __restrict__ mult, int* __restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int c = cls[i];
+    const int lvl = level_of(node_level, meta, i);
+    const int c = lvl < 0 ? -2 : cls[i];      // (nodes without a level were never classified)
     int m = 0;
     if (c == -1) {
         m = 1;
     } else if (c >= 0) {
-        const size_t cell = (size_t)node_level[i] * GPR_CLASSES + c;
+        const size_t cell = (size_t)lvl * GPR_CLASSES + c;
         if (first[cell] == i) m = 1;
         else if (second[cell] == i) m = cnt[cell] - 1;
     }
@@ -129,7 +144,7 @@ __global__ void k_gpr_keep(int n, const int* __restrict__ node_level, const int*
 }
 
 // rows in node order; everything past the last row gets neutral values (no level, weight 0)
-__global__ void k_gpr_emit(int n, const float* __restrict__ xr, const float* __restrict__ xf,
+__global__ void k_gpr_emit(int n, const int* __restrict__ meta, const float* __restrict__ xr, const float* __restrict__ xf,
                            const int* __restrict__ node_level, const float* __restrict__ w, const int* __restrict__ mult,
                            const int* __restrict__ pos, float* __restrict__ xr_rows, float* __restrict__ xf_rows,
                            long long* __restrict__ depth_rows, float* __restrict__ w_fwd, float* __restrict__ w_bwd,
@@ -143,7 +158,7 @@ __global__ void k_gpr_emit(int n, const float* __restrict__ xr, const float* __r
         const int r = pos[i];
         reinterpret_cast<float2*>(xr_rows)[r] = reinterpret_cast<const float2*>(xr)[i];
         reinterpret_cast<float2*>(xf_rows)[r] = reinterpret_cast<const float2*>(xf)[i];
-        depth_rows[r] = node_level[i];
+        depth_rows[r] = level_of(node_level, meta, i);
         const float wi = w[i];
         w_fwd[r] = (float)m * wi;
         w_bwd[r] = sqrtf((float)m) * wi;
@@ -174,11 +189,12 @@ extern "C" size_t aig_gp_rows_ws_bytes(int64_t n, int64_t L) {
     return 4 * align_up(N * 4) + 3 * align_up(cells * 4) + align_up(GPR_CLASSES * 4) + align_up(scan_bytes(n)) + 256;
 }
 
-extern "C" int aig_gp_rows(int64_t n, int64_t L, const float* x_real, const float* x_fake, const int32_t* node_level,
-                           const float* w, float* xr_rows, float* xf_rows, int64_t* depth_rows, float* w_fwd,
+extern "C" int aig_gp_rows(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const int32_t* perm,
+                           const float* x_real, const float* x_fake, const int32_t* node_level, const float* w, float* xr_rows, float* xf_rows, int64_t* depth_rows, float* w_fwd,
                            float* w_bwd, int32_t* n_rows, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX && L >= 0 && (L + 1) * (int64_t)GPR_CLASSES < INT_MAX, "aig_gp_rows: bad sizes n=%lld L=%lld",
                 (long long)n, (long long)L);
+    AIG_REQUIRE(nvalid >= 0 && nvalid <= n && perm, "aig_gp_rows: the full plan's perm and its number of nodes with a level are needed");
     AIG_REQUIRE(x_real && x_fake && node_level && w && xr_rows && xf_rows && depth_rows && w_fwd && w_bwd && n_rows && ws,
                 "aig_gp_rows: null pointer");
     if (ws_bytes < aig_gp_rows_ws_bytes(n, L)) return fail(AIG_EWORKSPACE, "aig_gp_rows: workspace too small");
@@ -200,12 +216,13 @@ extern "C" int aig_gp_rows(int64_t n, int64_t L, const float* x_real, const floa
     AIG_HIP_CHECK(fill_words(second, 0x7fffffffu, cells * 4, s));
     AIG_HIP_CHECK(fill_words(owner, 0xffffffffu, GPR_CLASSES * 4, s));
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(k_gpr_class, grid, block, 0, s, (int)n, (int)L, x_real, x_fake, node_level, owner, cls, cnt, first);
-    hipLaunchKernelGGL(k_gpr_second, grid, block, 0, s, (int)n, node_level, cls, first, second);
-    hipLaunchKernelGGL(k_gpr_keep, grid, block, 0, s, (int)n, node_level, cls, cnt, first, second, mult, flag);
+    hipLaunchKernelGGL(k_gpr_class, grid, block, 0, s, (int)nvalid, lvl_meta, perm, (int)L, x_real, x_fake, node_level, owner, cls,
+                       cnt, first);
+    hipLaunchKernelGGL(k_gpr_second, grid, block, 0, s, (int)nvalid, lvl_meta, perm, node_level, cls, first, second);
+    hipLaunchKernelGGL(k_gpr_keep, grid, block, 0, s, (int)n, lvl_meta, node_level, cls, cnt, first, second, mult, flag);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(rocprim::exclusive_scan(temp, sb, flag, pos, 0, (size_t)n, rocprim::plus<int>(), s));
-    hipLaunchKernelGGL(k_gpr_emit, grid, block, 0, s, (int)n, x_real, x_fake, node_level, w, mult, pos, xr_rows, xf_rows,
+    hipLaunchKernelGGL(k_gpr_emit, grid, block, 0, s, (int)n, lvl_meta, x_real, x_fake, node_level, w, mult, pos, xr_rows, xf_rows,
                        reinterpret_cast<long long*>(depth_rows), w_fwd, w_bwd, n_rows);
     AIG_LAUNCH_CHECK();
     return AIG_OK;

@@ -172,7 +172,8 @@ class GpRows:
             raise _abi.AigAbiError("GpRows.rebuild: sizes differ from the planned ones")
         xr, xf = x_real.float().contiguous(), x_fake.float().contiguous()
         ws = _abi.workspace(lib.aig_gp_rows_ws_bytes(self.n, self.L), xr.device)
-        _abi.check(lib.aig_gp_rows(self.n, self.L, _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(plan.node_level), _abi.ptr(plan.w),
+        _abi.check(lib.aig_gp_rows(self.n, plan.nvalid, self.L, _abi.ptr(plan.meta), _abi.ptr(plan.perm), _abi.ptr(xr), _abi.ptr(xf),
+                                   _abi.ptr(plan.node_level), _abi.ptr(plan.w),
                                    _abi.ptr(self.x_real), _abi.ptr(self.x_fake), _abi.ptr(self.depth), _abi.ptr(self.w_fwd),
                                    _abi.ptr(self.w_bwd), _abi.ptr(self.n_rows), _abi.ptr(ws), ws.numel(), _abi.stream()),
                    "aig_gp_rows")

@@ -783,6 +783,8 @@ class Trainer:
                 zs_once = [self.draw_z() for _ in templates]
                 if split:
                     raw_fakes_set = G.forward_set(templates, torch.stack(zs_once))
+                    raw_ready = torch.cuda.Event()
+                    raw_ready.record()
                     self._probe("side: fakes generated")
             if split and not real_first:
                 # The host enqueues the real side right behind the generator pass (half a millisecond of GPU
@@ -798,6 +800,21 @@ class Trainer:
                     features_ready = torch.cuda.Event()
                     features_ready.record()
                     self._probe("side: fakes repaired")
+            # The generated graphs' levels only need the raw graphs (breadth-first levels over their cleaned edges):
+            # one workgroup sweeps for a quarter of a millisecond.  With the real side replayed up front, the first
+            # stream would wait for the repair next - it takes the sweep instead (enqueued after the repair's launches:
+            # the real-side replay in front of it gives the host the time), and the second stream goes from the
+            # repair straight to the padded edges and edge lists.
+            depth_early = depth_ready = None
+            if split and real_replayed and terms.fake_side:
+                main_stream.wait_event(raw_ready)
+                depth_early = clean_depth_set(raw_fakes_set)
+                depth_early.record_stream(fakes_stream)
+                depth_ready = torch.cuda.Event()
+                depth_ready.record(main_stream)
+                self._probe("main: generated graphs' levels")
+            with torch.cuda.stream(fakes_stream):
+                if split:
 
                     def finish_fakes():
                         # the level walk behind the fakes' depths and the padded minibatch: enqueued by the first
@@ -812,7 +829,11 @@ class Trainer:
                             # the first stream's real-side and penalty terms, instead of in front of its replay
                             if terms.fake_side:
                                 terms.fk.load_edges(edges[0], edges[1])
-                            corr_set.node_depth = clean_depth_set(raw_fakes_set)
+                            if depth_early is not None:
+                                fakes_stream.wait_event(depth_ready)
+                                corr_set.node_depth = depth_early
+                            else:
+                                corr_set.node_depth = clean_depth_set(raw_fakes_set)
                             padded = self._pad_set(corr_set, edges)
                             if terms.fake_side:
                                 terms.fk.load_depth(padded.node_depth, check=False)
@@ -907,11 +928,26 @@ class Trainer:
                         if finish_fakes is not None:
                             fake_padded, edges_fake, edges_ready = finish_fakes()
                             fake_for_D, finish_fakes = fake_padded, None
-                        if deferred_wait:
+                        if fake_pending and edges_ready is not None and depth_early is not None:
+                            # the generated side's structures were loaded on the second stream: its recorded pass
+                            # follows them there, next to this stream's penalty term (one host read on that stream:
+                            # does the recording hold their depth?)
+                            fake_pending = False
+                            with torch.cuda.stream(fakes_stream):
+                                fake_recorded = not terms.fk.plan.overflowed()
+                                if fake_recorded:
+                                    terms.replay_fake()
                             main_stream.wait_stream(fakes_stream)
                             deferred_wait = False
                             self._mark("fakes ready")
-                        if fake_pending:
+                            if not fake_recorded:
+                                self._outgrown(terms, fake_padded)
+                            fake_here = fake_recorded
+                        elif fake_pending:
+                            if deferred_wait:
+                                main_stream.wait_stream(fakes_stream)
+                                deferred_wait = False
+                                self._mark("fakes ready")
                             # first iteration with the fakes' level walk behind the two replays above: their
                             # level plan is rebuilt now (one host read: does the recording hold their depth?)
                             # and the recorded pass over them follows on this stream

@@ -394,7 +394,8 @@ int aig_sort_pairs(int64_t items, int key_bytes, int bits, const void* keys_in, 
  *                      for cells of m > 1 nodes, its second node as a row standing for the other m - 1; rows come in
  *                      node order: xr_rows / xf_rows [n,2], depth_rows int64 [n] (the row's level; -1 past the last
  *                      row - feed it to aig_level_plan_dyn), w_fwd = m w and w_bwd = sqrt(m) w with w the node's
- *                      weight in the FULL plan (node_level, w: that plan's arrays; L: its level capacity), *n_rows.
+ *                      weight in the FULL plan (nvalid, lvl_meta, perm, node_level, w: that plan's sizes and arrays;
+ *                      L: its level capacity), *n_rows.
  *                      With w_fwd as the readout's weights in aig_level_pool_fwd and w_bwd as `w` of
  *                      aig_gp_input_grad / aig_gp_param_grad the penalty, its norm and every gradient equal those of
  *                      the run over all nodes (a row's backward chain is linear in the readout's gradient, so it
@@ -402,7 +403,8 @@ int aig_sort_pairs(int64_t items, int key_bytes, int bits, const void* keys_in, 
  *                      distinct feature pairs: the surplus nodes stay rows of their own.
  * ------------------------------------------------------------------------------------------- */
 size_t aig_gp_rows_ws_bytes(int64_t n, int64_t L);
-int aig_gp_rows(int64_t n, int64_t L, const float* x_real, const float* x_fake, const int32_t* node_level, const float* w,
+int aig_gp_rows(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const int32_t* perm, const float* x_real,
+                const float* x_fake, const int32_t* node_level, const float* w,
                 float* xr_rows, float* xf_rows, int64_t* depth_rows, float* w_fwd, float* w_bwd, int32_t* n_rows,
                 void* ws, size_t ws_bytes, void* stream);
 int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha, const float* W1,

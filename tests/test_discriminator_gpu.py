@@ -466,14 +466,15 @@ def test_closed_form_gradient_penalty_matches_autograd(case):
         assert err <= 1e-4, (tuple(p.shape), err)
 
 
-@pytest.mark.parametrize("case", ["aig_features", "negative_depths", "no_depth", "many_pairs", "all_distinct", "bench_100k"])
+@pytest.mark.parametrize("case", ["aig_features", "negative_depths", "no_depth", "many_pairs", "all_distinct", "bench_100k",
+                                  "dyn_plan", "dyn_no_valid_depth"])
 def test_gradient_penalty_over_distinct_rows(case):
     """The closed-form penalty over the distinct (level, feature pair) rows of aig_gp_rows against the same entry
     points run over every node: gp, norm and every parameter gradient within 2e-5 (the sums run in another order),
     and the row count is what a host-side count of the cells gives.  `many_pairs`: more distinct pairs than the
     256-slot table holds (the surplus nodes stay rows of their own); `all_distinct`: continuous features, nothing
     to merge."""
-    from gan_amd.discriminator import GpRows, LevelPlan
+    from gan_amd.discriminator import DynLevelPlan, GpRows, LevelPlan
     torch.manual_seed(11)
     big = case == "bench_100k"
     g = (synth_aig(1000, 98000, 1000, seed=3, window=4096, orientation="dataset") if big
@@ -488,6 +489,8 @@ def test_gradient_penalty_over_distinct_rows(case):
         nd[::7] = -1
     if case == "no_depth":
         nd = torch.zeros_like(nd)
+    if case == "dyn_no_valid_depth":        # a plan rebuilt in place for a depth vector without a single valid entry
+        nd = torch.full_like(nd, -1)
     if case == "many_pairs":
         xf[:, 1] = torch.randint(0, 700, (n,), generator=gen).float()
     if case == "all_distinct":
@@ -498,15 +501,20 @@ def test_gradient_penalty_over_distinct_rows(case):
             p.add_(0.05 * torch.randn_like(p))
     xr, xf, nd = xr.to(DEV), xf.to(DEV), nd.to(DEV)
     alpha = torch.tensor([[0.37]], device=DEV)
-    plan = LevelPlan(nd, n, DEV)
+    if case.startswith("dyn"):
+        plan = DynLevelPlan(n, int(g.node_depth.max()) + 4, DEV)
+        plan.rebuild(nd)
+    else:
+        plan = LevelPlan(nd, n, DEV)
     gp0, gn0, gr0 = D.gradient_penalty_closed_form(xr, xf, alpha, nd, plan=plan)
     rows = GpRows(n, plan.L + 3, DEV)
     rows.rebuild(xr, xf, plan)
     gp1, gn1, gr1 = D.gradient_penalty_closed_form(xr, xf, alpha, nd, plan=plan, rows=rows)
     torch.cuda.synchronize()
     # the row count against a host-side count of the cells
-    keys = torch.cat([xr, xf, nd.float().unsqueeze(1)], 1).cpu().numpy()
-    keys = keys[nd.cpu().numpy() >= 0]
+    nd_eff = torch.zeros_like(nd) if case == "dyn_no_valid_depth" else nd      # (no valid depth: one level for all)
+    keys = torch.cat([xr, xf, nd_eff.float().unsqueeze(1)], 1).cpu().numpy()
+    keys = keys[nd_eff.cpu().numpy() >= 0]
     _, counts = np.unique(keys, axis=0, return_counts=True)
     want_rows = int(len(counts) + (counts > 1).sum())
     got_rows = int(rows.n_rows.item())
