@@ -760,88 +760,164 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(GraphSet gs, SweepJob j
 // position): the positions are taken a tile at a time from the LAST to the first; every edge runs upward, so when a
 // tile's turn comes, every position above it has already pushed its mark down.  Inside a tile a marked position
 // marks its predecessors - in the tile's LDS flags when they lie in the tile, in memory below it - exactly once;
-// rounds repeat until no new position of the tile got marked.  reach[position] = 0 (reaches a seed; the seeds are
-// preset) or SWEEP_NONE.  One workgroup per graph.
-constexpr int REACH_ROUNDS = 4;
+// the waves poll their positions' flags until a count of marks not yet pushed on reaches zero.  reach[position] = 0
+// (reaches a seed; the seeds are preset) or SWEEP_NONE.  One workgroup per graph.
+constexpr int REACH_SPINS = 1 << 22;      // polls of a tile at most (a chain of marks needs a few per hop)
 __device__ __forceinline__ void reach_back_body(const GraphSet& gs, const int* __restrict__ tptr,
                                                 const int* __restrict__ tsrc, int* __restrict__ reach, const int graph) {
     __shared__ int cur[SWEEP_T];
+    __shared__ int pending;
     volatile int* cur_v = cur;
     const int n = gs.n, base = graph * gs.n, tid = threadIdx.x;
     const int ntiles = (n + SWEEP_T - 1) / SWEEP_T;
     const int last_e = max(gs.M() - 1, 0);
+    struct Bounds {
+        int lo[SWEEP_PT], hi[SWEEP_PT];
+    };
     struct Node {
         int lo, hi, q[SWEEP_INL];
     };
-    Node nx[SWEEP_PT];
-    auto fetch = [&](int t, Node* nd) {     // list bounds and first predecessors of tile t (unconditional, clamped loads)
-        const int a = t * SWEEP_T;
-        int lo[SWEEP_PT], hi[SWEEP_PT];
+    // what a tile needs from memory comes in two dependent steps (list bounds, then the first predecessors): the
+    // bounds are requested two tiles ahead and the predecessors one tile ahead, with unconditional loads on clamped
+    // indices, so that no tile waits for a round trip of its own
+    auto bounds = [&](int t, Bounds& bd) {
 #pragma unroll
         for (int j = 0; j < SWEEP_PT; ++j) {
-            const int p = a + j * SWEEP_THREADS + tid;
+            const int p = t * SWEEP_T + j * SWEEP_THREADS + tid;
             const bool live = t >= 0 && p < n;
             const int pc = base + (live ? p : 0);
-            lo[j] = tptr[pc];
-            hi[j] = tptr[pc + 1];
-            if (!live) lo[j] = hi[j] = 0;
-        }
-#pragma unroll
-        for (int j = 0; j < SWEEP_PT; ++j) {
-            nd[j].lo = lo[j];
-            nd[j].hi = hi[j];
-#pragma unroll
-            for (int k = 0; k < SWEEP_INL; ++k) nd[j].q[k] = tsrc[min(lo[j] + k, last_e)] - base;
+            const int lo = tptr[pc], hi = tptr[pc + 1];
+            bd.lo[j] = live ? lo : 0;
+            bd.hi[j] = live ? hi : 0;
         }
     };
-    fetch(ntiles - 1, nx);
+    auto lists = [&](const Bounds& bd, Node* nd) {
+        int raw[SWEEP_PT][SWEEP_INL];
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j)
+#pragma unroll
+            for (int k = 0; k < SWEEP_INL; ++k) raw[j][k] = tsrc[min(bd.lo[j] + k, last_e)];
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j) {
+            nd[j].lo = bd.lo[j];
+            nd[j].hi = bd.hi[j];
+#pragma unroll
+            for (int k = 0; k < SWEEP_INL; ++k) nd[j].q[k] = raw[j][k] - base;
+        }
+    };
+    Bounds bnext;
+    Node nx[SWEEP_PT];
+    bounds(ntiles - 1, bnext);
+    lists(bnext, nx);
+    bounds(ntiles - 2, bnext);
     for (int t = ntiles - 1; t >= 0; --t) {
         const int a = t * SWEEP_T;
         Node nd[SWEEP_PT];
 #pragma unroll
         for (int j = 0; j < SWEEP_PT; ++j) nd[j] = nx[j];
-        // marks pushed into this tile from above (L1-bypassing loads: the stores came from other waves of this block)
+        // marks pushed into this tile from above.  Every access to `reach` in here is a workgroup-scope atomic: the
+        // only readers and writers are the waves of this one workgroup, which share a CU and its cache - device scope
+        // would send every access past the XCD's L2 and make the fence below write that L2 back (24 us per tile)
+        int got[SWEEP_PT];
 #pragma unroll
         for (int j = 0; j < SWEEP_PT; ++j) {
             const int p = a + j * SWEEP_THREADS + tid;
-            cur[j * SWEEP_THREADS + tid] =
-                p < n ? __hip_atomic_load(&reach[base + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SWEEP_NONE;
+            got[j] = __hip_atomic_load(&reach[base + min(p, n - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        fetch(t - 1, nx);        // the next tile's lists are requested before this tile's rounds
+        lists(bnext, nx);          // the next tile's predecessors and the bounds of the one after it: requested before
+        bounds(t - 2, bnext);      // this tile's rounds
+#pragma unroll
+        for (int j = 0; j < SWEEP_PT; ++j)
+            cur[j * SWEEP_THREADS + tid] = a + j * SWEEP_THREADS + tid < n ? got[j] : SWEEP_NONE;
+        // `pending` = positions of the tile that carry a mark their owner has not pushed on yet.  Whoever lowers a flag
+        // of the tile raises it (an exchange tells the first marker from the others), the owner lowers it after pushing
+        // the mark to the position's predecessors; the waves poll their own positions until it reaches zero.  A chain
+        // of marks inside the tile then advances at the pace of an LDS poll (rounds between barriers advanced it a hop
+        // or two per barrier: the first tiles of what an untrained generator wires hold chains of a hundred hops and
+        // took 110 us each).  REACH_SPINS bounds the polling whatever happens.
+        // (the count is raised BEFORE the flag is lowered and taken back when another marker was first: raised after,
+        // the owner could push the mark on and lower the count to zero in between, and waves would leave early)
+        auto mark = [&](int at) {
+            atomicAdd(&pending, 1);
+            if (atomicExch(&cur[at], 0) == 0) atomicSub(&pending, 1);
+        };
         bool done[SWEEP_PT];
+        int mine = 0;
 #pragma unroll
-        for (int j = 0; j < SWEEP_PT; ++j) done[j] = false;
+        for (int j = 0; j < SWEEP_PT; ++j) {
+            done[j] = false;
+            mine += (a + j * SWEEP_THREADS + tid < n && got[j] == 0) ? 1 : 0;
+        }
+        if (tid == 0) pending = 0;
         __syncthreads();
-        while (true) {
-            bool any = false;
-#pragma unroll 1
-            for (int round = 0; round < REACH_ROUNDS; ++round) {
+        {
+            const unsigned long long any_mine = __ballot(mine > 0);
+            if (any_mine) {      // one LDS add per wave
+                int tot = mine;
 #pragma unroll
-                for (int j = SWEEP_PT - 1; j >= 0; --j) {
-                    if (done[j] || cur_v[j * SWEEP_THREADS + tid] != 0) continue;
-                    done[j] = true;
-                    auto mark = [&](int q) {
-                        if (q >= a) {
-                            if (cur_v[q - a] != 0) { cur_v[q - a] = 0; any = true; }
-                        } else {
-                            __hip_atomic_store(&reach[base + q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    };
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                if ((tid & 63) == 0) atomicAdd(&pending, tot);
+            }
+        }
+        __syncthreads();
+        for (int spin = 0; spin < REACH_SPINS; ++spin) {
+            if (__hip_atomic_load(&pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) break;
+            bool fresh[SWEEP_PT];
+            bool some = false;
 #pragma unroll
-                    for (int k = 0; k < SWEEP_INL; ++k)
-                        if (nd[j].lo + k < nd[j].hi) mark(nd[j].q[k]);
-                    for (int e = nd[j].lo + SWEEP_INL; e < nd[j].hi; ++e) mark(tsrc[e] - base);
+            for (int j = 0; j < SWEEP_PT; ++j) {
+                fresh[j] = !done[j] && cur_v[j * SWEEP_THREADS + tid] == 0;
+                some = some || fresh[j];
+            }
+            if (!__any(some)) {
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            int below[SWEEP_PT][SWEEP_INL];
+            int pushed = 0;
+#pragma unroll
+            for (int j = SWEEP_PT - 1; j >= 0; --j) {
+                done[j] = done[j] || fresh[j];
+                pushed += fresh[j] ? 1 : 0;
+#pragma unroll
+                for (int k = 0; k < SWEEP_INL; ++k) {
+                    const int q = nd[j].q[k];
+                    const bool has = fresh[j] && nd[j].lo + k < nd[j].hi;
+                    below[j][k] = has && q < a ? q : -1;
+                    if (has && q >= a && cur_v[q - a] != 0) mark(q - a);
                 }
             }
-            if (!__syncthreads_or(any)) break;
+            // below the tile: plain stores, nothing waits for them before the tile ends (a load first - is the mark
+            // there already? - would keep the wave from seeing new marks on its positions for a memory round trip)
+#pragma unroll
+            for (int j = 0; j < SWEEP_PT; ++j)
+#pragma unroll
+                for (int k = 0; k < SWEEP_INL; ++k)
+                    if (below[j][k] >= 0)
+                        __hip_atomic_store(&reach[base + below[j][k]], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // lists longer than the inline entries (rare): entry by entry
+#pragma unroll
+            for (int j = 0; j < SWEEP_PT; ++j) {
+                if (!fresh[j]) continue;
+                for (int e = nd[j].lo + SWEEP_INL; e < nd[j].hi; ++e) {
+                    const int q = tsrc[e] - base;
+                    if (q >= a) {
+                        if (cur_v[q - a] != 0) mark(q - a);
+                    } else {
+                        __hip_atomic_store(&reach[base + q], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            if (pushed) atomicSub(&pending, pushed);     // (after this thread's marks: the count never reads zero early)
         }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < SWEEP_PT; ++j) {
             const int p = a + j * SWEEP_THREADS + tid;
-            if (p < n && cur[j * SWEEP_THREADS + tid] == 0)
-                __hip_atomic_store(&reach[base + p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p < n && cur[j * SWEEP_THREADS + tid] == 0 && got[j] != 0)
+                __hip_atomic_store(&reach[base + p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __threadfence();      // the marks pushed below this tile are in memory before any wave loads the next tile
+        __threadfence_block();   // the marks pushed below this tile are visible before any wave loads the next tile
         __syncthreads();      // (and the tile's flags are overwritten next)
     }
 }
