@@ -834,7 +834,10 @@ __device__ __forceinline__ void reach_back_body(const GraphSet& gs, const int* _
         // the mark to the position's predecessors; the waves poll their own positions until it reaches zero.  A chain
         // of marks inside the tile then advances at the pace of an LDS poll (rounds between barriers advanced it a hop
         // or two per barrier: the first tiles of what an untrained generator wires hold chains of a hundred hops and
-        // took 110 us each).  REACH_SPINS bounds the polling whatever happens.
+        // took 110 us each, 77 us now).  What is left is the chain itself: some 900 marked positions of such a tile hang
+        // one behind the other, two LDS round trips a hop; polling faster (all flags of a poll in flight at once, one
+        // word per wave instead of its flags) measured slower, the polls then stand in the way of the marks.
+        // REACH_SPINS bounds the polling whatever happens.
         // (the count is raised BEFORE the flag is lowered and taken back when another marker was first: raised after,
         // the owner could push the mark on and lower the count to zero in between, and waves would leave early)
         auto mark = [&](int at) {
