@@ -73,7 +73,7 @@ __device__ __forceinline__ void for_each_cell(bool part, int key, F body) {
 // Nodes are taken in the order of the plan's `perm` (by level, ids ascending within a level): the lanes of a wave then
 // share a level or two and a handful of cells, so the per-wave merging of the atomics below has something to merge
 // (in node order a wave of the 100k-node workload holds sixty different cells and the kernel took 120 us).
-__global__ void k_gpr_class(int nvalid, const int* __restrict__ meta, const int* __restrict__ perm, int L,
+__global__ __launch_bounds__(1024) void k_gpr_class(int nvalid, const int* __restrict__ meta, const int* __restrict__ perm, int L,
                             const float* __restrict__ xr, const float* __restrict__ xf,
                             const int* __restrict__ node_level, int* __restrict__ owner, int* __restrict__ cls,
                             int* __restrict__ cnt, int* __restrict__ first) {
@@ -83,19 +83,54 @@ __global__ void k_gpr_class(int nvalid, const int* __restrict__ meta, const int*
     const int i = live ? perm[t] : 0;
     const int lvl = live ? level_of(node_level, meta, i) : -1;
     const Pair me = pair_of(xr, xf, i);
-    unsigned h = hash_of(me) & (GPR_CLASSES - 1);
+    int h = (int)(hash_of(me) & (GPR_CLASSES - 1));
     int c = -1;
-    for (int probe = 0; probe < GPR_PROBES && lvl >= 0 && lvl <= L; ++probe) {     // (a level past the cell table: a row of its own)
-        int o = __hip_atomic_load(&owner[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The lanes of a wave probe in step.  A free slot is claimed once per wave - by the lowest lane that wants it, for
+    // all of them - and what a block has learnt about a slot stays in LDS: when the kernel starts, every wave of
+    // the grid finds the table empty, and one compare-and-swap per NODE on a handful of addresses (a minibatch has a
+    // few dozen pairs) took 300 us at 100k nodes.
+    __shared__ int known[GPR_CLASSES], asks[GPR_CLASSES];
+    for (int k = threadIdx.x; k < GPR_CLASSES; k += blockDim.x) {
+        known[k] = -1;
+        asks[k] = INT_MAX;
+    }
+    __syncthreads();
+    // the slots the block's nodes look at first are settled by the block as a whole: one claim per (block, slot)
+    for_each_cell(lvl >= 0 && lvl <= L, h, [&](int slot, unsigned long long, bool leader) {
+        if (leader) atomicMin(&asks[slot], i);
+    });
+    __syncthreads();
+    for (int k = threadIdx.x; k < GPR_CLASSES; k += blockDim.x) {
+        if (asks[k] == INT_MAX) continue;
+        int o = __hip_atomic_load(&owner[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (o < 0) {
-            o = atomicCAS(&owner[h], -1, i);
-            if (o < 0) o = i;
+            o = atomicCAS(&owner[k], -1, asks[k]);
+            if (o < 0) o = asks[k];
         }
-        if (o == i || same(me, pair_of(xr, xf, o))) {
-            c = (int)h;
-            break;
+        known[k] = o;
+    }
+    __syncthreads();
+    bool need = lvl >= 0 && lvl <= L;       // (a level past the cell table: a row of its own)
+    for (int probe = 0; probe < GPR_PROBES && __any(need); ++probe) {
+        int o = need ? __hip_atomic_load(&known[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        if (need && o < 0) o = __hip_atomic_load(&owner[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for_each_cell(need && o < 0, h, [&](int slot, unsigned long long members, bool leader) {
+            int got = 0;
+            if (leader) {
+                got = atomicCAS(&owner[slot], -1, i);
+                if (got < 0) got = i;
+            }
+            o = __shfl(got, __ffsll(static_cast<long long>(members)) - 1);
+        });
+        if (need) {
+            __hip_atomic_store(&known[h], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (one value per slot, whoever stores it)
+            if (o == i || same(me, pair_of(xr, xf, o))) {
+                c = h;
+                need = false;
+            } else {
+                h = (h + 1) & (GPR_CLASSES - 1);
+            }
         }
-        h = (h + 1) & (GPR_CLASSES - 1);
     }
     if (live) cls[i] = c;
     // one update per (wave, cell) instead of one per node: neighbouring nodes share levels and pairs, and a hundred
@@ -216,7 +251,7 @@ extern "C" int aig_gp_rows(int64_t n, int64_t nvalid, int64_t L, const int32_t* 
     AIG_HIP_CHECK(fill_words(second, 0x7fffffffu, cells * 4, s));
     AIG_HIP_CHECK(fill_words(owner, 0xffffffffu, GPR_CLASSES * 4, s));
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(k_gpr_class, grid, block, 0, s, (int)nvalid, lvl_meta, perm, (int)L, x_real, x_fake, node_level, owner, cls,
+    hipLaunchKernelGGL(k_gpr_class, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, (int)nvalid, lvl_meta, perm, (int)L, x_real, x_fake, node_level, owner, cls,
                        cnt, first);
     hipLaunchKernelGGL(k_gpr_second, grid, block, 0, s, (int)nvalid, lvl_meta, perm, node_level, cls, first, second);
     hipLaunchKernelGGL(k_gpr_keep, grid, block, 0, s, (int)n, lvl_meta, node_level, cls, cnt, first, second, mult, flag);

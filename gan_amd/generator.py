@@ -73,10 +73,15 @@ class GeneratorPlan:
         if n > 0:
             bits = x.contiguous().view(torch.int32).to(torch.int64)
             rowkey = (bits[:, 0] << 32) | (bits[:, 1] & 0xFFFFFFFF)
-            uniq, inv = torch.unique(rowkey, return_inverse=True)
-            p.C = int(uniq.numel())
-            first = torch.full((p.C,), n, dtype=torch.int64, device=dev).scatter_reduce_(
-                0, inv, torch.arange(n, device=dev), reduce="amin", include_self=True)
+            # (one stable sort: classes numbered in key order, each represented by its lowest node - no reduction that
+            # sends every node's atomic to one of a handful of addresses)
+            skey, by_key = torch.sort(rowkey, stable=True)
+            opens = torch.ones(n, dtype=torch.bool, device=dev)
+            opens[1:] = skey[1:] != skey[:-1]
+            first = by_key[opens]
+            p.C = int(first.numel())
+            inv = torch.empty(n, dtype=torch.int64, device=dev)
+            inv[by_key] = torch.cumsum(opens, 0) - 1
             p.cls, p.x_cls = inv.to(torch.int32).contiguous(), x[first].contiguous()
         return p
 
