@@ -233,20 +233,9 @@ extern "C" size_t aig_wgrad_ws_bytes(int64_t n, int64_t F) {
     return align_up(blocks * H * (size_t)(F > 0 ? F : 1) * 4) + 256;
 }
 
-extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, float* dW, void* ws,
-                         size_t ws_bytes, void* stream) {
-    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_wgrad: n=%lld out of range", (long long)n);
-    AIG_REQUIRE(F == 128 || F == 1 || F == 2 || F == 4, "aig_wgrad: input width %lld not built (1, 2, 4 or 128)",
-                (long long)F);
-    AIG_REQUIRE(dW, "aig_wgrad: null output");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n == 0) {
-        AIG_HIP_CHECK(fill_words(dW, 0u, (size_t)H * F * 4, s));
-        return AIG_OK;
-    }
-    AIG_REQUIRE(g && x && ws, "aig_wgrad: null pointer");
-    if (ws_bytes < aig_wgrad_ws_bytes(n, F)) return fail(AIG_EWORKSPACE, "aig_wgrad: workspace too small");
-    float* partial = static_cast<float*>(ws);
+namespace aig {
+// partial sums of g^T x over the node range into `partial` ([blocks][128][F]); returns the number of blocks
+static int wgrad_partials(hipStream_t s, int64_t n, int64_t F, const float* g, const float* x, float* partial, int* nb_out) {
     int nb;
     if (F == 128) {
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wgrad128), (size_t)(WGRAD_LDS)));
@@ -263,6 +252,45 @@ extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, f
         hipLaunchKernelGGL(k_wgrad_small<4>, dim3(nb), dim3(256), 0, s, (int)n, g_row_limit, g, x, partial);
     }
     AIG_LAUNCH_CHECK();
+    *nb_out = nb;
+    return AIG_OK;
+}
+
+// dW = g1^T x1 + g2^T x2: the partial sums of both products side by side, added up by one launch (a weight that
+// collects two products - the closed-form gradient penalty's - would otherwise cost two reductions and an addition).
+// ws: 2 * aig_wgrad_ws_bytes(n, F) bytes.
+int wgrad_sum2(int64_t n, int64_t F, const float* g1, const float* x1, const float* g2, const float* x2, float* dW, void* ws,
+               size_t ws_bytes, hipStream_t s) {
+    AIG_REQUIRE(n > 0 && n < INT_MAX && (F == 128 || F == 1 || F == 2 || F == 4), "wgrad_sum2: bad sizes");
+    AIG_REQUIRE(g1 && x1 && g2 && x2 && dW && ws, "wgrad_sum2: null pointer");
+    if (ws_bytes < 2 * aig_wgrad_ws_bytes(n, F)) return fail(AIG_EWORKSPACE, "wgrad_sum2: workspace too small");
+    float* partial = static_cast<float*>(ws);
+    const int elems = (int)(H * F);
+    int nb = 0, nb2 = 0, rc;
+    if ((rc = wgrad_partials(s, n, F, g1, x1, partial, &nb))) return rc;
+    if ((rc = wgrad_partials(s, n, F, g2, x2, partial + (size_t)nb * elems, &nb2))) return rc;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(1024), 0, s, nb + nb2, elems, partial, dW);
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+}  // namespace aig
+
+extern "C" int aig_wgrad(int64_t n, int64_t F, const float* g, const float* x, float* dW, void* ws,
+                         size_t ws_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_wgrad: n=%lld out of range", (long long)n);
+    AIG_REQUIRE(F == 128 || F == 1 || F == 2 || F == 4, "aig_wgrad: input width %lld not built (1, 2, 4 or 128)",
+                (long long)F);
+    AIG_REQUIRE(dW, "aig_wgrad: null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        AIG_HIP_CHECK(fill_words(dW, 0u, (size_t)H * F * 4, s));
+        return AIG_OK;
+    }
+    AIG_REQUIRE(g && x && ws, "aig_wgrad: null pointer");
+    if (ws_bytes < aig_wgrad_ws_bytes(n, F)) return fail(AIG_EWORKSPACE, "aig_wgrad: workspace too small");
+    float* partial = static_cast<float*>(ws);
+    int nb = 0, rc;
+    if ((rc = wgrad_partials(s, n, F, g, x, partial, &nb))) return rc;
     const int elems = (int)(H * F);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems + 63) / 64), dim3(1024), 0, s, nb, elems, partial, dW);
     AIG_LAUNCH_CHECK();

@@ -94,9 +94,11 @@ __global__ __launch_bounds__(THREADS) void k_pool_bwd_adj(int n, int L, const in
     block_colsum<2 * H>(red, partial);
 }
 
-// out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree
+// out[c] = sum_b partial[b][c]: one block per column, strided partial sums then a fixed-shape tree.  Columns from
+// `split` on go to out2[c - split] (two results of one pass over the rows, summed by one launch).
 __global__ __launch_bounds__(256) void k_sum_cols(int nb, int width, const float* __restrict__ partial,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, int split = INT_MAX,
+                                                  float* __restrict__ out2 = nullptr) {
     __shared__ float red[256];
     const int c = blockIdx.x, t = threadIdx.x;
     float s = 0.f;
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(256) void k_sum_cols(int nb, int width, const float
         if (t < o) red[t] += red[t + o];
         __syncthreads();
     }
-    if (t == 0) out[c] = red[0];
+    if (t == 0) {
+        if (c < split) out[c] = red[0];
+        else out2[c - split] = red[0];
+    }
 }
 
 // x^ = alpha xr + (1 - alpha) xf,  h1 = elu(x^ W1^T + b1)
@@ -278,11 +283,6 @@ __global__ __launch_bounds__(THREADS) void k_gp_back3(int n, const int* __restri
     block_colsum<H>(red, partial);
 }
 
-__global__ void k_add_inplace(int m, float* __restrict__ a, const float* __restrict__ b) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) a[i] += b[i];
-}
-
 int gp_blocks(int64_t n) {
     int64_t g = (n + 63) / 64;
     if (g > GP_BLOCKS_MAX) g = GP_BLOCKS_MAX;
@@ -391,9 +391,9 @@ extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
 
 extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
     const size_t N = (size_t)(n > 0 ? n : 1);
-    size_t wg = aig_wgrad_ws_bytes(n, H), wg2 = aig_wgrad_ws_bytes(n, 2);
+    size_t wg = 2 * aig_wgrad_ws_bytes(n, H), wg2 = 2 * aig_wgrad_ws_bytes(n, 2);      // (two products per weight)
     return 5 * align_up(N * H * 4) + align_up(N * 2 * 4) + align_up((size_t)GP_BLOCKS_MAX * 3 * H * 4) +
-           align_up((size_t)H * H * 4) + align_up(wg > wg2 ? wg : wg2) + 1024;
+           align_up(wg > wg2 ? wg : wg2) + 1024;
 }
 
 extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
@@ -417,7 +417,6 @@ extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
     float* dh1 = c.take<float>(NH);
     float* u = c.take<float>((size_t)n * 2);
     float* partial = c.take<float>((size_t)GP_BLOCKS_MAX * 3 * H);
-    float* tmpW = c.take<float>((size_t)H * H);
     const size_t wg_bytes = ws_bytes - c.off;
     void* wg = c.base + c.off;
     const int g = gp_blocks(n);
@@ -431,23 +430,16 @@ extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
     hipLaunchKernelGGL(k_gp_back2, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, (int)L, lvl_meta, ubar_gz2, h2, g_r,
                        node_level, w, argmax, dz2, partial);
     // columns 0..127 -> db2, 128..383 -> ubar_gr
-    hipLaunchKernelGGL(k_sum_cols, dim3(H), dim3(256), 0, s, g, 3 * H, partial, db2);
-    hipLaunchKernelGGL(k_sum_cols, dim3(2 * H), dim3(256), 0, s, g, 3 * H, partial + H, ubar_gr);
+    hipLaunchKernelGGL(k_sum_cols, dim3(3 * H), dim3(256), 0, s, g, 3 * H, partial, db2, H, ubar_gr);
     AIG_LAUNCH_CHECK();
-    // dW2 = g_z2^T ubar_gh1 + dz2^T h1
-    if ((rc = aig_wgrad(n, H, g_z2, ubar_gh1, dW2, wg, wg_bytes, stream))) return rc;
-    if ((rc = aig_wgrad(n, H, dz2, h1, tmpW, wg, wg_bytes, stream))) return rc;
-    hipLaunchKernelGGL(k_add_inplace, dim3((H * H + 255) / 256), dim3(256), 0, s, H * H, dW2, tmpW);
-    AIG_LAUNCH_CHECK();
+    // dW2 = g_z2^T ubar_gh1 + dz2^T h1 (the partial sums of both products added up by one launch)
+    if ((rc = wgrad_sum2(n, H, g_z2, ubar_gh1, dz2, h1, dW2, wg, wg_bytes, s))) return rc;
     // dz1 = dz1a + (dz2 W2) * elu'(z1)
     if ((rc = aig_linear128(n, dz2, W2, 1, nullptr, 0, dh1, stream))) return rc;
     hipLaunchKernelGGL(k_gp_back3, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, dh1, h1, dz1, partial);
     hipLaunchKernelGGL(k_sum_cols, dim3(H), dim3(256), 0, s, g, H, partial, db1);
     AIG_LAUNCH_CHECK();
     // dW1 = g_z1^T u + dz1^T x^
-    if ((rc = aig_wgrad(n, 2, g_z1, u, dW1, wg, wg_bytes, stream))) return rc;
-    if ((rc = aig_wgrad(n, 2, dz1, xhat, tmpW, wg, wg_bytes, stream))) return rc;
-    hipLaunchKernelGGL(k_add_inplace, dim3(1), dim3(256), 0, s, H * 2, dW1, tmpW);
-    AIG_LAUNCH_CHECK();
+    if ((rc = wgrad_sum2(n, 2, g_z1, u, dz1, xhat, dW1, wg, wg_bytes, s))) return rc;
     return AIG_OK;
 }

@@ -695,7 +695,9 @@ class AIGDiscriminator(nn.Module):
         _abi.check(lib.aig_head_fwd(_abi.ptr(r), _abi.ptr(hw1), _abi.ptr(hb1), _abi.ptr(hw2), _abi.ptr(hb2),
                                     _abi.ptr(hw3), _abi.ptr(hb3), _abi.ptr(score), _abi.ptr(act), st), "aig_head_fwd")
         g_r_c = torch.empty((1, 2 * HIDDEN), **f32)
-        one = torch.ones(1, **f32)
+        one = self.__dict__.get("_one")       # (a constant kept per device: no fill launch per call)
+        if one is None or one.device != dev:
+            one = self.__dict__["_one"] = torch.ones(1, **f32)
         _abi.check(lib.aig_head_bwd(_abi.ptr(one), _abi.ptr(r), _abi.ptr(hw1), _abi.ptr(hw2), _abi.ptr(hw3), _abi.ptr(act),
                                     _abi.ptr(g_r_c), None, None, None, None, None, None, st), "aig_head_bwd")
         g_z2, g_h1, g_z1 = (torch.empty((n, HIDDEN), **f32) for _ in range(3))

@@ -322,9 +322,15 @@ class CapturedCriticTerms:
                 self.rw = _GeneratedSide(n, e_cols, self.fake_cap, device, torch.zeros((n, 2), **f32))
                 self.rw.load(example, check=False)
 
+        # seeds of the backward passes as constants: autograd would make them with a fill launch per pass, and the
+        # real side's sign with a negation launch forward and another one backward (the gradient of -d is the
+        # gradient of d seeded with -1: the same bits)
+        # (kept on the object: the recordings read them at every replay)
+        self._seeds = plus_one, minus_one = torch.ones((), **f32), -torch.ones((), **f32)
+
         def compute_real():
             d_real = mean_score(D, self.real_for_D)
-            return d_real.detach(), torch.autograd.grad(-d_real, params, allow_unused=True)
+            return d_real.detach(), torch.autograd.grad(d_real, params, grad_outputs=minus_one, allow_unused=True)
 
         def compute_gp():
             if closed_form_gp:
@@ -343,7 +349,7 @@ class CapturedCriticTerms:
                 with torch.no_grad():
                     return mean_score(D, side.for_D).detach(), [None] * len(params)
             d_side = mean_score(D, side.for_D)
-            return d_side.detach(), torch.autograd.grad(d_side, params, allow_unused=True)
+            return d_side.detach(), torch.autograd.grad(d_side, params, grad_outputs=plus_one, allow_unused=True)
 
         self._compute_gp = compute_gp
         cur = torch.cuda.current_stream(device)

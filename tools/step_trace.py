@@ -50,7 +50,7 @@ if len(sys.argv) > 6:   # compressed timeline of that step: wide kernels by name
     cur = None
     def flush():
         global cur
-        if cur: print(f"   t={cur[0] / 1e3:8.1f} us  q{cur[4]}  [{cur[2]} narrow launches, {cur[3] / 1e3:.1f} us busy, span {(cur[1] - cur[5]) / 1e3:.1f} us]")
+        if cur: print(f"   t={cur[0] / 1e3:8.1f} us  q{cur[4]}  [{cur[2]} narrow launches, {cur[3] / 1e3:.1f} us busy, span {(cur[1] - cur[5]) / 1e3:.1f} us]  " + " ".join(cur[6]))
         cur = None
     for r in ks:
         q = r[qk] if qk else '?'
@@ -58,9 +58,10 @@ if len(sys.argv) > 6:   # compressed timeline of that step: wide kernels by name
             flush()
             print(f"   t={(r['s'] - s0) / 1e3:8.1f} us  q{q}  {(r['e'] - r['s']) / 1e3:7.1f} us  {r['Kernel_Name'].replace('aig::(anonymous namespace)::', '').replace('void ', '')[:60]}")
         else:
-            if cur and cur[4] == q: cur[1] = r['e']; cur[2] += 1; cur[3] += r['e'] - r['s']
+            nm = r['Kernel_Name'].replace('aig::(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][-24:] + f":{(r['e'] - r['s']) / 1e3:.0f}"
+            if cur and cur[4] == q: cur[1] = r['e']; cur[2] += 1; cur[3] += r['e'] - r['s']; cur[6].append(nm)
             else:
-                flush(); cur = [r['s'] - s0, r['e'], 1, r['e'] - r['s'], q, r['s']]
+                flush(); cur = [r['s'] - s0, r['e'], 1, r['e'] - r['s'], q, r['s'], [nm]]
     flush()
 if len(sys.argv) > 7:   # wide-kernel busy fraction per window of W us, with the widest kernels of each window
     W = float(sys.argv[7]) * 1e3
