@@ -83,6 +83,7 @@ SIGNATURES = {
     "aig_gp_param_grad_ws_bytes": (SZ, [I64]),
     "aig_gp_param_grad": (INT, [I64, P, I64] + [P] * 20 + [P, SZ, P]),
     "aig_linear128": (INT, [I64, P, P, INT, P, INT, P, P]),
+    "aig_linear128_node_terms": (INT, [I64, P, P, INT, P, P, P, P, P, P, P, P, P]),
     "aig_linear_in2": (INT, [I64, P, P, P, P]),
     "aig_head_fwd": (INT, [P] * 9 + [P]),
     "aig_head_bwd": (INT, [P] * 13 + [P]),

@@ -93,6 +93,9 @@ __device__ __forceinline__ int limited_rows(int n, const int* __restrict__ limit
 // output columns, or (wt) stored [in][out]; act 0 none, 1 ReLU, 2 ELU.
 int launch_linear128_x6(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, const float* bias, int act,
                         float* out);
+int launch_linear128_x6_terms(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, float* out,
+                              const float* att_src, const float* att_dst, const float* lin_edge_w, const float* att_edge,
+                              float* a_s, float* a_d, float* ce);
 // dW = g1^T x1 + g2^T x2 over n rows ([128,F] in PyTorch's [out,in] layout; F in {1, 2, 4, 128}); ws holds
 // 2 * aig_wgrad_ws_bytes(n, F) bytes (dense.hip)
 int wgrad_sum2(int64_t n, int64_t F, const float* g1, const float* x1, const float* g2, const float* x2, float* dW, void* ws,

@@ -31,7 +31,7 @@ constexpr int THREADS = 512;
 constexpr int LDA = H / 2 + 4;     // dwords per tile row of a plane (two bf16 a dword), padded: conflict-free 16-byte reads
 constexpr int PLANE = BM * LDA;    // dwords per plane of a tile
 constexpr int ST_LD = 32 + 4;        // floats per row of a wave's output staging block (32 x 32), padded
-constexpr size_t X6_LDS = ((size_t)2 * 3 * PLANE + (size_t)(THREADS / 64) * 32 * ST_LD) * sizeof(unsigned);
+constexpr size_t X6_LDS = ((size_t)2 * 3 * PLANE + (size_t)(THREADS / 64) * 32 * ST_LD + 4 * H) * sizeof(unsigned);
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -63,6 +63,12 @@ __device__ __forceinline__ Cut8 cut8(const float (&v)[8]) {
     }
     return c;
 }
+// v of this lane + v of the lane 32 away, in both (one vector instruction: the two halves of a wave swap registers;
+// a shuffle through the LDS crossbar costs its round trip, and the compiler waits for each one in turn)
+__device__ __forceinline__ float across_halves(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 template <int ACT>
@@ -72,20 +78,45 @@ __device__ __forceinline__ float act1(float y) {
     return y;
 }
 
-template <int ACT>
+// The node terms of an attention layer whose projection this is (GATConv: a_s[i][h] = <y[i], att_src> over the 32
+// columns of head h, a_d likewise; ce[h] = <lin_edge.weight, att_edge> over the same columns): a wave holds exactly one
+// head of its rows when it stores them, so the terms cost a few dozen multiply-adds there instead of a pass of their
+// own over the [n,128] output.  Read by the TERMS form of the kernel only (which takes no bias and no activation: the
+// layer's projection has neither).
+struct NodeTerms {
+    const float* att_src;
+    const float* att_dst;
+    const float* lin_edge_w;
+    const float* att_edge;
+    float* a_s;
+    float* a_d;
+    float* ce;
+};
+
+template <int ACT, bool TERMS>
 __global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const int* __restrict__ row_limit,
                                                             const float* __restrict__ X,
                                                             const float* __restrict__ W, int ldw, int wt,
-                                                            const float* __restrict__ bias, float* __restrict__ out) {
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            NodeTerms nt_) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     M = limited_rows(M, row_limit);
-    if (M <= 0) return;
+    if (M <= 0 && !TERMS) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cw = wave & 3, uh = wave >> 2, frow = lane & 31, fh = lane >> 5;
+    // the attention vectors wait in LDS behind the staging blocks (the weight planes fill the registers)
+    float* att = reinterpret_cast<float*>(lds + 2 * 3 * PLANE) + (THREADS / 64) * 32 * ST_LD;
     const int G = gridDim.x;
     const int ntiles = (M + BM - 1) / BM;
     const int nt = (ntiles - (int)blockIdx.x + G - 1) / G;      // tiles of this block: blockIdx.x, + G, ...
-    if (nt <= 0) return;
+    if (nt <= 0) {      // (only under a row limit below the launch's rows; the coefficients are owed all the same)
+        if (TERMS && blockIdx.x == gridDim.x - 1 && tid < 4) {
+            float c = 0.f;
+            for (int k = 0; k < H / 4; ++k) c += nt_.lin_edge_w[tid * (H / 4) + k] * nt_.att_edge[tid * (H / 4) + k];
+            nt_.ce[tid] = c;
+        }
+        return;
+    }
     // (the first two tiles are requested right away - see the loader below - ahead of the weight loads)
     float4 pre0[4], pre1[4];
 #pragma unroll
@@ -95,6 +126,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const int* _
         const long long r1 = min(((long long)blockIdx.x + G) * BM + (idx >> 5), (long long)M - 1);
         pre0[q] = *reinterpret_cast<const float4*>(X + r0 * H + 4 * (idx & 31));
         pre1[q] = *reinterpret_cast<const float4*>(X + r1 * H + 4 * (idx & 31));
+    }
+    // (the edge coefficients are taken by the last block - the one with the fewest tiles - after its tiles)
+    if (TERMS) {
+        if (tid < 2 * H) att[tid] = tid < H ? nt_.att_src[tid] : nt_.att_dst[tid - H];
+        if (blockIdx.x == gridDim.x - 1 && tid < 2 * H) att[2 * H + tid] = tid < H ? nt_.lin_edge_w[tid] : nt_.att_edge[tid - H];
     }
     // the wave's weight slice as matrix fragments: lane (frow, fh) holds W[32 cw + frow][16 s + 8 fh .. + 7]
     u32x4 wh[8], wm[8], wl[8];
@@ -119,7 +155,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const int* _
     float4 bv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        bv[g] = bias ? *reinterpret_cast<const float4*>(bias + cw * 32 + 8 * g + 4 * fh) : make_float4(0, 0, 0, 0);
+        bv[g] = (bias && !TERMS) ? *reinterpret_cast<const float4*>(bias + cw * 32 + 8 * g + 4 * fh) : make_float4(0, 0, 0, 0);
 
     // loader: thread takes float4 q * 512 + tid of a tile, q = 0..3 (row = idx / 32, columns 4 (idx % 32) .. + 3).
     // Requests run TWO tiles ahead of the products (tile t waits in register set t % 2): the products of a tile
@@ -173,16 +209,38 @@ __global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const int* _
         // Stored from there an instruction would write 32-byte pieces of 32 different rows; the block goes through a
         // staging area of the wave's own instead and leaves as whole 128-byte lines, eight rows per instruction.
         float* stage = reinterpret_cast<float*>(lds + 2 * 3 * PLANE) + wave * 32 * ST_LD;
+        float ps[4], pd[4];
         {
             float* o = stage + frow * ST_LD + 4 * fh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 y;
-                y.x = act1<ACT>(acc[4 * g] + low[4 * g] + bv[g].x);
-                y.y = act1<ACT>(acc[4 * g + 1] + low[4 * g + 1] + bv[g].y);
-                y.z = act1<ACT>(acc[4 * g + 2] + low[4 * g + 2] + bv[g].z);
-                y.w = act1<ACT>(acc[4 * g + 3] + low[4 * g + 3] + bv[g].w);
+                y.x = TERMS ? acc[4 * g] + low[4 * g] : act1<ACT>(acc[4 * g] + low[4 * g] + bv[g].x);
+                y.y = TERMS ? acc[4 * g + 1] + low[4 * g + 1] : act1<ACT>(acc[4 * g + 1] + low[4 * g + 1] + bv[g].y);
+                y.z = TERMS ? acc[4 * g + 2] + low[4 * g + 2] : act1<ACT>(acc[4 * g + 2] + low[4 * g + 2] + bv[g].z);
+                y.w = TERMS ? acc[4 * g + 3] + low[4 * g + 3] : act1<ACT>(acc[4 * g + 3] + low[4 * g + 3] + bv[g].w);
                 *reinterpret_cast<float4*>(o + 8 * g) = y;
+                if (TERMS) {
+                    const float4 as4 = *reinterpret_cast<const float4*>(att + cw * 32 + 8 * g + 4 * fh);
+                    const float4 ad4 = *reinterpret_cast<const float4*>(att + H + cw * 32 + 8 * g + 4 * fh);
+                    ps[g] = y.x * as4.x + y.y * as4.y + y.z * as4.z + y.w * as4.w;
+                    pd[g] = y.x * ad4.x + y.y * ad4.y + y.z * ad4.z + y.w * ad4.w;
+                }
+            }
+        }
+        if (TERMS) {
+            // eight groups of four columns make a head (group 2g + fh here); added in the order of the layer's own
+            // pass: neighbours, then pairs of neighbours, then the two halves
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ps[g] = across_halves(ps[g]);
+                pd[g] = across_halves(pd[g]);
+            }
+            const float s_ = (ps[0] + ps[1]) + (ps[2] + ps[3]), d_ = (pd[0] + pd[1]) + (pd[2] + pd[3]);
+            const long long row = ((long long)blockIdx.x + (long long)it * G) * BM + uh * 32 + frow;
+            if (fh == 0 && row < M) {
+                nt_.a_s[row * 4 + cw] = s_;
+                nt_.a_d[row * 4 + cw] = d_;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -221,14 +279,20 @@ __global__ __launch_bounds__(THREADS, 1) void k_linear128_x6(int M, const int* _
         trip(it, pre1);                       // tile it + 1 waits in set 1
         if (it + 1 < nt) trip(it + 1, pre0);  // tile it + 2 in set 0
     }
+    if (TERMS && blockIdx.x == gridDim.x - 1 && tid < 4) {      // (the sum as the layer's own pass takes it: ascending, one lane per head)
+        float c = 0.f;
+        for (int k = 0; k < H / 4; ++k) c += att[2 * H + tid * (H / 4) + k] * att[3 * H + tid * (H / 4) + k];
+        nt_.ce[tid] = c;
+    }
 }
 
-template <int ACT>
-int launch(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, const float* bias, float* out) {
-    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128_x6<ACT>), X6_LDS));
+template <int ACT, bool TERMS = false>
+int launch(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, const float* bias, float* out,
+           const NodeTerms& terms = NodeTerms{}) {
+    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_linear128_x6<ACT, TERMS>), X6_LDS));
     const int tiles = (M + BM - 1) / BM;
     const int gx = tiles < 256 ? tiles : 256;      // one workgroup of eight waves per CU
-    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128_x6<ACT>), dim3(gx), dim3(THREADS), X6_LDS, s, M, g_row_limit, X, W, ldw, wt, bias, out);
+    AIG_LAUNCH_TIMED(AIG_KT_LINEAR128, (k_linear128_x6<ACT, TERMS>), dim3(gx), dim3(THREADS), X6_LDS, s, M, g_row_limit, X, W, ldw, wt, bias, out, terms);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
@@ -241,6 +305,15 @@ int launch_linear128_x6(hipStream_t s, int M, const float* X, const float* W, in
     if (act == 1) return launch<1>(s, M, X, W, ldw, wt, bias, out);
     if (act == 2) return launch<2>(s, M, X, W, ldw, wt, bias, out);
     return launch<0>(s, M, X, W, ldw, wt, bias, out);
+}
+
+
+// Y = X W^T (or X W) together with the node terms of the attention layer it feeds, see NodeTerms
+int launch_linear128_x6_terms(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, float* out,
+                              const float* att_src, const float* att_dst, const float* lin_edge_w, const float* att_edge,
+                              float* a_s, float* a_d, float* ce) {
+    if (M <= 0) return AIG_OK;
+    return launch<0, true>(s, M, X, W, ldw, wt, nullptr, out, NodeTerms{att_src, att_dst, lin_edge_w, att_edge, a_s, a_d, ce});
 }
 
 }  // namespace aig

@@ -991,3 +991,21 @@ extern "C" int aig_linear128(int64_t n, const float* x, const float* w, int w_in
     if (act == 2) return launch_linear<2>(s, static_cast<int>(n), x, ck);
     return launch_linear<0>(s, static_cast<int>(n), x, ck);
 }
+
+extern "C" int aig_linear128_node_terms(int64_t n, const float* x, const float* w, int w_in_major, const float* att_src,
+                                        const float* att_dst, const float* lin_edge_w, const float* att_edge, float* y,
+                                        float* a_s, float* a_d, float* ce, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT32_MAX, "aig_linear128_node_terms: n=%lld out of range", (long long)n);
+    AIG_REQUIRE(att_src && att_dst && lin_edge_w && att_edge && ce, "aig_linear128_node_terms: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool f32_products = [] { const char* e = getenv("AIG_LINEAR128_F32"); return e && e[0] == '1'; }();
+    if (n == 0 || f32_products) {      // (no rows: only ce; the f32 products: the two passes one after the other)
+        int rc = aig_linear128(n, x, w, w_in_major, nullptr, 0, y, stream);
+        if (rc) return rc;
+        return aig_gat_node_alpha(n, y, att_src, att_dst, lin_edge_w, att_edge, a_s, a_d, ce, stream);
+    }
+    AIG_REQUIRE(x && w && y && a_s && a_d, "aig_linear128_node_terms: null pointer");
+    AIG_REQUIRE(x != y, "aig_linear128_node_terms: in-place operation is not supported");
+    return launch_linear128_x6_terms(s, static_cast<int>(n), x, w, H, w_in_major ? 1 : 0, y, att_src, att_dst, lin_edge_w,
+                                     att_edge, a_s, a_d, ce);
+}

@@ -42,9 +42,14 @@ from .data import Data
 
 HIDDEN = 128
 # Switches for the tests that compare the fused forms with the separate kernels they replace (both stay in the
-# library): the first layer without projected rows (aig_gat1_*), the readout's backward inside the second layer's.
+# library): the first layer without projected rows (aig_gat1_*), the readout's backward inside the second layer's,
+# the second layer's node terms out of its projection's launch (aig_linear128_node_terms).
 FUSED_FIRST_LAYER = True
 FUSED_READOUT_BACKWARD = True
+FUSED_NODE_TERMS = True
+# ... which pays from a few hundred thousand rows on (1M nodes: the step 2 % faster; 100k: 0.7 % slower, the longer
+# epilogue shows while the projection is not yet bound by memory; small minibatches: 10 % slower)
+NODE_TERMS_MIN_ROWS = 400_000
 
 
 class GraphCSR:
@@ -184,22 +189,25 @@ class _GATAggregate(torch.autograd.Function):
     """softmax-attention aggregation + bias + ELU over a GraphCSR (first-order differentiable)."""
 
     @staticmethod
-    def forward(ctx, xw, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR):
+    def forward(ctx, xw, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR, terms=None):
         lib = _abi.lib()
         n, dev = csr.n, xw.device
         xw = xw.contiguous()
         att_src, att_dst, lin_edge_w, att_edge, bias = (t.detach().contiguous().view(-1)
                                                         for t in (att_src, att_dst, lin_edge_w, att_edge, bias))
         f32 = dict(dtype=torch.float32, device=dev)
-        ce = torch.empty(4, **f32)
-        a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
         out = torch.empty((n, HIDDEN), **f32)
         alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
         alpha_loop = torch.empty((max(n, 1), 4), **f32)
         st = _abi.stream()
-        _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
-                              _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
-                              _abi.ptr(ce), st), "aig_gat_node_alpha")
+        if terms is not None:       # (the projection's launch made them, see _ProjectTerms)
+            a_s, a_d, ce = terms
+        else:
+            ce = torch.empty(4, **f32)
+            a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
+            _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
+                                  _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
+                                  _abi.ptr(ce), st), "aig_gat_node_alpha")
         _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
                               _abi.ptr(ce), _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
                               _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
@@ -231,7 +239,7 @@ class _GATAggregate(torch.autograd.Function):
                                    _abi.ptr(d_xw), _abi.ptr(d_as), _abi.ptr(d_ad), _abi.ptr(d_ce), _abi.ptr(d_bias),
                                    _abi.ptr(d_lw), _abi.ptr(d_ae),
                                    _abi.ptr(ws), ws.numel(), _abi.stream(), meta=(n, csr.E)), "aig_gat_bwd")
-        return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None
+        return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None, None
 
 
 class _GAT1Fused(torch.autograd.Function):
@@ -291,22 +299,25 @@ class _GATAggregatePool(torch.autograd.Function):
     Same numbers as the two nodes in a row, bit for bit.  Differentiable once."""
 
     @staticmethod
-    def forward(ctx, xw, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR, plan):
+    def forward(ctx, xw, att_src, att_dst, lin_edge_w, att_edge, bias, csr: GraphCSR, plan, terms=None):
         lib = _abi.lib()
         n, dev = csr.n, xw.device
         xw = xw.contiguous()
         att_src, att_dst, lin_edge_w, att_edge, bias = (t.detach().contiguous().view(-1)
                                                         for t in (att_src, att_dst, lin_edge_w, att_edge, bias))
         f32 = dict(dtype=torch.float32, device=dev)
-        ce = torch.empty(4, **f32)
-        a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
         out = torch.empty((n, HIDDEN), **f32)
         alpha_e = torch.empty((max(csr.E, 1), 4), **f32)
         alpha_loop = torch.empty((max(n, 1), 4), **f32)
         st = _abi.stream()
-        _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
-                              _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
-                              _abi.ptr(ce), st), "aig_gat_node_alpha")
+        if terms is not None:       # (the projection's launch made them, see _ProjectTerms)
+            a_s, a_d, ce = terms
+        else:
+            ce = torch.empty(4, **f32)
+            a_s, a_d = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32)
+            _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
+                                  _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
+                                  _abi.ptr(ce), st), "aig_gat_node_alpha")
         _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
                               _abi.ptr(ce), _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
                               _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
@@ -345,7 +356,7 @@ class _GATAggregatePool(torch.autograd.Function):
                               _abi.ptr(d_xw), _abi.ptr(d_as), _abi.ptr(d_ad), _abi.ptr(d_ce), _abi.ptr(d_bias),
                               _abi.ptr(d_lw), _abi.ptr(d_ae), _abi.ptr(ws), ws.numel(), _abi.stream(), meta=(n, csr.E)),
                    "aig_gat_bwd_pooled")
-        return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None, None
+        return d_xw, d_as, d_ad, d_lw, d_ae, d_bias, None, None, None
 
 
 class _WGrad(torch.autograd.Function):
@@ -442,6 +453,35 @@ class _ProjectBack(torch.autograd.Function):
         return d_g, d_w
 
 
+class _ProjectTerms(torch.autograd.Function):
+    """``_Project`` for the projection of an attention layer, which also hands over the layer's node terms
+    ``a_s``, ``a_d`` and edge coefficients ``ce`` (``aig_linear128_node_terms``: one launch instead of a pass of
+    their own over the projected rows).  The three carry no gradient here: the aggregation that consumes them
+    differentiates through them itself, as when it computes them."""
+
+    @staticmethod
+    def forward(ctx, x, w, att_src, att_dst, lin_edge_w, att_edge):
+        ctx.save_for_backward(x, w)
+        x_, w_ = x.contiguous(), w.contiguous()
+        vecs = [t.detach().contiguous().view(-1) for t in (att_src, att_dst, lin_edge_w, att_edge)]
+        n = int(x_.size(0))
+        f32 = dict(dtype=torch.float32, device=x_.device)
+        y = torch.empty_like(x_)
+        a_s, a_d, ce = torch.empty((max(n, 1), 4), **f32), torch.empty((max(n, 1), 4), **f32), torch.empty(4, **f32)
+        _abi.check(_abi.timed("aig_linear128", _abi.lib().aig_linear128_node_terms, n, _abi.ptr(x_), _abi.ptr(w_), 0,
+                              _abi.ptr(vecs[0]), _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), _abi.ptr(y),
+                              _abi.ptr(a_s), _abi.ptr(a_d), _abi.ptr(ce), _abi.stream()), "aig_linear128_node_terms")
+        ctx.mark_non_differentiable(a_s, a_d, ce)
+        return y, a_s, a_d, ce
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        x, w = ctx.saved_tensors
+        d_x = _ProjectBack.apply(g, w) if ctx.needs_input_grad[0] else None
+        d_w = _WGrad.apply(g, x) if ctx.needs_input_grad[1] else None
+        return d_x, d_w, None, None, None, None
+
+
 class _LevelPool(torch.autograd.Function):
     """[n,128] -> [1,256] level-wise mean || max readout."""
 
@@ -534,20 +574,28 @@ class GATLayer(nn.Module):
             # two input features: the whole layer without its projected rows (see _GAT1Fused)
             return _GAT1Fused.apply(x, self.lin.weight, self.att_src, self.att_dst, self.lin_edge.weight, self.att_edge,
                                     self.bias, csr)
-        if x.size(1) in (1, 2, 4, HIDDEN) and self.lin.weight.size(0) == HIDDEN:
+        has_edges = csr is not None and csr.E > 0
+        terms = None
+        if (has_edges and _is128(x, self.lin.weight) and x.is_cuda and FUSED_NODE_TERMS
+                and int(x.size(0)) >= NODE_TERMS_MIN_ROWS):
+            # the projection's launch also makes the node terms of the attention (see _ProjectTerms)
+            xw, a_s, a_d, ce = _ProjectTerms.apply(x, self.lin.weight, self.att_src, self.att_dst, self.lin_edge.weight,
+                                                   self.att_edge)
+            terms = (a_s, a_d, ce)
+        elif x.size(1) in (1, 2, 4, HIDDEN) and self.lin.weight.size(0) == HIDDEN:
             xw = _Project.apply(x, self.lin.weight)
         else:
             xw = self.lin(x)
-        if csr is None or csr.E == 0:
+        if not has_edges:
             # only self loops: alpha = 1/(1 + 1e-16) = 1 in fp32
             return F.elu(xw + self.bias)
         # edge_dim = 1: an edge's attention term is attr * ce[h], ce[h] = <lin_edge.weight[h,:], att_edge[h,:]>,
         # formed (and differentiated) inside the kernels
         if plan is not None:
             return _GATAggregatePool.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), self.lin_edge.weight,
-                                           self.att_edge, self.bias, csr, plan)
+                                           self.att_edge, self.bias, csr, plan, terms)
         return _GATAggregate.apply(xw, self.att_src.reshape(-1), self.att_dst.reshape(-1), self.lin_edge.weight,
-                                   self.att_edge, self.bias, csr)
+                                   self.att_edge, self.bias, csr, terms)
 
 
 class _CriticHead(torch.autograd.Function):

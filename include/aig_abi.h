@@ -245,6 +245,15 @@ int aig_gat1_bwd(int64_t n, const float* x, const float* W, const float* att_src
 int aig_linear128(int64_t n, const float* x, const float* w, int w_in_major, const float* bias, int act,
                   float* y, void* stream);
 
+/* aig_linear128 (no bias, no activation) and aig_gat_node_alpha of its output in one launch: y = x W^T together with
+ * a_s, a_d [n,4] and ce [4] of the attention layer the projection belongs to - GATConv.lin and the (x_src * att_src)
+ * .sum(-1) / (x_dst * att_dst).sum(-1) that follow it inside GATConv.forward (models/discriminator.py:61).  A wave
+ * holds one head of its output rows when it stores them, so the node terms need no pass of their own over y.
+ * Same y; a_s, a_d, ce as aig_gat_node_alpha gives them (the sums are taken in the same order). */
+int aig_linear128_node_terms(int64_t n, const float* x, const float* w, int w_in_major, const float* att_src,
+                             const float* att_dst, const float* lin_edge_w, const float* att_edge, float* y,
+                             float* a_s, float* a_d, float* ce, void* stream);
+
 /* Projection of the critic's FIRST attention layer, y = x W^T with x [n,2] (node type, inverter count), w [128,2],
  * y [n,128] - torch.nn.functional.linear inside GATConv(2, 32, heads=4).lin (models/discriminator.py:31,56). */
 int aig_linear_in2(int64_t n, const float* x, const float* w, float* y, void* stream);

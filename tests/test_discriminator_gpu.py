@@ -658,3 +658,53 @@ def test_fused_layers_against_the_separate_kernels(name):
     # ... and twice in a row the fused forms give the same bits (no atomics on floats anywhere)
     s3, g3 = _score_and_grads(D, dd)
     assert torch.equal(s2, s3) and all(torch.equal(g2[k], g3[k]) for k in g2)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 100003])
+def test_node_terms_from_the_projection_launch(n):
+    """aig_linear128_node_terms = aig_linear128 + aig_gat_node_alpha of its output (GATConv.lin and the two
+    (x * att).sum(-1) of models/discriminator.py:61): same rows, node terms and edge coefficients - the sums are
+    taken in the same order, so bit for bit (a product that the compiler fuses differently in the two kernels
+    would show here as a last-bit difference: bound 1e-6 of the largest term then)."""
+    lib = _abi.lib()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 128, generator=g).to(DEV)
+    w = (torch.randn(128, 128, generator=g) / 11).to(DEV)
+    vec = [torch.randn(128, generator=g).to(DEV) for _ in range(4)]
+    f32 = dict(dtype=torch.float32, device=DEV)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    a0, d0, c0 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32), torch.empty(4, **f32)
+    a1, d1, c1 = torch.empty((n, 4), **f32), torch.empty((n, 4), **f32), torch.empty(4, **f32)
+    st = _abi.stream()
+    _abi.check(lib.aig_linear128(n, _abi.ptr(x), _abi.ptr(w), 0, None, 0, _abi.ptr(y0), st), "aig_linear128")
+    _abi.check(lib.aig_gat_node_alpha(n, _abi.ptr(y0), _abi.ptr(vec[0]), _abi.ptr(vec[1]), _abi.ptr(vec[2]), _abi.ptr(vec[3]),
+                                      _abi.ptr(a0), _abi.ptr(d0), _abi.ptr(c0), st), "aig_gat_node_alpha")
+    _abi.check(lib.aig_linear128_node_terms(n, _abi.ptr(x), _abi.ptr(w), 0, _abi.ptr(vec[0]), _abi.ptr(vec[1]), _abi.ptr(vec[2]),
+                                            _abi.ptr(vec[3]), _abi.ptr(y1), _abi.ptr(a1), _abi.ptr(d1), _abi.ptr(c1), st),
+               "aig_linear128_node_terms")
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(c0, c1)
+    scale = float(max(a0.abs().max(), d0.abs().max()))
+    assert float((a0 - a1).abs().max()) <= 1e-6 * scale and float((d0 - d1).abs().max()) <= 1e-6 * scale
+    # against float64 on the host
+    ref = (x.double() @ w.double().t()).view(n, 4, 32)
+    close(a1.cpu().numpy(), (ref * vec[0].double().view(1, 4, 32)).sum(-1).cpu().numpy(), rtol=1e-4, what="a_s")
+    close(d1.cpu().numpy(), (ref * vec[1].double().view(1, 4, 32)).sum(-1).cpu().numpy(), rtol=1e-4, what="a_d")
+
+
+def test_critic_with_and_without_fused_node_terms():
+    from gan_amd import discriminator as dmod
+    d = synth_aig(300, 20000, 200, seed=3, window=512, orientation="dataset")
+    D, _ = make_critic(seed=5)
+    dd = Data(x=d.x.to(DEV), edge_index=d.edge_index.to(DEV), edge_attr=d.edge_attr.to(DEV), node_depth=d.node_depth.to(DEV).long())
+    rows = dmod.NODE_TERMS_MIN_ROWS
+    try:
+        dmod.FUSED_NODE_TERMS = False
+        s0, g0 = _score_and_grads(D, dd)
+        dmod.FUSED_NODE_TERMS, dmod.NODE_TERMS_MIN_ROWS = True, 0      # (taken at any size)
+        s1, g1 = _score_and_grads(D, dd)
+    finally:
+        dmod.FUSED_NODE_TERMS, dmod.NODE_TERMS_MIN_ROWS = True, rows
+    close(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6, what="score")
+    for k in g0:
+        close(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=2e-5, what="grad " + k)
