@@ -934,6 +934,12 @@ class Trainer:
                         if finish_fakes is not None:
                             fake_padded, edges_fake, edges_ready = finish_fakes()
                             fake_for_D, finish_fakes = fake_padded, None
+                        if deferred_wait and not fake_pending:
+                            # no recording of the generated side: the eager pass below reads the padded minibatch
+                            # on this stream
+                            main_stream.wait_stream(fakes_stream)
+                            deferred_wait = False
+                            self._mark("fakes ready")
                         if fake_pending and edges_ready is not None and depth_early is not None:
                             # the generated side's structures were loaded on the second stream: its recorded pass
                             # follows them there, next to this stream's penalty term (one host read on that stream:

@@ -331,9 +331,9 @@ def test_one_launch_update_matches_separate_launches():
 # The step as bench.py runs it (recorded critic terms over all three sides, one-launch update, two streams, level cap
 # from the data), at the sizes bench.py runs it on.  Only there do the position sweeps (from 16,384 nodes), the
 # hub-chunk backward pass, multi-tile sorts and real overlap between the two streams happen inside a step.
-def _bench_trainer(max_nodes, max_edges, level_cap, seed_d):
+def _bench_trainer(max_nodes, max_edges, level_cap, seed_d, capture_fake="auto"):
     args = build_parser().parse_args(["--dataset-dir", "synthetic", "--candidate-k", "64", "--save-every", "1000000000",
-                                      "--capture-fake", "auto"])
+                                      "--capture-fake", capture_fake])
     args.level_cap = level_cap
     tr = Trainer(args, max_nodes, max_edges, DEV)
     tr.G.load_state_dict(gen_state())
@@ -400,8 +400,10 @@ def test_bench_step_on_the_iscas85_sized_minibatch_matches_cpu_checker():
 
 
 @pytest.mark.timeout(600)
-def test_bench_step_is_bitwise_reproducible_across_trainers():
-    """Two fresh trainers, same weights and draws, four steps over three rotating 100k-node minibatches: critic,
+@pytest.mark.parametrize("capture_fake", ["auto", "off"])
+def test_bench_step_is_bitwise_reproducible_across_trainers(capture_fake):
+    """(``off``: the pass over the generated minibatch runs eagerly on the first stream, as in the second timed loop of
+    bench.py - it reads what the second stream pads.)  Two fresh trainers, same weights and draws, four steps over three rotating 100k-node minibatches: critic,
     Adam moments and every logged scalar bit-identical.  No kernel of the library adds floats atomically, so a
     difference between two runs can only come from a missing wait between the step's two streams (a kernel reading
     what another stream has not finished writing)."""
@@ -409,7 +411,7 @@ def test_bench_step_is_bitwise_reproducible_across_trainers():
     _, dev, mn, me, top = _bench_minibatches(groups)
     runs = []
     for _ in range(2):
-        tr, args = _bench_trainer(mn, me, top, seed_d=5)
+        tr, args = _bench_trainer(mn, me, top, seed_d=5, capture_fake=capture_fake)
         g = torch.Generator().manual_seed(23)
         rows = []
         for step in range(4):
