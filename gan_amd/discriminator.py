@@ -566,6 +566,34 @@ class GATLayer(nn.Module):
             state_dict.pop(dst, None)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def forward_by_torch_ops(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
+        """The layer (and the ELU behind it) out of torch operations alone, for the one caller that differentiates
+        the critic TWICE through its edges and w.r.t. its edge attributes: ``gradient_penalty(use_edges=True)``
+        (train.py:154-185, a branch the reference's loop never takes).  The kernels' backward passes are
+        differentiable once; this form is for correctness there, not for speed.  GATConv's steps: self loops are
+        dropped and one per node is appended whose attribute is the mean attribute of the edges entering the node
+        (0 without any); e = leaky_relu(a_s[src] + a_d[dst] + a_e, 0.2); softmax per target with the maximum
+        taken out (no gradient through it) and 1e-16 added to the sum; bias after the heads are concatenated."""
+        n, H, C = int(x.size(0)), self.heads, self.out_per_head
+        ea = edge_attr.reshape(-1, 1).to(x.dtype)
+        ok = (edge_index.min(dim=0).values >= 0) & (edge_index[0] != edge_index[1])
+        src, dst, ea = edge_index[0][ok], edge_index[1][ok], ea[ok]
+        entering = torch.zeros(n, dtype=x.dtype, device=x.device).index_add(0, dst, torch.ones_like(ea[:, 0]))
+        loop_ea = torch.zeros((n, 1), dtype=x.dtype, device=x.device).index_add(0, dst, ea) / entering.clamp(min=1).unsqueeze(1)
+        ids = torch.arange(n, device=x.device, dtype=src.dtype)
+        src, dst, ea = torch.cat([src, ids]), torch.cat([dst, ids]), torch.cat([ea, loop_ea])
+        xw = (x @ self.lin.weight.t()).view(n, H, C)
+        a_s, a_d = (xw * self.att_src).sum(-1), (xw * self.att_dst).sum(-1)
+        a_e = ((ea @ self.lin_edge.weight.t()).view(-1, H, C) * self.att_edge).sum(-1)
+        e = F.leaky_relu(a_s[src] + a_d[dst] + a_e, 0.2)
+        top = torch.full((n, H), float("-inf"), dtype=x.dtype, device=x.device).scatter_reduce(
+            0, dst.unsqueeze(1).expand(-1, H), e.detach(), "amax", include_self=True)
+        w = torch.exp(e - top[dst])
+        total = torch.zeros((n, H), dtype=x.dtype, device=x.device).index_add(0, dst, w)
+        alpha = w / (total[dst] + 1e-16)
+        out = torch.zeros((n, H, C), dtype=x.dtype, device=x.device).index_add(0, dst, alpha.unsqueeze(-1) * xw[src])
+        return F.elu(out.reshape(n, H * C) + self.bias)
+
     def forward(self, x: torch.Tensor, csr: Optional[GraphCSR], plan=None) -> torch.Tensor:
         """``plan``: a level plan - the layer's output then goes straight into the level readout and the
         readout's [1,256] row is returned (the critic's second layer; edge-carrying graphs only)."""
@@ -795,6 +823,17 @@ class AIGDiscriminator(nn.Module):
         edge_index = data.edge_index
         has_edges = edge_index is not None and edge_index.numel() > 0
         edge_attr = data.edge_attr if (hasattr(data, "edge_attr") and data.edge_attr is not None) else None
+        if twice_differentiable and has_edges:
+            # differentiated twice THROUGH the edges (gradient_penalty(use_edges=True), train.py:154-185): the
+            # attention layers out of torch operations, the readout and the head in their twice-differentiable forms
+            _abi.lib()        # (the readout below is a kernel: no library, no critic)
+            ea = edge_attr if edge_attr is not None else torch.zeros((edge_index.size(1), 1), dtype=x.dtype, device=x.device)
+            h = self.gat2.forward_by_torch_ops(self.gat1.forward_by_torch_ops(x, edge_index, ea), edge_index, ea)
+            nd_ = data.node_depth if (hasattr(data, "node_depth") and data.node_depth is not None) else None
+            plan_ = data.__dict__.get("_plan") if hasattr(data, "__dict__") else None
+            if plan_ is None:
+                plan_ = self.level_plan(nd_, n, x.device)
+            return self.out(self.mlp(_LevelPool.apply(h, plan_))).view(-1)
         # a caller that keeps its inputs in fixed buffers hands over the structures it rebuilt in place
         csr = data.__dict__.get("_csr") if hasattr(data, "__dict__") else None
         if csr is None:

@@ -156,23 +156,38 @@ def mean_score(D, data: Data) -> torch.Tensor:
 
 def gradient_penalty(D, real_pad: Data, fake_pad: Data, device, use_edges: bool = True,
                      alpha: Optional[torch.Tensor] = None, plan=None):
-    """Node-feature gradient penalty on an edge-free interpolate (train.py:141-152).
+    """The gradient penalty on an interpolate of the two padded minibatches (train.py:133-185).
 
-    Returns ``(gp, grad_norm)``.  Only the branch the reference's loop takes is provided
-    (``use_edges=False``, train.py:261); its edge-interpolating branch is never reached there.
+    Returns ``(gp, grad_norm)``.  ``use_edges=False`` (what the reference's loop passes, train.py:261), or no edge
+    slot that holds an edge on both sides: node features only, on an edge-free interpolate (train.py:141-152,
+    154-166).  Otherwise the interpolate keeps the real side's edges in the slots where both sides hold one, with
+    interpolated attributes, and the norm is taken over the gradients w.r.t. features and attributes together
+    (train.py:168-185) - the critic then runs out of torch operations (``GATLayer.forward_by_torch_ops``).
     ``plan``: a level plan of ``real_pad.node_depth`` the caller already holds."""
-    if use_edges:
-        raise NotImplementedError("only the node-only gradient penalty (use_edges=False) is implemented")
     if alpha is None:
         alpha = torch.rand(1, 1, device=device)
     x_inter = (alpha * real_pad.x + (1 - alpha) * fake_pad.x).requires_grad_(True)
-    inter = Data(x=x_inter, edge_index=torch.zeros((2, 0), dtype=torch.long, device=device),
-                 edge_attr=torch.zeros((0, 1), dtype=torch.float32, device=device), node_depth=real_pad.node_depth)
+    common = None
+    if use_edges:
+        mask_real, mask_fake = valid_edge_mask(real_pad), valid_edge_mask(fake_pad)
+        if mask_real.numel() > 0 and mask_fake.numel() > 0:
+            common = mask_real & mask_fake
+            if int(common.sum().item()) == 0:
+                common = None
+    if common is None:
+        inter = Data(x=x_inter, edge_index=torch.zeros((2, 0), dtype=torch.long, device=device),
+                     edge_attr=torch.zeros((0, 1), dtype=torch.float32, device=device), node_depth=real_pad.node_depth)
+        wrt = [x_inter]
+    else:
+        ea_inter = (alpha * real_pad.edge_attr.float()[common] + (1 - alpha) * fake_pad.edge_attr.float()[common]).requires_grad_(True)
+        inter = Data(x=x_inter, edge_index=real_pad.edge_index[:, common], edge_attr=ea_inter, node_depth=real_pad.node_depth)
+        wrt = [x_inter, ea_inter]
     if plan is not None:
         inter._plan = plan
     out = D(inter)
-    grads = torch.autograd.grad(out.sum(), [x_inter], create_graph=True, retain_graph=True, only_inputs=True)
-    grad_norm = torch.norm(grads[0].reshape(-1), p=2)
+    grads = torch.autograd.grad(out.sum(), wrt, create_graph=True, retain_graph=True, only_inputs=True)
+    flat = grads[0].reshape(-1) if len(grads) == 1 else torch.cat([g.reshape(-1) for g in grads], dim=0)
+    grad_norm = torch.norm(flat, p=2)
     gp = (grad_norm - 1.0) ** 2
     return gp, grad_norm.detach()
 

@@ -12,7 +12,8 @@ Imported by tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
   forward (PyG 2.3-2.6, ``edge_dim=1``, ``concat=True``, ``add_self_loops=True``,
   ``fill_value='mean'``, ``negative_slope=0.2``) is restated here.  Parity status:
   PARITY UNPINNED - the reference holds no test, fixture or output for this layer.
-* ``gradient_penalty`` follows train.py:133-152 (the only live branch, use_edges=False).
+* ``gradient_penalty`` follows train.py:133-152 (the only live branch, use_edges=False), ``gradient_penalty_edges``
+  the branch the loop never takes (train.py:154-185).
 """
 from __future__ import annotations
 
@@ -328,6 +329,23 @@ def gradient_penalty(p: Dict[str, torch.Tensor], real_x: torch.Tensor, fake_x: t
     out = discriminator_forward(p, x_inter, ei, ea, node_depth, readout=readout)
     grads = torch.autograd.grad(out.sum(), [x_inter], create_graph=True, retain_graph=True, only_inputs=True)
     gn = torch.norm(grads[0].reshape(-1), p=2)
+    return (gn - 1.0) ** 2, gn.detach()
+
+
+def gradient_penalty_edges(p: Dict[str, torch.Tensor], real, fake, alpha: torch.Tensor, readout=None):
+    """train.py:154-185 (use_edges=True) with a given alpha [1,1] on two padded graphs (objects with x, edge_index,
+    edge_attr, node_depth); -> (gp, grad_norm).  Without a slot that holds an edge on both sides: train.py:156-166,
+    the node-only form."""
+    m_r = real.edge_index.min(dim=0).values >= 0 if real.edge_index.numel() else torch.zeros(0, dtype=torch.bool)
+    m_f = fake.edge_index.min(dim=0).values >= 0 if fake.edge_index.numel() else torch.zeros(0, dtype=torch.bool)
+    if m_r.numel() == 0 or m_f.numel() == 0 or int((m_r & m_f).sum()) == 0:
+        return gradient_penalty(p, real.x, fake.x, real.node_depth, alpha, readout=readout)
+    both = m_r & m_f
+    x_inter = (alpha * real.x + (1 - alpha) * fake.x).requires_grad_(True)
+    ea_inter = (alpha * real.edge_attr.float()[both] + (1 - alpha) * fake.edge_attr.float()[both]).requires_grad_(True)
+    out = discriminator_forward(p, x_inter, real.edge_index[:, both], ea_inter, real.node_depth, readout=readout)
+    g_x, g_ea = torch.autograd.grad(out.sum(), [x_inter, ea_inter], create_graph=True, retain_graph=True, only_inputs=True)
+    gn = torch.norm(torch.cat([g_x.reshape(-1), g_ea.reshape(-1)], dim=0), p=2)
     return (gn - 1.0) ** 2, gn.detach()
 
 

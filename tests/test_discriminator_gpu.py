@@ -344,6 +344,42 @@ def test_gradient_penalty_and_double_backward():
         close(v.grad.cpu().numpy(), ref_g.numpy(), rtol=RTOL, what="gp grad " + k)
 
 
+@pytest.mark.parametrize("overlap", ["some", "none"])
+def test_gradient_penalty_through_the_edges(overlap):
+    """``gradient_penalty(use_edges=True)`` (train.py:154-185, never reached by the reference's loop): the interpolate
+    keeps the edge slots that hold an edge on both sides, the norm covers the gradients w.r.t. features and edge
+    attributes, and the penalty is differentiated once more w.r.t. the critic's weights.  Against the checker's
+    restatement of the same lines (no output of the reference exists for this branch: parity unpinned beyond the
+    restatement).  ``none``: no common slot - the node-only form (train.py:156-166)."""
+    from gan_amd.train import gradient_penalty
+    real = pad_data(synth_aig(8, 60, 5, seed=21, window=20, orientation="dataset"), 90, 200)
+    fake = pad_data(synth_aig(8, 60, 5, seed=22, window=20), 90, 200)
+    if overlap == "none":       # the generated side holds its edges where the real side holds padding
+        k = int((real.edge_index.min(dim=0).values >= 0).sum())
+        ei = torch.full_like(fake.edge_index, -1)
+        m = min(int((fake.edge_index.min(dim=0).values >= 0).sum()), ei.size(1) - k)
+        ei[:, k:k + m] = fake.edge_index[:, :m]
+        ea = torch.zeros_like(fake.edge_attr)
+        ea[k:k + m] = fake.edge_attr[:m]
+        fake.edge_index, fake.edge_attr = ei, ea
+    D, p = make_critic(seed=5)
+    alpha = torch.tensor([[0.37]])
+    to_dev = lambda d: Data(x=d.x.to(DEV), edge_index=d.edge_index.to(DEV), edge_attr=d.edge_attr.to(DEV),
+                            node_depth=d.node_depth.to(DEV))
+    gp, gn = gradient_penalty(D, to_dev(real), to_dev(fake), DEV, use_edges=True, alpha=alpha.to(DEV))
+    gp_ref, gn_ref = omodel.gradient_penalty_edges(p, real, fake, alpha)
+    close(gn.item(), gn_ref.item(), what="grad norm")
+    close(gp.item(), gp_ref.item(), what="gp")
+    (10.0 * gp).backward()
+    (10.0 * gp_ref).backward()
+    for k, v in D.named_parameters():
+        ref_g = p[k].grad
+        if ref_g is None or float(ref_g.abs().max()) == 0.0:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        close(v.grad.cpu().numpy(), ref_g.numpy(), rtol=RTOL, what="gp grad " + k)
+
+
 def test_critic_full_size_runs_and_is_reproducible():
     """100k-node graph: finite score, and bitwise identical when repeated (no float atomics)."""
     d = synth_aig(1000, 98000, 1000, seed=0, window=4096, orientation="dataset")

@@ -269,11 +269,6 @@ def test_training_follows_reference_run(name, mode):
     check_epoch(last_epoch)
 
 
-def test_gradient_penalty_rejects_edge_branch():
-    with pytest.raises(NotImplementedError):
-        gradient_penalty(None, None, None, DEV, use_edges=True)
-
-
 def test_sanitize_drops_padding_edges():
     g = pad_data(synth_aig(5, 6, 2, seed=1, window=8), 20, 40).to(DEV)
     s = sanitize_for_D(g)
