@@ -89,6 +89,28 @@ struct RowLimitScope {
 };
 __device__ __forceinline__ int limited_rows(int n, const int* __restrict__ limit) { return limit ? min(n, limit[0]) : n; }
 
+// Sum over the 64 lanes of a wave, in every lane, in the order of a butterfly that pairs lanes 32, 16, 8, 4, 2 and 1
+// apart - what `for (off = 32; off; off >>= 1) v += __shfl_xor(v, off)` computes, bit for bit (a + b == b + a, and
+// after the step for distance d the lanes d apart hold equal values, so a rotation by d/2 inside a row of 16 fetches
+// the same value the exchange would) - out of vector instructions: the two half-swaps of gfx950 and four row
+// rotations.  A shuffle goes through the LDS crossbar and the compiler waits for each one: six in a row cost ~0.3 us,
+// which is what the single-workgroup kernels (critic head, readout finish) mostly consisted of.
+__device__ __forceinline__ float wave_sum_butterfly(float v) {
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false));   // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));   // row_ror:1
+    return v;
+}
+
 // y = act(x W^T + bias), x [M,128] f32, on the bf16 matrix cores at f32 accuracy (dense6.hip).  W: [128][ldw] rows =
 // output columns, or (wt) stored [in][out]; act 0 none, 1 ReLU, 2 ELU.
 int launch_linear128_x6(hipStream_t s, int M, const float* X, const float* W, int ldw, int wt, const float* bias, int act,
