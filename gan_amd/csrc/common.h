@@ -122,6 +122,9 @@ int launch_linear128_x6_terms(hipStream_t s, int M, const float* X, const float*
 // 2 * aig_wgrad_ws_bytes(n, F) bytes (dense.hip)
 int wgrad_sum2(int64_t n, int64_t F, const float* g1, const float* x1, const float* g2, const float* x2, float* dW, void* ws,
                size_t ws_bytes, hipStream_t s);
+// partial sums of g^T x (g, x [n,128]) on the bf16 matrix cores at f32 accuracy: partial[blocks][128][128], units of
+// 32 rows dealt round-robin over the blocks (wgrad6.hip)
+int launch_wgrad128_x6(hipStream_t s, int n, int blocks, const float* g, const float* x, float* partial);
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

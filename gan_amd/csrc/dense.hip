@@ -6,6 +6,7 @@
 // operands are read as 128-byte row segments, no staging), and the partials are added in block
 // order, so the result is reproducible.
 #include <climits>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -238,6 +239,15 @@ namespace aig {
 static int wgrad_partials(hipStream_t s, int64_t n, int64_t F, const float* g, const float* x, float* partial, int* nb_out) {
     int nb;
     if (F == 128) {
+        // the six-product form on the bf16 matrix cores (wgrad6.hip) unless AIG_WGRAD128_F32=1 asks for the f32 products
+        static const bool f32_products = [] { const char* e = getenv("AIG_WGRAD128_F32"); return e && e[0] == '1'; }();
+        if (!f32_products) {
+            nb = wg_blocks(n, 32, WG_BLOCKS_MAX);
+            int rc = launch_wgrad128_x6(s, (int)n, nb, g, x, partial);
+            if (rc) return rc;
+            *nb_out = nb;
+            return AIG_OK;
+        }
         AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wgrad128), (size_t)(WGRAD_LDS)));
         nb = wg_blocks(n, 2 * TILE, WG_BLOCKS_MAX);
         AIG_LAUNCH_TIMED(AIG_KT_WGRAD128, k_wgrad128, dim3(nb), dim3(512), WGRAD_LDS, s, (int)n, g_row_limit, g, x, partial);
