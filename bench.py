@@ -106,7 +106,7 @@ def rocprof_shares():
         with open(path) as f:
             for r in csv.DictReader(f):
                 name = re.sub(r"[(<].*", "", re.sub(r"^(void )?(aig::\(anonymous namespace\)::)?", "", r["Name"]))
-                name = {"k_linear128_x6": "k_linear128"}.get(name, name)     # (the kernel behind aig_linear128)
+                name = {"k_linear128_x6": "k_linear128", "k_wgrad128_x6": "k_wgrad128"}.get(name, name)     # (the kernels behind aig_linear128 / aig_wgrad)
                 out[name] = round(out.get(name, 0.0) + float(r["Percentage"]), 2)
     except (OSError, KeyError, ValueError):
         pass
@@ -117,11 +117,12 @@ def rocprof_shares():
 # what one launch on a graph of n nodes / e edges / `levels` depth levels costs by the algorithm: bytes for the
 # memory-bound ones (every gathered row counts once per list entry, whether a cache serves it or not), flops for the
 # two dense products (which sit at the ridge: their bytes are given too).
-HBM_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_gat1_fwd", "k_gat1_bwd", "k_linear128"]
-MFMA_KERNELS = ["k_wgrad128"]
-# k_linear128 takes its products on the bf16 matrix cores (every f32 operand cut into three bf16 pieces, six piece
-# products: f32 accuracy at 6/16 of the f32 matrix time, csrc/dense6.hip), which leaves it bound by reading X and
-# writing Y: priced against the memory, its f32-equivalent product rate given beside it.
+HBM_KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_gat1_fwd", "k_gat1_bwd", "k_linear128",
+               "k_wgrad128"]
+MFMA_KERNELS = []
+# k_linear128 and k_wgrad128 take their products on the bf16 matrix cores (every f32 operand cut into three bf16
+# pieces, six piece products: f32 accuracy at 6/16 of the f32 matrix time, csrc/dense6.hip, csrc/wgrad6.hip), which
+# leaves them bound by their [n,128] operands: priced against the memory, the f32-equivalent product rate beside it.
 
 
 def timed_kernel_names(lib):
@@ -822,7 +823,7 @@ def main():
                              "traffic": pmc_traffic(a.workload, kernel, kind), "algorithmic_bytes_per_launch": None})
                 return line
             achieved = bytes_alg / (us * 1e-6) / 1e9
-            if kernel == "k_linear128":
+            if kernel in ("k_linear128", "k_wgrad128"):
                 tf = kernel_flops(kernel, nn) / (us * 1e-6) / 1e12
                 line.update({"f32_equivalent_TFLOPs": round(tf, 1), "f32_matrix_peak": MFMA_F32_PEAK_TF,
                              "arithmetic": "six bf16 piece products per f32 product on the bf16 matrix cores, f32 accumulate"})

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 KERNELS = ["k_gat_aggregate", "k_gat_bwd_dst", "k_gat_bwd_src", "k_pool_walk", "k_linear128", "k_wgrad128", "k_gat1_fwd",
            "k_gat1_bwd"]
-ALIAS = {"k_linear128_x6": "k_linear128"}      # the kernel behind aig_linear128
+ALIAS = {"k_linear128_x6": "k_linear128", "k_wgrad128_x6": "k_wgrad128"}      # the kernels behind aig_linear128 / aig_wgrad
 
 
 def read(dirs):
