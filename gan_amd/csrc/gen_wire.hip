@@ -66,52 +66,57 @@ __global__ __launch_bounds__(256) void k_score(int n, int K, const int* __restri
 // ATen's CPU top-k comparator (largest=True): NaN ranks first, then the larger value.
 __device__ __forceinline__ bool gt(float x, float y) { return (isnan(x) && !isnan(y)) || (x > y); }
 
-// Per-thread view of a row while std::nth_element's steps are replayed on it.  Only the permutation
-// moves: position p holds the original index idx[p]; values stay put.  Both live in LDS, laid out
-// [element][thread] so that neighbouring threads touch neighbouring banks.
+// Per-thread view of a row while std::nth_element's steps are replayed on it: position p holds the original index
+// idx[p] AND its value val[p] - both move together, so that a scan step is ONE LDS read (values left in place and
+// looked up through the index made every comparison two dependent reads, and a row's replay is a serial walk of a
+// few hundred of them).  Both live in LDS, laid out [element][thread] so that neighbouring threads touch neighbouring
+// banks.
 template <int STRIDE>
 struct RowView {
     unsigned char* idx;  // idx[p * STRIDE]
-    const float* val;    // val[i * (STRIDE + 1)]  (padded against the transposing fill)
+    float* val;          // val[p * (STRIDE + 1)]  (padded against the transposing fill)
     __device__ __forceinline__ int I(int p) const { return idx[p * STRIDE]; }
-    __device__ __forceinline__ float V(int p) const { return val[I(p) * (STRIDE + 1)]; }
-    __device__ __forceinline__ float Vi(int i) const { return val[i * (STRIDE + 1)]; }
-    __device__ __forceinline__ void set(int p, int i) { idx[p * STRIDE] = static_cast<unsigned char>(i); }
+    __device__ __forceinline__ float V(int p) const { return val[p * (STRIDE + 1)]; }
+    __device__ __forceinline__ void set(int p, int i, float v) {
+        idx[p * STRIDE] = static_cast<unsigned char>(i);
+        val[p * (STRIDE + 1)] = v;
+    }
+    __device__ __forceinline__ void move(int to, int from) { set(to, I(from), V(from)); }
     __device__ __forceinline__ void swap(int p, int q) {
-        int a = I(p), b = I(q);
-        set(p, b);
-        set(q, a);
+        const int a = I(p), b = I(q);
+        const float va = V(p), vb = V(q);
+        set(p, b, vb);
+        set(q, a, va);
     }
 };
 
-// libstdc++ heap primitives on positions [first, first+len), value carried as an original index
+// libstdc++ heap primitives on positions [first, first+len), the value in hand carried as (original index, value)
 template <int S>
-__device__ void push_heap_(RowView<S>& q, int first, int hole, int top, int vi) {
-    const float vv = q.Vi(vi);
+__device__ void push_heap_(RowView<S>& q, int first, int hole, int top, int vi, float vv) {
     int parent = (hole - 1) / 2;
     while (hole > top && gt(q.V(first + parent), vv)) {
-        q.set(first + hole, q.I(first + parent));
+        q.move(first + hole, first + parent);
         hole = parent;
         parent = (hole - 1) / 2;
     }
-    q.set(first + hole, vi);
+    q.set(first + hole, vi, vv);
 }
 template <int S>
-__device__ void adjust_heap_(RowView<S>& q, int first, int hole, int len, int vi) {
+__device__ void adjust_heap_(RowView<S>& q, int first, int hole, int len, int vi, float vv) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
         if (gt(q.V(first + child), q.V(first + child - 1))) --child;
-        q.set(first + hole, q.I(first + child));
+        q.move(first + hole, first + child);
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        q.set(first + hole, q.I(first + child - 1));
+        q.move(first + hole, first + child - 1);
         hole = child - 1;
     }
-    push_heap_(q, first, hole, top, vi);
+    push_heap_(q, first, hole, top, vi, vv);
 }
 template <int S>
 __device__ void heap_select_(RowView<S>& q, int first, int middle, int last) {
@@ -119,17 +124,19 @@ __device__ void heap_select_(RowView<S>& q, int first, int middle, int last) {
     if (len >= 2) {
         int parent = (len - 2) / 2;
         while (true) {
-            int vi = q.I(first + parent);
-            adjust_heap_(q, first, parent, len, vi);
+            const int vi = q.I(first + parent);
+            const float vv = q.V(first + parent);
+            adjust_heap_(q, first, parent, len, vi, vv);
             if (parent == 0) break;
             --parent;
         }
     }
     for (int i = middle; i < last; ++i) {
         if (gt(q.V(i), q.V(first))) {  // pop_heap(first, middle, i)
-            int vi = q.I(i);
-            q.set(i, q.I(first));
-            adjust_heap_(q, first, 0, len, vi);
+            const int vi = q.I(i);
+            const float vv = q.V(i);
+            q.move(i, first);
+            adjust_heap_(q, first, 0, len, vi, vv);
         }
     }
 }
@@ -171,17 +178,17 @@ __device__ void nth_element_(RowView<S>& q, int nth, int c) {
     // insertion sort of [first, last)
     for (int i = first + 1; i < last; ++i) {
         const int vi = q.I(i);
-        const float vv = q.Vi(vi);
+        const float vv = q.V(i);
         if (gt(vv, q.V(first))) {
-            for (int p = i; p > first; --p) q.set(p, q.I(p - 1));
-            q.set(first, vi);
+            for (int p = i; p > first; --p) q.move(p, p - 1);
+            q.set(first, vi, vv);
         } else {
             int p = i;
             while (gt(vv, q.V(p - 1))) {
-                q.set(p, q.I(p - 1));
+                q.move(p, p - 1);
                 --p;
             }
-            q.set(p, vi);
+            q.set(p, vi, vv);
         }
     }
 }
@@ -193,29 +200,36 @@ __device__ void nth_element_(RowView<S>& q, int nth, int c) {
 constexpr int SEL_THREADS = 128;
 constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets two blocks share a CU
 
-__global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
-                                                             const int* __restrict__ cnt,
-                                                             const int* __restrict__ want, int* __restrict__ sel,
-                                                             int fused, GenSet gs) {
+// T rows (threads) a block: 128 - two full waves - or 32, half a wave.  A row's replay is a serial walk whose branches
+// differ from row to row, so a wave spends the SUM of its rows' walks: with few rows in all (a minibatch of small
+// graphs) the narrow form spreads them over four times as many waves, which the GPU has room for.
+template <int T>
+__global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
+                                                   const int* __restrict__ cnt,
+                                                   const int* __restrict__ want, int* __restrict__ sel,
+                                                   int fused, GenSet gs) {
+    static_assert(T == 128 || T == 32, "two waves or half a wave");
+    constexpr int W = T < 64 ? T : 64;            // rows (lanes) of a wave
+    constexpr int PARTS = 128 / W;                // loads that cover a row of fewer than 128 entries
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
         const long long g = blockIdx.y;
         logits += g * (long long)rows * ld; cnt += g * gs.node; want += g * gs.node; sel += g * 2ll * rows;
     }
-    float* val = reinterpret_cast<float*>(smem);                                     // [cap][SEL_THREADS+1]
-    unsigned char* idx = smem + (size_t)cap * (SEL_THREADS + 1) * sizeof(float);     // [cap][SEL_THREADS]
+    float* val = reinterpret_cast<float*>(smem);                           // [cap][T+1]
+    unsigned char* idx = smem + (size_t)cap * (T + 1) * sizeof(float);     // [cap][T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row_base = blockIdx.x * SEL_THREADS;
+    const int row_base = blockIdx.x * T;
 
-    // cooperative fill: each wave copies the short rows of its own 64 threads, coalesced along the row,
-    // eight rows (two loads each: rows have fewer than 128 entries) in flight at a time
+    // cooperative fill: each wave copies the short rows of its own threads, coalesced along the row, eight rows
+    // (rows have fewer than 128 entries: PARTS loads each) in flight at a time
     const int my_r = row_base + tid;
     const int my_c = my_r < rows ? cnt[my_r] : 0;
     const int my_k = my_r < rows ? min(want[my_r], my_c) : 0;
     const bool my_need = my_k > 0 && my_k * 64 > my_c;   // replayed on the LDS copy
     const bool any_need = __syncthreads_or(my_need);
-    for (int t0 = 0; any_need && t0 < 64; t0 += 8) {
-        float v0[8], v1[8];
+    for (int t0 = 0; any_need && t0 < W; t0 += 8) {
+        float v[8][PARTS];
         int cc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -223,14 +237,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, i
             cc[u] = __shfl(my_need ? my_c : 0, t, 64);
             // unconditional loads at clamped addresses (a load under a condition becomes a branch with a wait)
             const float* row = logits + static_cast<size_t>(min(row_base + wave * 64 + t, rows - 1)) * ld;
-            v0[u] = row[min(lane, ld - 1)];
-            v1[u] = row[min(lane + 64, ld - 1)];
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) v[u][part] = row[min(lane + W * part, ld - 1)];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int slot = wave * 64 + t0 + u;
-            if (lane < cc[u]) val[lane * (SEL_THREADS + 1) + slot] = v0[u];
-            if (lane + 64 < cc[u]) val[(lane + 64) * (SEL_THREADS + 1) + slot] = v1[u];
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part)
+                if (lane + W * part < cc[u]) val[(lane + W * part) * (T + 1) + slot] = v[u][part];
         }
     }
     __syncthreads();
@@ -272,8 +287,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, i
                 s1 = top;
             }
         } else {
-            RowView<SEL_THREADS> q{idx + tid, val + tid};
-            for (int j = 0; j < c; ++j) q.set(j, j);
+            RowView<T> q{idx + tid, val + tid};
+            for (int j = 0; j < c; ++j) q.idx[j * T] = static_cast<unsigned char>(j);      // (the values are in place)
             nth_element_(q, k - 1, c);
             // std::sort of the first k-1 <= 1 elements changes nothing
             s0 = q.I(0);
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_topk_select(int rows, int ld, i
 
 // LDS of a block whose longest replayed row has `cap` entries (rows are at most ld long): with the 64
 // candidates of the default window three blocks share a CU instead of two
-constexpr size_t sel_lds(int cap) { return (size_t)cap * ((SEL_THREADS + 1) * sizeof(float) + SEL_THREADS); }
+constexpr size_t sel_lds(int cap, int threads = SEL_THREADS) { return (size_t)cap * ((threads + 1) * sizeof(float) + threads); }
 constexpr size_t SEL_LDS = sel_lds(SEL_CAP);
 
 // ------------------------------------------------------------------------------------------ emit
@@ -784,11 +799,19 @@ int launch_score(hipStream_t s, int B, int n, int K, const int* order, const int
 
 int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, const int* cnt, const int* want, int* sel,
                   bool fused, const GenSet& gs) {
-    AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select), (size_t)(SEL_LDS)));
-    const unsigned blocks = (unsigned)((rows + SEL_THREADS - 1) / SEL_THREADS);
     const int cap = ld < SEL_CAP ? ld : SEL_CAP;
-    hipLaunchKernelGGL(k_topk_select, dim3(blocks, B), dim3(SEL_THREADS), sel_lds(cap), s, rows, ld, cap, logits, cnt,
-                       want, sel, fused ? 1 : 0, gs);
+    // rows in all up to which the narrow form is taken (AIG_SELECT_NARROW_ROWS overrides: a tuning aid)
+    static const long long narrow_rows = [] { const char* e = getenv("AIG_SELECT_NARROW_ROWS"); return e ? atoll(e) : 262144ll; }();
+    if ((long long)rows * B <= narrow_rows) {
+        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select<32>), sel_lds(SEL_CAP, 32)));
+        hipLaunchKernelGGL(k_topk_select<32>, dim3((unsigned)((rows + 31) / 32), B), dim3(32), sel_lds(cap, 32), s, rows, ld, cap,
+                           logits, cnt, want, sel, fused ? 1 : 0, gs);
+    } else {
+        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select<SEL_THREADS>), (size_t)(SEL_LDS)));
+        const unsigned blocks = (unsigned)((rows + SEL_THREADS - 1) / SEL_THREADS);
+        hipLaunchKernelGGL(k_topk_select<SEL_THREADS>, dim3(blocks, B), dim3(SEL_THREADS), sel_lds(cap), s, rows, ld, cap, logits,
+                           cnt, want, sel, fused ? 1 : 0, gs);
+    }
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
