@@ -200,15 +200,15 @@ __device__ void nth_element_(RowView<S>& q, int nth, int c) {
 constexpr int SEL_THREADS = 128;
 constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets two blocks share a CU
 
-// T rows (threads) a block: 128 - two full waves - or 32, half a wave.  A row's replay is a serial walk whose branches
-// differ from row to row, so a wave spends the SUM of its rows' walks: with few rows in all (a minibatch of small
-// graphs) the narrow form spreads them over four times as many waves, which the GPU has room for.
+// T rows (threads) a block: 128 - two full waves - down to 8, an eighth of one.  A row's replay is a serial walk whose
+// branches differ from row to row, so a wave spends the SUM of its rows' walks: the fewer rows there are in all, the
+// fewer a wave is given (launch_select), as long as the GPU has waves to spare.
 template <int T>
 __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
                                                    const int* __restrict__ cnt,
                                                    const int* __restrict__ want, int* __restrict__ sel,
                                                    int fused, GenSet gs) {
-    static_assert(T == 128 || T == 32, "two waves or half a wave");
+    static_assert(T == 128 || T == 32 || T == 16 || T == 8, "two waves, half a wave, a quarter or an eighth");
     constexpr int W = T < 64 ? T : 64;            // rows (lanes) of a wave
     constexpr int PARTS = 128 / W;                // loads that cover a row of fewer than 128 entries
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -302,7 +302,6 @@ __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, co
 // LDS of a block whose longest replayed row has `cap` entries (rows are at most ld long): with the 64
 // candidates of the default window three blocks share a CU instead of two
 constexpr size_t sel_lds(int cap, int threads = SEL_THREADS) { return (size_t)cap * ((threads + 1) * sizeof(float) + threads); }
-constexpr size_t SEL_LDS = sel_lds(SEL_CAP);
 
 // ------------------------------------------------------------------------------------------ emit
 __device__ __forceinline__ int inv_bit(const float* __restrict__ A2, const float* __restrict__ B2,
@@ -800,18 +799,26 @@ int launch_score(hipStream_t s, int B, int n, int K, const int* order, const int
 int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, const int* cnt, const int* want, int* sel,
                   bool fused, const GenSet& gs) {
     const int cap = ld < SEL_CAP ? ld : SEL_CAP;
-    // rows in all up to which the narrow form is taken (AIG_SELECT_NARROW_ROWS overrides: a tuning aid)
-    static const long long narrow_rows = [] { const char* e = getenv("AIG_SELECT_NARROW_ROWS"); return e ? atoll(e) : 262144ll; }();
-    if ((long long)rows * B <= narrow_rows) {
-        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select<32>), sel_lds(SEL_CAP, 32)));
-        hipLaunchKernelGGL(k_topk_select<32>, dim3((unsigned)((rows + 31) / 32), B), dim3(32), sel_lds(cap, 32), s, rows, ld, cap,
-                           logits, cnt, want, sel, fused ? 1 : 0, gs);
-    } else {
-        AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_topk_select<SEL_THREADS>), (size_t)(SEL_LDS)));
-        const unsigned blocks = (unsigned)((rows + SEL_THREADS - 1) / SEL_THREADS);
-        hipLaunchKernelGGL(k_topk_select<SEL_THREADS>, dim3(blocks, B), dim3(SEL_THREADS), sel_lds(cap), s, rows, ld, cap, logits,
-                           cnt, want, sel, fused ? 1 : 0, gs);
-    }
+    // rows a block: the fewest that still leave the GPU with waves to spare (~6,500 in flight: measured 172 -> 72 us
+    // with 8 rows a block on 26k rows, where 8 rows a block on 100k rows took 186 us against 56 with 16)
+    const long long all_rows = (long long)rows * B;
+    auto go = [&](auto kernel, int threads) -> hipError_t {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), sel_lds(SEL_CAP, threads));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + threads - 1) / threads), B), dim3(threads), sel_lds(cap, threads), s, rows,
+                           ld, cap, logits, cnt, want, sel, fused ? 1 : 0, gs);
+        return hipSuccess;
+    };
+    static const int forced = [] { const char* e = getenv("AIG_SELECT_ROWS"); return e ? atoi(e) : 0; }();      // (a tuning aid)
+    // (rows of 128 candidates and more are served while they are scored and only a few percent of the rows are replayed
+    //  here: the blocks' fixed work counts then, 206 against 186 M nodes/s at candidate-k 256 - two full waves a block)
+    const int threads = forced ? forced
+                        : ld >= 128 ? SEL_THREADS
+                        : all_rows <= 52000 ? 8 : all_rows <= 104000 ? 16 : all_rows <= 262144 ? 32 : SEL_THREADS;
+    if (threads == 8) AIG_HIP_CHECK(go(&k_topk_select<8>, 8));
+    else if (threads == 16) AIG_HIP_CHECK(go(&k_topk_select<16>, 16));
+    else if (threads == 32) AIG_HIP_CHECK(go(&k_topk_select<32>, 32));
+    else AIG_HIP_CHECK(go(&k_topk_select<SEL_THREADS>, SEL_THREADS));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
