@@ -6,6 +6,7 @@
 // operands are read as 128-byte row segments, no staging), and the partials are added in block
 // order, so the result is reproducible.
 #include <climits>
+#include <cstdint>
 #include <cstdlib>
 
 #include "common.h"
@@ -237,6 +238,8 @@ extern "C" size_t aig_wgrad_ws_bytes(int64_t n, int64_t F) {
 namespace aig {
 // partial sums of g^T x over the node range into `partial` ([blocks][128][F]); returns the number of blocks
 static int wgrad_partials(hipStream_t s, int64_t n, int64_t F, const float* g, const float* x, float* partial, int* nb_out) {
+    AIG_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0 && (F != 128 || (reinterpret_cast<uintptr_t>(x) & 15) == 0),
+                "aig_wgrad: rows are read as 16-byte vectors (g, and x when it has 128 columns, must be 16-byte aligned)");
     int nb;
     if (F == 128) {
         // the six-product form on the bf16 matrix cores (wgrad6.hip) unless AIG_WGRAD128_F32=1 asks for the f32 products

@@ -6,6 +6,8 @@
 // kernels), ten times per training step.  Here the forward pass, the backward pass and the two
 // passes the gradient penalty needs (the input gradient ds/dr and the weight gradient of <ds/dr, u>)
 // are one single-workgroup launch each.  Sums run in a fixed order: results are reproducible.
+#include <cstdint>
+
 #include "common.h"
 
 namespace aig {
@@ -191,6 +193,9 @@ using namespace aig;
 extern "C" int aig_head_fwd(const float* r, const float* w1, const float* b1, const float* w2, const float* b2,
                             const float* w3, const float* b3, float* score, float* act, void* stream) {
     AIG_REQUIRE(r && w1 && b1 && w2 && b2 && w3 && b3 && score && act, "aig_head_fwd: null pointer");
+    AIG_REQUIRE(((reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(w1)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(w2) & 7) == 0,
+                "aig_head_fwd: r and w1 must be 16-byte aligned, w2 8-byte aligned (rows are read as vectors)");
     hipLaunchKernelGGL(k_head_fwd, dim3(1), dim3(HD_FWD_THREADS), 0, static_cast<hipStream_t>(stream), r, w1, b1, w2, b2,
                        w3, b3, score, act);
     AIG_LAUNCH_CHECK();
@@ -210,6 +215,9 @@ extern "C" int aig_head_bwd(const float* d_score, const float* r, const float* w
 extern "C" int aig_head_input_grad_wgrad(const float* u, const float* w1, const float* w2, const float* w3,
                                          const float* act, float* d_w1, float* d_w2, float* d_w3, void* stream) {
     AIG_REQUIRE(u && w1 && w2 && w3 && act && d_w1 && d_w2 && d_w3, "aig_head_input_grad_wgrad: null pointer");
+    AIG_REQUIRE(((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(w1)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(w2) & 7) == 0,
+                "aig_head_input_grad_wgrad: u and w1 must be 16-byte aligned, w2 8-byte aligned (rows are read as vectors)");
     hipLaunchKernelGGL(k_head_gr_wgrad, dim3(1), dim3(HD_GR_THREADS), 0, static_cast<hipStream_t>(stream), u, w1, w2, w3, act,
                        d_w1, d_w2, d_w3);
     AIG_LAUNCH_CHECK();
