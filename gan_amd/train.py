@@ -617,6 +617,8 @@ class Trainer:
         # ... and the generator step's raw graphs (which depend on nothing the critic iterations compute) are
         # made, padded and loaded into their recording's buffers on a third stream underneath those iterations
         self.raw_stream = self.side_stream
+        # ... and the level sweep of the critic's fakes on one more (a chain of single-workgroup kernels, see step)
+        self.depth_stream = torch.cuda.Stream(device=device)
         # ... and so do the critic's fakes (generator pass and repair), underneath the recorded
         # real-side term of the first critic iteration
         self.overlap_fakes = not bool(getattr(args, "no_overlap", False))
@@ -822,17 +824,22 @@ class Trainer:
                     features_ready.record()
                     self._probe("side: fakes repaired")
             # The generated graphs' levels only need the raw graphs (breadth-first levels over their cleaned edges):
-            # one workgroup sweeps for a quarter of a millisecond.  With the real side replayed up front, the first
-            # stream would wait for the repair next - it takes the sweep instead (enqueued after the repair's launches:
-            # the real-side replay in front of it gives the host the time), and the second stream goes from the
-            # repair straight to the padded edges and edge lists.
+            # three sorts and one workgroup that sweeps for a quarter of a millisecond.  They run on a stream of their
+            # own from the moment the raw graphs exist - next to the repair on the second stream and the real-side
+            # replay on the first (a chain of single-workgroup kernels: it takes nothing from either) - so that the
+            # first stream goes from the real side straight to the penalty term and the second from the repair straight
+            # to the padded edges and edge lists.
             depth_early = depth_ready = None
             if split and real_replayed and terms.fake_side:
-                main_stream.wait_event(raw_ready)
-                depth_early = clean_depth_set(raw_fakes_set)
-                depth_early.record_stream(fakes_stream)
-                depth_ready = torch.cuda.Event()
-                depth_ready.record(main_stream)
+                ds = self.depth_stream
+                ds.wait_event(raw_ready)
+                with torch.cuda.stream(ds):
+                    depth_early = clean_depth_set(raw_fakes_set)
+                    depth_ready = torch.cuda.Event()
+                    depth_ready.record(ds)
+                for t_ in (raw_fakes_set.x, raw_fakes_set.edge_index, raw_fakes_set.count):
+                    if t_ is not None:
+                        t_.record_stream(ds)         # (allocated under the second stream, read by this one)
                 self._probe("main: generated graphs' levels")
             with torch.cuda.stream(fakes_stream):
                 if split:
@@ -851,10 +858,27 @@ class Trainer:
                             if terms.fake_side:
                                 terms.fk.load_edges(edges[0], edges[1])
                             if depth_early is not None:
-                                fakes_stream.wait_event(depth_ready)
-                                corr_set.node_depth = depth_early
-                            else:
-                                corr_set.node_depth = clean_depth_set(raw_fakes_set)
+                                # The padded minibatch and the generated side's level plan follow the penalty term on
+                                # the FIRST stream (which has the time: the second still builds the edge lists when
+                                # the levels arrive); the recorded pass over the generated side, on the second stream,
+                                # waits for them.
+                                with torch.cuda.stream(main_stream):
+                                    main_stream.wait_event(ready)
+                                    main_stream.wait_event(depth_ready)
+                                    for t_ in edges:
+                                        if torch.is_tensor(t_):
+                                            t_.record_stream(main_stream)
+                                    depth_early.record_stream(main_stream)
+                                    corr_set.node_depth = depth_early
+                                    padded = self._pad_set(corr_set, edges)
+                                    terms.fk.load_depth(padded.node_depth, check=False)
+                                    loaded = torch.cuda.Event()
+                                    loaded.record(main_stream)
+                                    n_edges = count_edges(padded.edge_index)
+                                fakes_stream.wait_event(loaded)
+                                self._probe("side: fakes' levels and padding")
+                                return padded, n_edges, ready
+                            corr_set.node_depth = clean_depth_set(raw_fakes_set)
                             padded = self._pad_set(corr_set, edges)
                             if terms.fake_side:
                                 terms.fk.load_depth(padded.node_depth, check=False)
