@@ -126,6 +126,23 @@ int wgrad_sum2(int64_t n, int64_t F, const float* g1, const float* x1, const flo
 // 32 rows dealt round-robin over the blocks (wgrad6.hip)
 int launch_wgrad128_x6(hipStream_t s, int n, int blocks, const float* g, const float* x, float* partial);
 
+// The closed-form gradient penalty over tiles of 32 rows (gp_tile.hip): forward, input gradient (partial[blocks] =
+// shares of |g_x|^2, zero for blocks without rows) and everything behind the norm (partial: gp_tiles_partial_bytes()).
+// AIG_GP_TILES=0 in the environment keeps the chain of one kernel per pass (gp.hip).
+bool gp_tiles_enabled();
+size_t gp_tiles_partial_bytes();
+int launch_gp_tiles_fwd(hipStream_t s, int n, const int* row_limit, const float* xr, const float* xf, const float* alpha,
+                        const float* W1, const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2);
+int launch_gp_tiles_input_grad(hipStream_t s, int n, const int* row_limit, int L, const int* meta, const float* g_r,
+                               const int* node_level, const float* w, const int* argmax, const float* W1, const float* W2,
+                               const float* h1, const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x,
+                               float* partial, int* blocks);
+int launch_gp_tiles_param_grad(hipStream_t s, int n, const int* row_limit, int L, const int* meta, const float* coef,
+                               const float* g_r, const int* node_level, const float* w, const int* argmax, const float* W1,
+                               const float* W2, const float* xhat, const float* h1, const float* h2, const float* g_z2,
+                               const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1, float* dW2,
+                               float* db2, float* ubar_gr, float* partial);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // Direct global -> LDS load of 16 bytes per lane that the compiler's wait-count bookkeeping does not

@@ -340,6 +340,7 @@ extern "C" int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float*
     AIG_REQUIRE(n > 0 && n < INT_MAX, "aig_gp_forward: n=%lld out of range", (long long)n);
     AIG_REQUIRE(x_real && x_fake && alpha && W1 && b1 && W2 && b2 && xhat && h1 && h2, "aig_gp_forward: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gp_tiles_enabled()) return launch_gp_tiles_fwd(s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, W2, b2, xhat, h1, h2);
     hipLaunchKernelGGL(k_gp_enc, dim3(gp_blocks(n)), dim3(THREADS), 0, s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, xhat, h1);
     AIG_LAUNCH_CHECK();
     RowLimitScope limit(n_rows_dev);
@@ -375,6 +376,16 @@ extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
                 "aig_gp_input_grad: null pointer");
     if (ws_bytes < aig_gp_input_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_input_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    float* partial = static_cast<float*>(ws);
+    if (gp_tiles_enabled()) {
+        int blocks = 0;
+        int rc = launch_gp_tiles_input_grad(s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w, argmax, W1, W2, h1, h2,
+                                            g_z2, g_h1, g_z1, g_x, partial, &blocks);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(256), 0, s, blocks, 1, partial, norm_sq);
+        AIG_LAUNCH_CHECK();
+        return AIG_OK;
+    }
     RowLimitScope limit(n_rows_dev);
     const int g = gp_blocks(n);
     hipLaunchKernelGGL(k_gp_gz2, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w, argmax,
@@ -382,7 +393,6 @@ extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
     AIG_LAUNCH_CHECK();
     int rc = aig_linear128(n, g_z2, W2, 1, nullptr, 0, g_h1, stream);
     if (rc) return rc;
-    float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL(k_gp_gx, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, g_h1, h1, W1, g_z1, g_x, partial);
     hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(256), 0, s, g, 1, partial, norm_sq);
     AIG_LAUNCH_CHECK();
@@ -392,8 +402,10 @@ extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
 extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
     const size_t N = (size_t)(n > 0 ? n : 1);
     size_t wg = 2 * aig_wgrad_ws_bytes(n, H), wg2 = 2 * aig_wgrad_ws_bytes(n, 2);      // (two products per weight)
-    return 5 * align_up(N * H * 4) + align_up(N * 2 * 4) + align_up((size_t)GP_BLOCKS_MAX * 3 * H * 4) +
-           align_up(wg > wg2 ? wg : wg2) + 1024;
+    const size_t chain = 5 * align_up(N * H * 4) + align_up(N * 2 * 4) + align_up((size_t)GP_BLOCKS_MAX * 3 * H * 4) +
+                         align_up(wg > wg2 ? wg : wg2) + 1024;
+    const size_t tiles = gp_tiles_partial_bytes() + 256;
+    return gp_tiles_enabled() ? tiles : chain;
 }
 
 extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
@@ -408,6 +420,9 @@ extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
                 "aig_gp_param_grad: null pointer");
     if (ws_bytes < aig_gp_param_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_param_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gp_tiles_enabled())
+        return launch_gp_tiles_param_grad(s, (int)n, n_rows_dev, (int)L, lvl_meta, coef, g_r, node_level, w, argmax, W1, W2, xhat,
+                                          h1, h2, g_z2, g_h1, g_z1, g_x, dW1, db1, dW2, db2, ubar_gr, static_cast<float*>(ws));
     const size_t NH = (size_t)n * H;
     Carver c(ws);
     float* ubar_gh1 = c.take<float>(NH);
