@@ -39,10 +39,15 @@ __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : expm1f(z); 
 __device__ __forceinline__ int acc_row(int i, int kh) { return (i & 3) + 8 * (i >> 2) + 4 * kh; }
 
 __device__ __forceinline__ void stage_w2(float* __restrict__ W2s, const float* __restrict__ W2) {
-    for (int q = threadIdx.x; q < H * H / 4; q += THREADS) {
-        const float4 v = reinterpret_cast<const float4*>(W2)[q];
+    constexpr int N = H * H / 4 / THREADS;      // 16-byte loads per thread, all in flight before the first write
+    float4 v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = reinterpret_cast<const float4*>(W2)[threadIdx.x + u * THREADS];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int q = threadIdx.x + u * THREADS;
         float* d = W2s + (q >> 5) * LD + 4 * (q & 31);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
     }
 }
 
@@ -154,17 +159,25 @@ __global__ __launch_bounds__(THREADS) void k_gpt_input_grad(int n, const int* __
             lv[t] = row < n ? node_level[row] : -1;
         }
         __syncthreads();
+        // (loads of rows past the end go to the last row instead of standing under a condition: sixteen loads in
+        //  flight, not sixteen round trips)
+        float hv2[16], hv1[16];
+        int am[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = acc_row(i, kh), rr = min(row0 + r, n - 1);
+            hv2[i] = h2[(size_t)rr * H + c];
+            am[i] = argmax[(size_t)max(lv[r], 0) * H + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hv1[i] = h1[(size_t)min(row0 + acc_row(i, kh), n - 1) * H + c];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = acc_row(i, kh), row = row0 + r;
-            float gz = 0.f;
-            if (row < n) {
-                const int lvl = lv[r];
-                const bool hit = lvl >= 0 && argmax[(size_t)lvl * H + c] == row;
-                const float pull = wr[r] * g_mean + (hit ? g_max * inv_levels : 0.f);
-                gz = pull * d_elu(h2[(size_t)row * H + c]);
-                g_z2[(size_t)row * H + c] = gz;
-            }
+            const bool hit = lv[r] >= 0 && am[i] == row;
+            const float pull = wr[r] * g_mean + (hit ? g_max * inv_levels : 0.f);
+            const float gz = row < n ? pull * d_elu(hv2[i]) : 0.f;
+            if (row < n) g_z2[(size_t)row * H + c] = gz;
             TA[r * LD + c] = gz;
         }
         __syncthreads();
@@ -172,10 +185,9 @@ __global__ __launch_bounds__(THREADS) void k_gpt_input_grad(int n, const int* __
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = acc_row(i, kh), row = row0 + r;
-            float z = 0.f;
+            const float z = row < n ? acc[i] * d_elu(hv1[i]) : 0.f;
             if (row < n) {
                 g_h1[(size_t)row * H + c] = acc[i];
-                z = acc[i] * d_elu(h1[(size_t)row * H + c]);
                 g_z1[(size_t)row * H + c] = z;
             }
             TB[r * LD + c] = z;
@@ -264,55 +276,64 @@ __global__ __launch_bounds__(THREADS) void k_gpt_param_grad(
             lv[t] = row < n ? node_level[row] : -1;
         }
         __syncthreads();
-        float dz1a[16];
+        // (loads of rows past the end go to the last row instead of standing under a condition: all of a phase's
+        //  loads in flight at once)
+        float dz1a[16], hv2[16], gz1[16];
+        int am[16];
+        {
+            float hv[16], gz[16], gv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = acc_row(i, kh), row = row0 + r;
-            float ug = 0.f, hv = 0.f, gz = 0.f;
-            dz1a[i] = 0.f;
-            if (row < n) {
-                hv = h1[(size_t)row * H + c];
-                gz = g_z2[(size_t)row * H + c];
-                const float gv = g_h1[(size_t)row * H + c];
-                const float z = us[2 * r] * w0 + us[2 * r + 1] * w1;
-                ug = z * d_elu(hv);
-                dz1a[i] = z * gv * dd_elu(hv);
+            for (int i = 0; i < 16; ++i) {
+                const size_t at = (size_t)min(row0 + acc_row(i, kh), n - 1) * H + c;
+                hv[i] = h1[at];
+                gz[i] = g_z2[at];
+                gv[i] = g_h1[at];
             }
-            T_ug1[r * LD + c] = ug;
-            T_h1[r * LD + c] = hv;
-            T_gz2[r * LD + c] = gz;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = acc_row(i, kh);
+                const size_t at = (size_t)min(row0 + r, n - 1) * H + c;
+                hv2[i] = h2[at];
+                gz1[i] = g_z1[at];
+                am[i] = argmax[(size_t)max(lv[r], 0) * H + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = acc_row(i, kh);
+                const bool valid = row0 + r < n;
+                const float z = us[2 * r] * w0 + us[2 * r + 1] * w1;
+                dz1a[i] = valid ? z * gv[i] * dd_elu(hv[i]) : 0.f;
+                T_ug1[r * LD + c] = valid ? z * d_elu(hv[i]) : 0.f;
+                T_h1[r * LD + c] = valid ? hv[i] : 0.f;
+                T_gz2[r * LD + c] = valid ? gz[i] : 0.f;
+            }
         }
         __syncthreads();
         const f32x16 zv2 = tile_times_w2<true>(T_ug1, W2s, ln, kh, c);       // ubar_gz2
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = acc_row(i, kh), row = row0 + r;
-            float dz = 0.f;
-            if (row < n) {
-                const float hv = h2[(size_t)row * H + c];
-                const int lvl = lv[r];
-                const float wi = wr[r];
-                const float pick = (lvl >= 0 && argmax[(size_t)lvl * H + c] == row) ? inv_levels : 0.f;
-                const float gh = wi * g_mean + pick * g_max;
-                const float ug2 = zv2[i] * d_elu(hv);
-                dz = zv2[i] * gh * dd_elu(hv);
-                sb += dz;
-                sm += wi * ug2;
-                sx += pick * ug2;
-            }
+            const bool valid = row < n;
+            const float wi = wr[r];
+            const float pick = (valid && lv[r] >= 0 && am[i] == row) ? inv_levels : 0.f;
+            const float gh = wi * g_mean + pick * g_max;
+            const float ug2 = valid ? zv2[i] * d_elu(hv2[i]) : 0.f;
+            const float dz = valid ? zv2[i] * gh * dd_elu(hv2[i]) : 0.f;
+            sb += dz;
+            sm += wi * ug2;
+            sx += pick * ug2;
             T_dz2[r * LD + c] = dz;
         }
         __syncthreads();
         const f32x16 dh1 = tile_times_w2<false>(T_dz2, W2s, ln, kh, c);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int r = acc_row(i, kh), row = row0 + r;
-            if (row < n) {
+            const int r = acc_row(i, kh);
+            if (row0 + r < n) {
                 const float dz1 = dz1a[i] + dh1[i] * d_elu(T_h1[r * LD + c]);
-                const float gz1 = g_z1[(size_t)row * H + c];
                 sb1 += dz1;
-                d10 += gz1 * us[2 * r] + dz1 * xh[2 * r];
-                d11 += gz1 * us[2 * r + 1] + dz1 * xh[2 * r + 1];
+                d10 += gz1[i] * us[2 * r] + dz1 * xh[2 * r];
+                d11 += gz1[i] * us[2 * r + 1] + dz1 * xh[2 * r + 1];
             }
         }
         // dW2[m][c] += sum_rows g_z2[row][m] ubar_gh1[row][c] + dz2[row][m] h1[row][c]
