@@ -25,22 +25,43 @@ constexpr int COEF = 20;
 // columns of a block's partial row in the backward pass
 constexpr int P_BIAS = 0, P_DW0 = H, P_DW1 = 2 * H, P_CE = 3 * H, P_SS = 3 * H + 4, P_SD = 3 * H + 12, P_WIDTH = 3 * H + 20;
 
+// coefficient t (< COEF) of the layer: a 32-term dot product, terms in ascending order
+__device__ __forceinline__ float coef_of(int t, const float* __restrict__ W, const float* __restrict__ att_src,
+                                         const float* __restrict__ att_dst, const float* __restrict__ lin_edge_w,
+                                         const float* __restrict__ att_edge) {
+    constexpr int C = H / HEADS;
+    float s = 0.f;
+    if (t < 16) {
+        const int which = t >> 3, f = (t >> 2) & 1, h = t & 3;
+        const float* a = which ? att_dst : att_src;
+        float wv[C], av[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            wv[c] = W[(h * C + c) * 2 + f];
+            av[c] = a[h * C + c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += wv[c] * av[c];
+    } else {
+        const int h = t - 16;
+        float wv[C], av[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            wv[c] = lin_edge_w[h * C + c];
+            av[c] = att_edge[h * C + c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += wv[c] * av[c];
+    }
+    return s;
+}
+
+// (the forward kernel computes the coefficients itself, per block; this launch serves an empty graph)
 __global__ void k_gat1_coef(const float* __restrict__ W, const float* __restrict__ att_src,
                             const float* __restrict__ att_dst, const float* __restrict__ lin_edge_w,
                             const float* __restrict__ att_edge, float* __restrict__ coef) {
     const int t = threadIdx.x;
-    if (t < 16) {
-        const int which = t >> 3, f = (t >> 2) & 1, h = t & 3;
-        const float* a = which ? att_dst : att_src;
-        float s = 0.f;
-        for (int c = 0; c < H / HEADS; ++c) s += W[(h * (H / HEADS) + c) * 2 + f] * a[h * (H / HEADS) + c];
-        coef[t] = s;
-    } else if (t < COEF) {
-        const int h = t - 16;
-        float s = 0.f;
-        for (int c = 0; c < H / HEADS; ++c) s += lin_edge_w[h * (H / HEADS) + c] * att_edge[h * (H / HEADS) + c];
-        coef[t] = s;
-    }
+    if (t < COEF) coef[t] = coef_of(t, W, att_src, att_dst, lin_edge_w, att_edge);
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -173,15 +194,24 @@ __device__ __forceinline__ float4 inv_den4(float4 den) {
                        1.f / (den.w + SOFTMAX_EPS));
 }
 
+// The layer's twenty coefficients (products of weights only) are computed here, by every block for itself, instead
+// of by a launch in front of this one; block 0 leaves them in `coef` for the backward pass.
 __global__ __launch_bounds__(THREADS) void k_gat1_fwd(int n, const float2* __restrict__ x, const float* __restrict__ W,
-                                                      const float* __restrict__ coef, const float* __restrict__ bias,
+                                                      const float* __restrict__ att_src, const float* __restrict__ att_dst,
+                                                      const float* __restrict__ lin_edge_w, const float* __restrict__ att_edge,
+                                                      float* __restrict__ coef, const float* __restrict__ bias,
                                                       Lists g, float* __restrict__ out, float* __restrict__ alpha_e,
                                                       float* __restrict__ alpha_loop) {
     __shared__ float s_xa[WAVES][NODES_PER_WAVE][8];      // per node: xa[f][h] = sum over its list of alpha_h * x_f
+    __shared__ __attribute__((aligned(16))) float s_coef[COEF];
+    if (threadIdx.x < COEF) {
+        const float v = coef_of(threadIdx.x, W, att_src, att_dst, lin_edge_w, att_edge);
+        s_coef[threadIdx.x] = v;
+        if (blockIdx.x == 0) coef[threadIdx.x] = v;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k = lane >> 3, j = lane & 7;       // entry phase: node of the wave's eight, list entry
     const int l = lane & 31, hv = lane >> 5, h = l >> 3;   // row phase: channel quad, which of the two nodes, head
-    const Coef cf(coef);
     const LaneW w = lane_weights(W, l);
     const float4 b4 = ld4(bias + 4 * l);
     float4* alpha_e4 = reinterpret_cast<float4*>(alpha_e);
@@ -193,6 +223,8 @@ __global__ __launch_bounds__(THREADS) void k_gat1_fwd(int n, const float2* __res
     const int first = r.begin + wv * NODES_PER_WAVE;
     ListReader::Bounds bd = rd.bounds(first + k), bd1 = rd.bounds(first + NODES_PER_BLOCK_TURN + k);
     ListReader::Entry en = rd.entry_of(bd, j);
+    __syncthreads();
+    const Coef cf(s_coef);
     for (int base = first; base < r.end; base += NODES_PER_BLOCK_TURN) {
         // ---- entry phase: node base + k, entry j (requests of the turns ahead first)
         const float2 xs = x[en.s];
@@ -532,13 +564,16 @@ extern "C" int aig_gat1_fwd(int64_t n, const float* x, const float* W, const flo
     AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat1_fwd: n=%lld out of range", (long long)n);
     AIG_REQUIRE(W && att_src && att_dst && lin_edge_w && att_edge && coef, "aig_gat1_fwd: null parameter");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_gat1_coef, dim3(1), dim3(64), 0, s, W, att_src, att_dst, lin_edge_w, att_edge, coef);
-    AIG_LAUNCH_CHECK();
-    if (n == 0) return AIG_OK;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_gat1_coef, dim3(1), dim3(64), 0, s, W, att_src, att_dst, lin_edge_w, att_edge, coef);
+        AIG_LAUNCH_CHECK();
+        return AIG_OK;
+    }
     AIG_REQUIRE(x && bias && row_ptr && loop_ea && out && alpha_loop, "aig_gat1_fwd: null pointer");
     const Lists g{row_ptr, csr_src, csr_ea, loop_ea};
     AIG_LAUNCH_TIMED(AIG_KT_GAT1_FWD, k_gat1_fwd, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n,
-                     reinterpret_cast<const float2*>(x), W, coef, bias, g, out, alpha_e, alpha_loop);
+                     reinterpret_cast<const float2*>(x), W, att_src, att_dst, lin_edge_w, att_edge, coef, bias, g, out, alpha_e,
+                     alpha_loop);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }
