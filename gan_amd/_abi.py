@@ -59,6 +59,7 @@ SIGNATURES = {
     "aig_gat_csr": (INT, [I64, I64] + [P] * 11 + [P, SZ, P]),
     "aig_gat_node_alpha": (INT, [I64, P, P, P, P, P, P, P, P, P]),
     "aig_gat_fwd": (INT, [I64] + [P] * 12 + [P]),
+    "aig_gat_fwd_clearing": (INT, [I64] + [P] * 12 + [P, SZ, P]),
     "aig_gat_bwd_ws_bytes": (SZ, [I64, I64]),
     "aig_gat_bwd": (INT, [I64, I64] + [P] * 27 + [P, SZ, P]),
     "aig_gat_bwd_pooled": (INT, [I64, I64, I64] + [P] * 31 + [P, SZ, P]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "aig_gp_rows_ws_bytes": (SZ, [I64, I64]),
     "aig_gp_rows": (INT, [I64, I64, I64] + [P] * 12 + [P, SZ, P]),
     "aig_gp_forward": (INT, [I64, P] + [P] * 10 + [P]),
+    "aig_gp_forward_clearing": (INT, [I64, P] + [P] * 10 + [P, SZ, P]),
     "aig_gp_scalars": (INT, [P, C.c_float, P, P]),
     "aig_adam_chunk_elems": (INT, []),
     "aig_adam_sum3": (INT, [I64, P, I64, P, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float,
@@ -95,6 +97,8 @@ SIGNATURES = {
     "aig_level_plan_dyn": (INT, [I64, I64, P, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_ws_bytes": (SZ, [I64, I64]),
     "aig_level_pool_fwd": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
+    "aig_level_pool_table_bytes": (SZ, [I64]),
+    "aig_level_pool_fwd_cleared": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P, SZ, P]),
     "aig_level_pool_fwd_noalloc": (INT, [I64, I64, I64, P, P, P, P, P, P, P, P, P]),
     "aig_enforce_ws_bytes": (SZ, [I64, I64]),
     "aig_enforce": (INT, [I64, I64, P, P, P, INT, P, P, I64, P, P, P, P, P, SZ, P]),

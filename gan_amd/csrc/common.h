@@ -132,7 +132,8 @@ int launch_wgrad128_x6(hipStream_t s, int n, int blocks, const float* g, const f
 bool gp_tiles_enabled();
 size_t gp_tiles_partial_bytes();
 int launch_gp_tiles_fwd(hipStream_t s, int n, const int* row_limit, const float* xr, const float* xf, const float* alpha,
-                        const float* W1, const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2);
+                        const float* W1, const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2,
+                        void* clear, size_t clear_bytes);
 int launch_gp_tiles_input_grad(hipStream_t s, int n, const int* row_limit, int L, const int* meta, const float* g_r,
                                const int* node_level, const float* w, const int* argmax, const float* W1, const float* W2,
                                const float* h1, const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x,

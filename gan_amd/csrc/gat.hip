@@ -173,9 +173,13 @@ __global__ __launch_bounds__(THREADS) void k_gat_aggregate(
     int n, const float* __restrict__ xw, const float* __restrict__ a_s, const float* __restrict__ a_d,
     const float* __restrict__ ce, const float* __restrict__ bias, const int* __restrict__ row_ptr,
     const int* __restrict__ csr_src, const float* __restrict__ csr_ea, const float* __restrict__ loop_ea,
-    float* __restrict__ out, float* __restrict__ alpha_e, float* __restrict__ alpha_loop) {
+    float* __restrict__ out, float* __restrict__ alpha_e, float* __restrict__ alpha_loop,
+    uint2* __restrict__ clear, int clear_count) {
     __shared__ float s_alpha[HW_PER_BLOCK][32][HEADS];
     const int l = threadIdx.x & 31, hw = threadIdx.x >> 5, h = l >> 3;
+    // a buffer the next kernel on the stream wants zeroed (the readout's table of maxima): a few stores per block
+    // here instead of a launch of its own in between
+    for (int q = blockIdx.x * THREADS + threadIdx.x; q < clear_count; q += gridDim.x * THREADS) clear[q] = make_uint2(0u, 0u);
     const float4 ce4 = make_float4(ce[0], ce[1], ce[2], ce[3]);
     const float4 b4 = reinterpret_cast<const float4*>(bias)[l];
     const float4* xw4 = reinterpret_cast<const float4*>(xw);
@@ -753,17 +757,32 @@ extern "C" int aig_gat_node_alpha(int64_t n, const float* xw, const float* att_s
     return AIG_OK;
 }
 
+extern "C" int aig_gat_fwd_clearing(int64_t n, const float* xw, const float* a_s, const float* a_d, const float* ce,
+                                    const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                                    const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* clear,
+                                    size_t clear_bytes, void* stream) {
+    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat_fwd: n=%lld out of range", (long long)n);
+    AIG_REQUIRE(clear_bytes == 0 || (clear && (reinterpret_cast<uintptr_t>(clear) & 7) == 0 && clear_bytes % 8 == 0 &&
+                                     clear_bytes / 8 < (size_t)INT_MAX),
+                "aig_gat_fwd_clearing: the buffer to clear must be 8-byte aligned and a multiple of 8 bytes long");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        if (clear_bytes) AIG_HIP_CHECK(fill_words(clear, 0u, clear_bytes, s));
+        return AIG_OK;
+    }
+    AIG_REQUIRE(xw && a_s && a_d && ce && bias && row_ptr && loop_ea && out && alpha_loop, "aig_gat_fwd: null pointer");
+    AIG_LAUNCH_TIMED(AIG_KT_GAT_AGGREGATE, k_gat_aggregate, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d,
+                     ce, bias, row_ptr, csr_src, csr_ea, loop_ea, out, alpha_e, alpha_loop, static_cast<uint2*>(clear),
+                     (int)(clear_bytes / 8));
+    AIG_LAUNCH_CHECK();
+    return AIG_OK;
+}
+
 extern "C" int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const float* a_d, const float* ce,
                            const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
                            const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* stream) {
-    AIG_REQUIRE(n >= 0 && n < INT_MAX, "aig_gat_fwd: n=%lld out of range", (long long)n);
-    if (n == 0) return AIG_OK;
-    AIG_REQUIRE(xw && a_s && a_d && ce && bias && row_ptr && loop_ea && out && alpha_loop, "aig_gat_fwd: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    AIG_LAUNCH_TIMED(AIG_KT_GAT_AGGREGATE, k_gat_aggregate, dim3(grid_blocks(n)), dim3(THREADS), 0, s, (int)n, xw, a_s, a_d,
-                     ce, bias, row_ptr, csr_src, csr_ea, loop_ea, out, alpha_e, alpha_loop);
-    AIG_LAUNCH_CHECK();
-    return AIG_OK;
+    return aig_gat_fwd_clearing(n, xw, a_s, a_d, ce, bias, row_ptr, csr_src, csr_ea, loop_ea, out, alpha_e, alpha_loop, nullptr,
+                                0, stream);
 }
 
 extern "C" size_t aig_gat_bwd_ws_bytes(int64_t n, int64_t E) {

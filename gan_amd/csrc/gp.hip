@@ -334,17 +334,28 @@ extern "C" int aig_level_pool_bwd_adj(int64_t n, int64_t L, const int32_t* lvl_m
 }
 
 // --------------------------------------------------------------------------------------------- gradient penalty
-extern "C" int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
-                              const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2,
-                              void* stream) {
+extern "C" int aig_gp_forward_clearing(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake,
+                                       const float* alpha, const float* W1, const float* b1, const float* W2, const float* b2,
+                                       float* xhat, float* h1, float* h2, void* clear, size_t clear_bytes, void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX, "aig_gp_forward: n=%lld out of range", (long long)n);
     AIG_REQUIRE(x_real && x_fake && alpha && W1 && b1 && W2 && b2 && xhat && h1 && h2, "aig_gp_forward: null pointer");
+    AIG_REQUIRE(clear_bytes == 0 || (clear && (reinterpret_cast<uintptr_t>(clear) & 7) == 0 && clear_bytes % 8 == 0 &&
+                                     clear_bytes / 8 < (size_t)INT_MAX),
+                "aig_gp_forward_clearing: the buffer to clear must be 8-byte aligned and a multiple of 8 bytes long");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (gp_tiles_enabled()) return launch_gp_tiles_fwd(s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, W2, b2, xhat, h1, h2);
+    if (gp_tiles_enabled())
+        return launch_gp_tiles_fwd(s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, W2, b2, xhat, h1, h2, clear, clear_bytes);
+    if (clear_bytes) AIG_HIP_CHECK(fill_words(clear, 0u, clear_bytes, s));
     hipLaunchKernelGGL(k_gp_enc, dim3(gp_blocks(n)), dim3(THREADS), 0, s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, xhat, h1);
     AIG_LAUNCH_CHECK();
     RowLimitScope limit(n_rows_dev);
     return aig_linear128(n, h1, W2, 0, b2, 2, h2, stream);
+}
+
+extern "C" int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
+                              const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2,
+                              void* stream) {
+    return aig_gp_forward_clearing(n, n_rows_dev, x_real, x_fake, alpha, W1, b1, W2, b2, xhat, h1, h2, nullptr, 0, stream);
 }
 
 __global__ void k_gp_scalars(const float* __restrict__ norm_sq, float scale, float* __restrict__ out3) {

@@ -76,11 +76,13 @@ __global__ __launch_bounds__(THREADS) void k_gpt_fwd(int n, const int* __restric
                                                      const float* __restrict__ W1, const float* __restrict__ b1,
                                                      const float* __restrict__ W2, const float* __restrict__ b2,
                                                      float* __restrict__ xhat, float* __restrict__ h1,
-                                                     float* __restrict__ h2) {
+                                                     float* __restrict__ h2, uint2* __restrict__ clear, int clear_count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* W2s = lds;
     float* TA = W2s + H * LD;
     float* xs = TA + TR * LD;
+    // (what the readout behind this kernel wants zeroed: by every block of the grid, with or without a tile)
+    for (int q = blockIdx.x * THREADS + threadIdx.x; q < clear_count; q += gridDim.x * THREADS) clear[q] = make_uint2(0u, 0u);
     n = limited_rows(n, row_limit);
     const int ntiles = (n + TR - 1) / TR;
     if ((int)blockIdx.x >= ntiles) return;
@@ -411,13 +413,14 @@ bool gp_tiles_enabled() {
 size_t gp_tiles_partial_bytes() { return align_up((size_t)GPT_BLOCKS_MAX * P_ROW * 4); }
 
 int launch_gp_tiles_fwd(hipStream_t s, int n, const int* row_limit, const float* xr, const float* xf, const float* alpha,
-                        const float* W1, const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2) {
+                        const float* W1, const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2,
+                        void* clear, size_t clear_bytes) {
     AIG_REQUIRE(((reinterpret_cast<uintptr_t>(xr) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(xhat)) & 7) == 0 &&
                     (reinterpret_cast<uintptr_t>(W2) & 15) == 0,
                 "gradient penalty: feature rows are read as 8-byte pairs, the weight as 16-byte vectors");
     AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_gpt_fwd), LDS_FWD));
     hipLaunchKernelGGL(k_gpt_fwd, dim3(tiles_grid(n)), dim3(THREADS), LDS_FWD, s, n, row_limit, xr, xf, alpha, W1, b1, W2, b2,
-                       xhat, h1, h2);
+                       xhat, h1, h2, static_cast<uint2*>(clear), (int)(clear_bytes / 8));
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -343,10 +343,12 @@ extern "C" size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L) {
     return align_up((size_t)(L + 1) * H * 8) + align_up(blocks * H * 4) + 256;
 }
 
-extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
-                                  const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level,
-                                  const float* w, float* out, int32_t* argmax, void* ws, size_t ws_bytes,
-                                  void* stream) {
+extern "C" size_t aig_level_pool_table_bytes(int64_t L) { return (size_t)(L > 0 ? L + 1 : 1) * H * 8; }
+
+namespace {
+int pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h, const int32_t* perm,
+             const int32_t* lvl_ptr, const int32_t* node_level, const float* w, float* out, int32_t* argmax, void* ws,
+             size_t ws_bytes, bool table_cleared, void* stream) {
     AIG_REQUIRE(n >= 0 && n < INT_MAX && L >= 0 && nvalid >= 0 && nvalid <= n, "aig_level_pool_fwd: bad sizes");
     AIG_REQUIRE(out && argmax && lvl_ptr && ws, "aig_level_pool_fwd: null pointer");
     if (ws_bytes < aig_level_pool_fwd_ws_bytes(n, L))
@@ -355,7 +357,7 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const in
     hipStream_t s = static_cast<hipStream_t>(stream);
     Carver c(ws);
     unsigned long long* table = c.take<unsigned long long>((size_t)(L + 1) * H);
-    AIG_HIP_CHECK(fill_words(table, 0u, (size_t)(L + 1) * H * 8, s));
+    if (!table_cleared) AIG_HIP_CHECK(fill_words(table, 0u, (size_t)(L + 1) * H * 8, s));
     int blocks = 0;
     float* partial = nullptr;
     if (nvalid > 0) {
@@ -372,6 +374,21 @@ extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const in
                        argmax);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+}  // namespace
+
+extern "C" int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                                  const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level,
+                                  const float* w, float* out, int32_t* argmax, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    return pool_fwd(n, nvalid, L, lvl_meta, h, perm, lvl_ptr, node_level, w, out, argmax, ws, ws_bytes, false, stream);
+}
+
+extern "C" int aig_level_pool_fwd_cleared(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                                          const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level,
+                                          const float* w, float* out, int32_t* argmax, void* ws, size_t ws_bytes,
+                                          void* stream) {
+    return pool_fwd(n, nvalid, L, lvl_meta, h, perm, lvl_ptr, node_level, w, out, argmax, ws, ws_bytes, true, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

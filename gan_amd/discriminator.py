@@ -318,14 +318,16 @@ class _GATAggregatePool(torch.autograd.Function):
             _abi.check(_abi.timed("aig_gat_node_alpha", lib.aig_gat_node_alpha, n, _abi.ptr(xw), _abi.ptr(att_src),
                                   _abi.ptr(att_dst), _abi.ptr(lin_edge_w), _abi.ptr(att_edge), _abi.ptr(a_s), _abi.ptr(a_d),
                                   _abi.ptr(ce), st), "aig_gat_node_alpha")
-        _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
+        # (the aggregation's launch also clears the readout's table of maxima at the head of the readout's workspace)
+        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), dev)
+        _abi.check(_abi.timed("aig_gat_fwd", lib.aig_gat_fwd_clearing, n, _abi.ptr(xw), _abi.ptr(a_s), _abi.ptr(a_d),
                               _abi.ptr(ce), _abi.ptr(bias), _abi.ptr(csr.row_ptr), _abi.ptr(csr.csr_src),
                               _abi.ptr(csr.csr_ea), _abi.ptr(csr.loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
-                              _abi.ptr(alpha_loop), st, meta=(n, csr.E)), "aig_gat_fwd")
+                              _abi.ptr(alpha_loop), _abi.ptr(ws), lib.aig_level_pool_table_bytes(plan.L), st,
+                              meta=(n, csr.E)), "aig_gat_fwd_clearing")
         r = torch.empty((1, 2 * HIDDEN), **f32)
         argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
-        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L), dev)
-        _abi.check(_abi.timed("aig_level_pool_fwd", lib.aig_level_pool_fwd, plan.n, plan.nvalid, plan.L, _abi.ptr(plan.meta),
+        _abi.check(_abi.timed("aig_level_pool_fwd", lib.aig_level_pool_fwd_cleared, plan.n, plan.nvalid, plan.L, _abi.ptr(plan.meta),
                               _abi.ptr(out), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr), _abi.ptr(plan.node_level),
                               _abi.ptr(plan.w), _abi.ptr(r), _abi.ptr(argmax), _abi.ptr(ws), ws.numel(), st),
                    "aig_level_pool_fwd")
@@ -754,13 +756,15 @@ class AIGDiscriminator(nn.Module):
         h1, h2 = torch.empty((n, HIDDEN), **f32), torch.empty((n, HIDDEN), **f32)
         if w_fwd is None:
             w_fwd = w_bwd = plan.w
-        _abi.check(lib.aig_gp_forward(n, _abi.ptr(n_dev), _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(al), _abi.ptr(W1), _abi.ptr(b1),
-                                      _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(xhat), _abi.ptr(h1), _abi.ptr(h2), st),
-                   "aig_gp_forward")
+        # (the forward launch also clears the readout's table of maxima at the head of the readout's workspace)
+        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(n, plan.L), dev)
+        _abi.check(lib.aig_gp_forward_clearing(n, _abi.ptr(n_dev), _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(al), _abi.ptr(W1),
+                                               _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(xhat), _abi.ptr(h1),
+                                               _abi.ptr(h2), _abi.ptr(ws), lib.aig_level_pool_table_bytes(plan.L), st),
+                   "aig_gp_forward_clearing")
         r = torch.empty((1, 2 * HIDDEN), **f32)
         argmax = torch.empty((plan.L + 1, HIDDEN), dtype=torch.int32, device=dev)
-        ws = _abi.workspace(lib.aig_level_pool_fwd_ws_bytes(n, plan.L), dev)
-        _abi.check(lib.aig_level_pool_fwd(n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
+        _abi.check(lib.aig_level_pool_fwd_cleared(n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h2), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
                                           _abi.ptr(plan.node_level), _abi.ptr(w_fwd), _abi.ptr(r), _abi.ptr(argmax),
                                           _abi.ptr(ws), ws.numel(), st), "aig_level_pool_fwd")
         # head: s = out(mlp(r)), g_r = ds/dr (the backward kernel of the head with ds = 1)

@@ -184,6 +184,14 @@ int aig_gat_node_alpha(int64_t n, const float* xw, const float* att_src, const f
 int aig_gat_fwd(int64_t n, const float* xw, const float* a_s, const float* a_d, const float* ce,
                 const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
                 const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* stream);
+/* The same launch, which also zeroes `clear_bytes` bytes at `clear` (8-byte aligned, a multiple of 8; nothing when
+ * 0): what the next kernel on the stream wants cleared - the readout's table of maxima, see
+ * aig_level_pool_fwd_cleared - costs a few stores per block here instead of a launch of its own (a launch that does
+ * nothing takes ~4.6 us inside a replayed HIP graph).  Same reference lines as aig_gat_fwd (discriminator.py:56-61). */
+int aig_gat_fwd_clearing(int64_t n, const float* xw, const float* a_s, const float* a_d, const float* ce,
+                         const float* bias, const int32_t* row_ptr, const int32_t* csr_src, const float* csr_ea,
+                         const float* loop_ea, float* out, float* alpha_e, float* alpha_loop, void* clear,
+                         size_t clear_bytes, void* stream);
 
 /* Backward of the same layer: given g_out = dLoss/d out, returns d_xw [n,128], d_att_src [128],
  * d_att_dst [128], d_ce [4], d_bias [128] and, when asked for (both or neither; they need lin_edge_w and att_edge),
@@ -314,6 +322,13 @@ size_t aig_level_pool_fwd_ws_bytes(int64_t n, int64_t L);
 int aig_level_pool_fwd(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
                        const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
                        float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+/* The same readout (discriminator.py:63-91) when the first aig_level_pool_table_bytes(L) bytes of `ws` - its table
+ * of packed level maxima - are already zero when the call's first kernel runs, cleared by an earlier kernel on the
+ * same stream (aig_gat_fwd_clearing, aig_gp_forward_clearing): one launch less. */
+size_t aig_level_pool_table_bytes(int64_t L);
+int aig_level_pool_fwd_cleared(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, const float* h,
+                               const int32_t* perm, const int32_t* lvl_ptr, const int32_t* node_level, const float* w,
+                               float* out, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
 
 /* The same readout for callers that cannot allocate device memory or are not allowed to - code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (which allocates
@@ -418,6 +433,11 @@ int aig_gp_rows(int64_t n, int64_t nvalid, int64_t L, const int32_t* lvl_meta, c
                 void* ws, size_t ws_bytes, void* stream);
 int aig_gp_forward(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha, const float* W1,
                    const float* b1, const float* W2, const float* b2, float* xhat, float* h1, float* h2, void* stream);
+/* aig_gp_forward that also zeroes `clear_bytes` bytes at `clear` for the readout that follows it (as
+ * aig_gat_fwd_clearing does; the same lines of train.py:133-152) */
+int aig_gp_forward_clearing(int64_t n, const int32_t* n_rows_dev, const float* x_real, const float* x_fake, const float* alpha,
+                            const float* W1, const float* b1, const float* W2, const float* b2, float* xhat, float* h1,
+                            float* h2, void* clear, size_t clear_bytes, void* stream);
 int aig_gp_scalars(const float* norm_sq, float scale, float* out3, void* stream);
 size_t aig_gp_input_grad_ws_bytes(int64_t n);
 int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r, const int32_t* node_level,

@@ -744,3 +744,69 @@ def test_critic_with_and_without_fused_node_terms():
     close(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6, what="score")
     for k in g0:
         close(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=2e-5, what="grad " + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,levels,dyn", [(5000, 37, False), (70, 3, True), (20000, 150, True)])
+def test_readout_over_a_table_cleared_by_the_launch_before(n, levels, dyn):
+    """``aig_gat_fwd_clearing`` / ``aig_gp_forward_clearing`` zero the head of a workspace full of ones and
+    ``aig_level_pool_fwd_cleared`` pools over it: bit-equal with ``aig_level_pool_fwd``, which clears for itself."""
+    from gan_amd.discriminator import DynLevelPlan, LevelPlan
+    lib = _abi.lib()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(n)
+    depth = torch.randint(-1, levels, (n,), generator=g)
+    depth[:levels] = torch.arange(levels)
+    if dyn:
+        plan = DynLevelPlan(n, levels + 4, dev)
+        plan.rebuild(depth.to(dev))
+    else:
+        plan = LevelPlan(depth.to(dev), n, dev)
+    H = 128
+    # an attention layer over a graph without edges: every node aggregates itself
+    xw = torch.randn((n, H), generator=g).to(dev)
+    z4, zn4 = torch.zeros(4, device=dev), torch.zeros((n, 4), device=dev)
+    row_ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    loop_ea, bias = torch.zeros(n, device=dev), torch.zeros(H, device=dev)
+    st = _abi.stream()
+
+    def pool(fn, ws, h):
+        out = torch.full((1, 2 * H), float("nan"), device=dev)
+        argmax = torch.full((plan.L + 1, H), -7, dtype=torch.int32, device=dev)
+        _abi.check(fn(plan.n, plan.nvalid, plan.L, _abi.ptr(plan.meta), _abi.ptr(h), _abi.ptr(plan.perm), _abi.ptr(plan.lvl_ptr),
+                      _abi.ptr(plan.node_level), _abi.ptr(plan.w), _abi.ptr(out), _abi.ptr(argmax), _abi.ptr(ws), ws.numel(), st))
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), argmax.cpu().numpy()
+
+    nbytes = lib.aig_level_pool_fwd_ws_bytes(plan.n, plan.L)
+    table = lib.aig_level_pool_table_bytes(plan.L)
+    assert 0 < table <= nbytes and table % 8 == 0
+    # through the aggregation's launch
+    ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev)
+    out = torch.empty((n, H), device=dev)
+    alpha_e, alpha_loop = torch.empty((1, 4), device=dev), torch.empty((n, 4), device=dev)
+    _abi.check(lib.aig_gat_fwd_clearing(n, _abi.ptr(xw), _abi.ptr(zn4), _abi.ptr(zn4), _abi.ptr(z4), _abi.ptr(bias),
+                                        _abi.ptr(row_ptr), None, None, _abi.ptr(loop_ea), _abi.ptr(out), _abi.ptr(alpha_e),
+                                        _abi.ptr(alpha_loop), _abi.ptr(ws), table, st), "aig_gat_fwd_clearing")
+    torch.cuda.synchronize()
+    assert int(ws[:table].max()) == 0 and int(ws[table:].min()) == 0xFF      # cleared exactly what was asked
+    got = pool(lib.aig_level_pool_fwd_cleared, ws, out)
+    want = pool(lib.aig_level_pool_fwd, torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev), out)
+    assert np.isfinite(want[0]).all()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1][:levels], want[1][:levels])
+    # through the penalty's forward launch (rows limited on the device to fewer than the grid covers)
+    ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev)
+    xr, xf = torch.rand((n, 2), generator=g).to(dev), torch.rand((n, 2), generator=g).to(dev)
+    W1, b1 = torch.randn((H, 2), generator=g).to(dev), torch.randn(H, generator=g).to(dev)
+    W2, b2 = (torch.randn((H, H), generator=g) / 11).to(dev), torch.randn(H, generator=g).to(dev)
+    alpha = torch.full((1,), 0.3, device=dev)
+    n_rows = torch.tensor([max(1, n // 3)], dtype=torch.int32, device=dev)
+    xhat, h1, h2 = torch.empty((n, 2), device=dev), torch.empty((n, H), device=dev), torch.zeros((n, H), device=dev)
+    _abi.check(lib.aig_gp_forward_clearing(n, _abi.ptr(n_rows), _abi.ptr(xr), _abi.ptr(xf), _abi.ptr(alpha), _abi.ptr(W1),
+                                           _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(xhat), _abi.ptr(h1), _abi.ptr(h2),
+                                           _abi.ptr(ws), table, st), "aig_gp_forward_clearing")
+    torch.cuda.synchronize()
+    assert int(ws[:table].max()) == 0 and int(ws[table:].min()) == 0xFF
+    got = pool(lib.aig_level_pool_fwd_cleared, ws, h2)
+    want = pool(lib.aig_level_pool_fwd, torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev), h2)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1][:levels], want[1][:levels])
