@@ -24,7 +24,7 @@ class GenWeights(C.Structure):
     """Mirror of ``aig_gen_weights``."""
     _fields_ = [(n, P) for n in (
         "enc0_w", "enc0_b", "enc2_w", "enc2_b", "proj0_w", "proj0_b", "proj2_w", "proj2_b",
-        "sc0_w", "sc0_b", "sc2_w", "sc2_b", "at0_w", "at0_b", "at2_w", "at2_b")]
+        "sc0_w", "sc0_b", "sc2_w", "sc2_b", "at0_w", "at0_b", "at2_w", "at2_b")] + [("z_dim", C.c_int32)]
 
 
 class GenWireSet(C.Structure):

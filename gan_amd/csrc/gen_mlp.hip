@@ -25,13 +25,13 @@ struct Chunk {          // one 128-column slice of the output
     int wt;             // 1: w is stored [in][out] (ldw = row length of that layout)
 };
 
-// z-dependent bias vectors: out[v*128 + j] = b_v[j] + sum_k W_v[j][off_v + k] * z[k]
+// z-dependent bias vectors: out[v*128 + j] = b_v[j] + sum_k W_v[j][off_v + k] * z[k], k < zdim ascending
 __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w0, const float* __restrict__ b0,
                         int ld0, int off0, const float* __restrict__ w1, const float* __restrict__ b1, int ld1,
                         int off1, const float* __restrict__ w2, const float* __restrict__ b2, int ld2, int off2,
-                        float* __restrict__ out) {
+                        int zdim, float* __restrict__ out) {
     int v = blockIdx.x, j = threadIdx.x;
-    z += static_cast<size_t>(blockIdx.y) * H;           // blockIdx.y: the sample (one z and four vectors each)
+    z += static_cast<size_t>(blockIdx.y) * zdim;        // blockIdx.y: the sample (one z and four vectors each)
     out += static_cast<size_t>(blockIdx.y) * 4 * H;
     if (v == 3) {  // a zero vector for layers without bias
         out[v * H + j] = 0.f;
@@ -42,7 +42,7 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
     int ld = v == 0 ? ld0 : (v == 1 ? ld1 : ld2), off = v == 0 ? off0 : (v == 1 ? off1 : off2);
     float acc = 0.f;
     const float* row = w + static_cast<size_t>(j) * ld + off;
-    for (int k = 0; k < H; ++k) acc = fmaf(row[k], z[k], acc);
+    for (int k = 0; k < zdim; ++k) acc = fmaf(row[k], z[k], acc);
     out[v * H + j] = acc + b[j];
 }
 
@@ -800,13 +800,20 @@ int check_gen_weights(const char* who, const float* x, const float* z, const aig
                     aligned(w->enc2_b, 16) && aligned(w->proj0_w, 16) && aligned(w->proj2_w, 16) &&
                     aligned(w->proj2_b, 16) && aligned(w->sc0_w, 16) && aligned(w->at0_w, 16),
                 "%s: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned", who);
+    AIG_REQUIRE(w->z_dim == 0 || (w->z_dim >= 4 && w->z_dim <= 1024 && w->z_dim % 4 == 0),
+                "%s: z_dim=%d (a multiple of 4 in 4..1024; 0 = 128)", who, (int)w->z_dim);
     return AIG_OK;
 }
 
+// width of z, and the row lengths of the layers that take it: node_proj.0 reads [h, z], the edge MLPs [h_u, h_v, z]
+int z_dim_of(const aig_gen_weights* w) { return w->z_dim > 0 ? w->z_dim : H; }
+int ld_proj0(const aig_gen_weights* w) { return H + z_dim_of(w); }
+int ld_edge0(const aig_gen_weights* w) { return 2 * H + z_dim_of(w); }
+
 void launch_zbias(hipStream_t s, int samples, const float* z, const aig_gen_weights* w, float* zb) {
     // per sample: [0] node_proj.0, [1] edge_scorer.0, [2] edge_attr_pred.0, [3] zeros
-    hipLaunchKernelGGL(k_zbias, dim3(4, (unsigned)samples), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, 2 * H, H, w->sc0_w,
-                       w->sc0_b, 3 * H, 2 * H, w->at0_w, w->at0_b, 3 * H, 2 * H, zb);
+    hipLaunchKernelGGL(k_zbias, dim3(4, (unsigned)samples), dim3(H), 0, s, z, w->proj0_w, w->proj0_b, ld_proj0(w), H, w->sc0_w,
+                       w->sc0_b, ld_edge0(w), 2 * H, w->at0_w, w->at0_b, ld_edge0(w), 2 * H, z_dim_of(w), zb);
 }
 
 size_t proj_f32_ws(int64_t B, int64_t n) {
@@ -837,7 +844,7 @@ int node_proj_f32(hipStream_t s, int B, int n, const float* x, long long x_strid
         p.enc0_w = w->enc0_w;
         p.enc0_b = w->enc0_b;
         p.w[0] = w->enc2_w;  p.b[0] = w->enc2_b;  p.ldw[0] = H;
-        p.w[1] = w->proj0_w; p.b[1] = zb;         p.ldw[1] = 2 * H;
+        p.w[1] = w->proj0_w; p.b[1] = zb;         p.ldw[1] = ld_proj0(w);
         p.w[2] = w->proj2_w; p.b[2] = w->proj2_b; p.ldw[2] = H;
         p.out = hc;
         p.gx = x_stride; p.gout = static_cast<long long>(n) * H; p.gzb = 4 * H;
@@ -857,7 +864,7 @@ int node_proj_f32(hipStream_t s, int B, int n, const float* x, long long x_strid
         q.w[1] = w->sc0_w + H; q.b[1] = zb + H;     q.out[1] = proj + plane;
         q.w[2] = w->at0_w;     q.b[2] = zb + 3 * H; q.out[2] = proj + 2 * plane;
         q.w[3] = w->at0_w + H; q.b[3] = zb + 2 * H; q.out[3] = proj + 3 * plane;
-        for (int i = 0; i < 4; ++i) q.ldw[i] = 3 * H;
+        for (int i = 0; i < 4; ++i) q.ldw[i] = ld_edge0(w);
         q.gx = static_cast<long long>(n) * H; q.gout = rows * H; q.gzb = 4 * H;
         hipLaunchKernelGGL(k_node_proj4, grid, dim3(THREADS), PROJ4_LDS, s, M, rpb, q);
         AIG_LAUNCH_CHECK();
@@ -886,12 +893,12 @@ int node_proj_bf16(hipStream_t s, int n, int samples, const float* x, int x_samp
     AIG_LAUNCH_CHECK();
     PackSrc src{};
     src.w[0] = w->enc2_w;      src.ldw[0] = H;
-    src.w[1] = w->proj0_w;     src.ldw[1] = 2 * H;
+    src.w[1] = w->proj0_w;     src.ldw[1] = ld_proj0(w);
     src.w[2] = w->proj2_w;     src.ldw[2] = H;
-    src.w[3] = w->sc0_w;       src.ldw[3] = 3 * H;
-    src.w[4] = w->sc0_w + H;   src.ldw[4] = 3 * H;
-    src.w[5] = w->at0_w;       src.ldw[5] = 3 * H;
-    src.w[6] = w->at0_w + H;   src.ldw[6] = 3 * H;
+    src.w[3] = w->sc0_w;       src.ldw[3] = ld_edge0(w);
+    src.w[4] = w->sc0_w + H;   src.ldw[4] = ld_edge0(w);
+    src.w[5] = w->at0_w;       src.ldw[5] = ld_edge0(w);
+    src.w[6] = w->at0_w + H;   src.ldw[6] = ld_edge0(w);
     hipLaunchKernelGGL(k_pack_bf16, dim3(PIPE_LAYERS * 8), dim3(256), 0, s, src, wpack);
     AIG_LAUNCH_CHECK();
     AIG_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_node_pipe_bf16), PIPE_LDS));

@@ -119,9 +119,11 @@ class AIGGenerator(nn.Module):
                                          nn.Linear(hidden_dim, 1))
         self.edge_attr_pred = nn.Sequential(nn.Linear(hidden_dim * 2 + z_dim, hidden_dim), nn.ReLU(),
                                             nn.Linear(hidden_dim, 1))
-        if (node_in_dim, hidden_dim, z_dim) != (2, 128, 128):
+        if (node_in_dim, hidden_dim) != (2, 128):
             raise NotImplementedError(
-                "the MI355X kernels are built for node_in_dim=2, hidden_dim=128, z_dim=128 (the reference defaults)")
+                "the MI355X kernels are built for node_in_dim=2, hidden_dim=128 (the reference defaults)")
+        if not (4 <= z_dim <= 1024 and z_dim % 4 == 0):
+            raise NotImplementedError("the MI355X kernels take z_dim as a multiple of 4 in 4..1024 (default 128)")
 
     # ------------------------------------------------------------------ plumbing
     def _weights(self) -> _abi.GenWeights:
@@ -158,6 +160,7 @@ class AIGGenerator(nn.Module):
         w.sc2_w, w.sc2_b = p(self.edge_scorer[2].weight), p(self.edge_scorer[2].bias)
         w.at0_w, w.at0_b = p(self.edge_attr_pred[0].weight), p(self.edge_attr_pred[0].bias)
         w.at2_w, w.at2_b = p(self.edge_attr_pred[2].weight), p(self.edge_attr_pred[2].bias)
+        w.z_dim = int(self.z_dim)
         return w
 
     def plan_for(self, template: Data, x: torch.Tensor, nd: Optional[torch.Tensor]) -> GeneratorPlan:
@@ -182,6 +185,8 @@ class AIGGenerator(nn.Module):
         if dev.type != "cuda":
             raise _abi.AigAbiError("AIGGenerator.forward_many needs the template on a HIP device (no CPU path exists)")
         zs = zs.to(dev).float().contiguous()
+        if zs.dim() != 2 or int(zs.size(1)) != self.z_dim:
+            raise _abi.AigAbiError(f"zs must be [samples, z_dim={self.z_dim}], got {tuple(zs.shape)}")
         S = int(zs.size(0))
         if self.score_dtype != "bf16" or S == 1:
             return [self(template, zs[i]) for i in range(S)]
@@ -262,6 +267,8 @@ class AIGGenerator(nn.Module):
         if dev.type != "cuda":
             raise _abi.AigAbiError("AIGGenerator.forward_set needs the templates on a HIP device (no CPU path exists)")
         zs = zs.to(dev).float().contiguous()
+        if zs.dim() != 2 or int(zs.size(1)) != self.z_dim:
+            raise _abi.AigAbiError(f"zs must be [samples, z_dim={self.z_dim}], got {tuple(zs.shape)}")
         B = int(zs.size(0))
         K = int(self.candidate_k)
         if shared:
@@ -401,6 +408,8 @@ class AIGGenerator(nn.Module):
         if z.dim() == 2 and z.size(0) == 1:
             z = z.squeeze(0)
         z = z.to(dev).float().contiguous()
+        if z.numel() != self.z_dim:
+            raise _abi.AigAbiError(f"z must hold z_dim={self.z_dim} values, got {tuple(z.shape)}")
         x_src = template.x
         x_in = x_src if (x_src.dtype == torch.float32 and x_src.is_contiguous()) else x_src.float().contiguous()
         n = int(x_in.size(0))

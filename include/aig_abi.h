@@ -73,12 +73,15 @@ int aig_gen_candidates(int64_t n, int64_t K, const int32_t* types, const int32_t
 typedef struct aig_gen_weights {
     const float *enc0_w, *enc0_b;   /* node_enc.0        [128,2],   [128] */
     const float *enc2_w, *enc2_b;   /* node_enc.2        [128,128], [128] */
-    const float *proj0_w, *proj0_b; /* node_proj.0       [128,256], [128] */
+    const float *proj0_w, *proj0_b; /* node_proj.0       [128,256], [128] (z_dim = 128) */
     const float *proj2_w, *proj2_b; /* node_proj.2       [128,128], [128] */
-    const float *sc0_w, *sc0_b;     /* edge_scorer.0     [128,384], [128] */
+    const float *sc0_w, *sc0_b;     /* edge_scorer.0     [128,384], [128] (z_dim = 128) */
     const float *sc2_w, *sc2_b;     /* edge_scorer.2     [1,128],   [1]   */
-    const float *at0_w, *at0_b;     /* edge_attr_pred.0  [128,384], [128] */
+    const float *at0_w, *at0_b;     /* edge_attr_pred.0  [128,384], [128] (z_dim = 128) */
     const float *at2_w, *at2_b;     /* edge_attr_pred.2  [1,128],   [1]   */
+    int32_t z_dim;                  /* width of z (--z-dim of train.py:374 / AIGgan.py:78); 0 means 128.  With z_dim = Z
+                                     * node_proj.0 is [128,128+Z] and the two edge MLPs' first layers [128,256+Z]; Z must
+                                     * be a multiple of 4 in 4..1024 (weight rows are read as 16-byte vectors) */
 } aig_gen_weights;
 
 /* Node encoder + conditioning + the node-wise halves of both edge MLPs -

@@ -467,11 +467,11 @@ static float chain128(const float *a, const float *w) {
     return acc;
 }
 
-/* out[j] = b[j] + sum_k w[j*ld + off + k] * z[k], k ascending */
-static void zbias128(const float *w, int ld, int off, const float *b, const float *z, float *out) {
+/* out[j] = b[j] + sum_k w[j*ld + off + k] * z[k], k < zd ascending */
+static void zbias128(const float *w, int ld, int off, const float *b, const float *z, int zd, float *out) {
     for (int j = 0; j < 128; ++j) {
         float acc = 0.0f;
-        for (int k = 0; k < 128; ++k) acc = fmaf(w[(size_t)j * ld + off + k], z[k], acc);
+        for (int k = 0; k < zd; ++k) acc = fmaf(w[(size_t)j * ld + off + k], z[k], acc);
         out[j] = acc + b[j];
     }
 }
@@ -487,15 +487,33 @@ static void layer128(int64_t n, const float *x, const float *w, int ldw, const f
 /* weights: the 16 tensors of AIGGenerator in state_dict order, PyTorch [out,in] layout.
  * h_cond [n,128]; proj = 4 planes [n,128]: source half / target half(+z,+bias) of edge_scorer.0,
  * then the same two for edge_attr_pred.0. */
+int orc_node_proj_z(int64_t n, const float *x, const float *z, int zd,
+                    const float *enc0_w, const float *enc0_b, const float *enc2_w, const float *enc2_b,
+                    const float *proj0_w, const float *proj0_b, const float *proj2_w, const float *proj2_b,
+                    const float *sc0_w, const float *sc0_b, const float *at0_w, const float *at0_b,
+                    float *h_cond, float *proj);
+
 int orc_node_proj(int64_t n, const float *x, const float *z,
                   const float *enc0_w, const float *enc0_b, const float *enc2_w, const float *enc2_b,
                   const float *proj0_w, const float *proj0_b, const float *proj2_w, const float *proj2_b,
                   const float *sc0_w, const float *sc0_b, const float *at0_w, const float *at0_b,
                   float *h_cond, float *proj) {
+    return orc_node_proj_z(n, x, z, 128, enc0_w, enc0_b, enc2_w, enc2_b, proj0_w, proj0_b, proj2_w, proj2_b, sc0_w, sc0_b,
+                           at0_w, at0_b, h_cond, proj);
+}
+
+/* the same for a z of zd values (--z-dim of train.py:374 / AIGgan.py:78; models/generator.py:24-41: node_proj.0 is
+ * Linear(128 + zd, 128), the edge MLPs' first layers Linear(256 + zd, 128)) */
+int orc_node_proj_z(int64_t n, const float *x, const float *z, int zd,
+                    const float *enc0_w, const float *enc0_b, const float *enc2_w, const float *enc2_b,
+                    const float *proj0_w, const float *proj0_b, const float *proj2_w, const float *proj2_b,
+                    const float *sc0_w, const float *sc0_b, const float *at0_w, const float *at0_b,
+                    float *h_cond, float *proj) {
+    const int ldp = 128 + zd, lde = 256 + zd;
     float zb[3][128];
-    zbias128(proj0_w, 256, 128, proj0_b, z, zb[0]);
-    zbias128(sc0_w, 384, 256, sc0_b, z, zb[1]);
-    zbias128(at0_w, 384, 256, at0_b, z, zb[2]);
+    zbias128(proj0_w, ldp, 128, proj0_b, z, zd, zb[0]);
+    zbias128(sc0_w, lde, 256, sc0_b, z, zd, zb[1]);
+    zbias128(at0_w, lde, 256, at0_b, z, zd, zb[2]);
     float *t0 = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * 128 * 2), *t1 = t0 + n * 128;
     if (!t0) return -1;
     for (int64_t i = 0; i < n; ++i)
@@ -504,12 +522,12 @@ int orc_node_proj(int64_t n, const float *x, const float *z,
             t0[i * 128 + j] = s > 0.0f ? s : 0.0f;
         }
     layer128(n, t0, enc2_w, 128, enc2_b, 1, t1);
-    layer128(n, t1, proj0_w, 256, zb[0], 1, t0);
+    layer128(n, t1, proj0_w, ldp, zb[0], 1, t0);
     layer128(n, t0, proj2_w, 128, proj2_b, 1, h_cond);
-    layer128(n, h_cond, sc0_w, 384, NULL, 0, proj);
-    layer128(n, h_cond, sc0_w + 128, 384, zb[1], 0, proj + n * 128);
-    layer128(n, h_cond, at0_w, 384, NULL, 0, proj + 2 * n * 128);
-    layer128(n, h_cond, at0_w + 128, 384, zb[2], 0, proj + 3 * n * 128);
+    layer128(n, h_cond, sc0_w, lde, NULL, 0, proj);
+    layer128(n, h_cond, sc0_w + 128, lde, zb[1], 0, proj + n * 128);
+    layer128(n, h_cond, at0_w, lde, NULL, 0, proj + 2 * n * 128);
+    layer128(n, h_cond, at0_w + 128, lde, zb[2], 0, proj + 3 * n * 128);
     free(t0);
     return 0;
 }

@@ -38,7 +38,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         for fn in ("orc_build_order", "orc_enforce", "orc_penalties", "orc_validate", "orc_resync",
-                   "orc_topk", "orc_topk_rows", "orc_node_proj", "orc_score_rows", "orc_inv_bits"):
+                   "orc_topk", "orc_topk_rows", "orc_node_proj", "orc_node_proj_z", "orc_score_rows", "orc_inv_bits"):
             getattr(_lib, fn).restype = C.c_int
         _lib.orc_candidates.restype = C.c_int64
     return _lib
@@ -140,8 +140,10 @@ def node_proj(state, x: np.ndarray, z: np.ndarray, dedup_rows: Optional[bool] = 
         ws += [_f32(state[k + ".weight"]), _f32(state[k + ".bias"])]
     h_cond = np.empty((n, 128), np.float32)
     proj = np.empty((4, max(n, 1), 128), np.float32)
-    rc = lib().orc_node_proj(C.c_int64(n), _p(x, f32p), _p(z, f32p), *[_p(w, f32p) for w in ws],
-                             _p(h_cond, f32p), _p(proj, f32p))
+    zd = int(z.size)        # (the weights' row lengths must agree with it: node_proj.0 [128,128+zd], edge MLPs [128,256+zd])
+    assert ws[4].shape == (128, 128 + zd) and ws[8].shape == (128, 256 + zd) and ws[10].shape == (128, 256 + zd)
+    rc = lib().orc_node_proj_z(C.c_int64(n), _p(x, f32p), _p(z, f32p), C.c_int(zd), *[_p(w, f32p) for w in ws],
+                               _p(h_cond, f32p), _p(proj, f32p))
     assert rc == 0
     return h_cond, proj[:, :n]
 

@@ -568,3 +568,62 @@ def test_scoring_by_class_equals_scoring_by_node(dtype):
     c = Gl(tpls[2], zs[2])
     d = Gn(tpls[2], zs[2])
     assert torch.equal(c.edge_index, d.edge_index) and torch.equal(c.edge_attr, d.edge_attr)
+
+
+# ------------------------------------------------------------------------------------------------------
+# --z-dim other than 128 (train.py:374, AIGgan.py:78): z only enters through three bias vectors, one per layer
+# that reads it, so the width of z is a row length of three weight matrices and a loop bound.
+@pytest.mark.parametrize("zd,K", [(32, 64), (64, 16), (200, 64), (4, 8)])
+def test_other_z_widths_against_the_checker_and_the_reference_formula(zd, K):
+    g = torch.Generator().manual_seed(zd)
+    torch.manual_seed(zd)
+    G = AIGGenerator(z_dim=zd, candidate_k=K).to(DEV).eval()
+    state = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    assert tuple(state["node_proj.0.weight"].shape) == (128, 128 + zd)
+    assert tuple(state["edge_scorer.0.weight"].shape) == (128, 256 + zd)
+    t = synth_aig(40, 900, 25, seed=zd, window=200, orientation="dataset")
+    z = torch.randn(zd, generator=g)
+    tpl = Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV))
+    out = G(tpl, z.to(DEV), return_debug=True)
+    n = t.x.size(0)
+    # the checker's fixed-order form: bit for bit
+    ref = omodel.generator_forward_canonical(state, t.x, t.node_depth, z, K)
+    assert np.array_equal(out._debug["h_cond"].cpu().numpy()[:n].view(np.int32), ref["h_cond"].view(np.int32))
+    assert np.array_equal(out._debug["proj"].cpu().numpy()[:, :n].view(np.int32), ref["proj"].view(np.int32))
+    assert np.array_equal(out.edge_index.cpu().numpy(), ref["edge_index"].numpy())
+    assert np.array_equal(out.edge_attr.cpu().numpy(), ref["edge_attr"].numpy())
+    assert np.array_equal(out.x.cpu().numpy(), ref["x"].numpy())
+    # the reference's formulation (cat[h, z] through nn.Linear, models/generator.py:115-117): 1e-4
+    plain = omodel.generator_forward(state, t.x, t.node_depth, z, K)
+    np.testing.assert_allclose(out._debug["h_cond"].cpu().numpy()[:n], plain["h_cond"].numpy(), rtol=1e-4, atol=1e-5)
+    assert np.array_equal(out.edge_index[1].cpu().numpy(), plain["edge_index"][1].numpy())
+    # the set path and the bulk path give the one-at-a-time graphs
+    zs = torch.randn((3, zd), generator=g).to(DEV)
+    singles = [G(Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV)), zs[i]) for i in range(3)]
+    many = G.forward_many(tpl, zs)
+    graphs = G.forward_set([tpl] * 3, zs).graphs()
+    for a, b, c in zip(singles, many, graphs):
+        for k in ("x", "edge_index", "edge_attr"):
+            assert torch.equal(getattr(a, k), getattr(b, k)) and torch.equal(getattr(a, k), getattr(c, k)), k
+    # a z of another width is refused before any kernel reads past it
+    with pytest.raises(_abi.AigAbiError):
+        G(tpl, torch.randn(zd + 4).to(DEV))
+
+
+def test_other_z_widths_bf16_projection_and_refusals():
+    zd = 96
+    torch.manual_seed(3)
+    G32 = AIGGenerator(z_dim=zd, candidate_k=32).to(DEV).eval()
+    G16 = AIGGenerator(z_dim=zd, candidate_k=32, score_dtype="bf16").to(DEV).eval()
+    G16.load_state_dict(G32.state_dict())
+    t = synth_aig(30, 600, 20, seed=9, window=150, orientation="dataset")
+    tpl = Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV))
+    z = torch.randn(zd, generator=torch.Generator().manual_seed(4)).to(DEV)
+    a, b = G32(tpl, z, return_debug=True), G16(tpl, z, return_debug=True)
+    n = t.x.size(0)
+    ha, hb = a._debug["h_cond"][:n].float().cpu().numpy(), b._debug["h_cond"][:n].float().cpu().numpy()
+    assert np.abs(ha - hb).max() <= BF16_TOL * max(1.0, np.abs(ha).max())
+    assert torch.equal(a.edge_index[1], b.edge_index[1])
+    for bad in (0, 2, 130, 1028):
+        with pytest.raises(NotImplementedError):
+            AIGGenerator(z_dim=bad)

@@ -82,6 +82,41 @@ def test_training_step_matches_cpu_checker(batch, capture, gp):
     assert all(p.grad is None for p in tr.G.parameters())
 
 
+def test_training_step_with_another_z_width_matches_cpu_checker():
+    """``--z-dim 48`` (train.py:374): the step of the default recording path against the CPU checker."""
+    batch, zd = 2, 48
+    graphs = [synth_aig(6 + 2 * i, 60 + 25 * i, 4 + i, seed=90 + i, window=24, orientation="dataset") for i in range(batch)]
+    max_nodes = max(g.x.size(0) for g in graphs)
+    max_edges = max(g.edge_index.size(1) for g in graphs)
+    padded = [pad_data(g, max_nodes, max_edges) for g in graphs]
+    args = build_parser().parse_args(["--dataset-dir", "unused", "--candidate-k", "16", "--save-every", "1", "--z-dim", str(zd)])
+    tr = Trainer(args, max_nodes, max_edges, DEV)
+    torch.manual_seed(17)
+    from gan_amd.generator import AIGGenerator
+    gs = {k: v.detach().clone() for k, v in AIGGenerator(z_dim=zd, candidate_k=16).state_dict().items()}
+    assert tuple(gs["node_proj.0.weight"].shape) == (128, 128 + zd)
+    dparams = omodel.init_discriminator_params(13)
+    tr.G.load_state_dict(gs)
+    tr.D.load_state_dict(dparams)
+    g = torch.Generator().manual_seed(6)
+    zs = [torch.randn(zd, generator=g) for _ in range(2 * batch)]
+    alphas = [torch.rand(1, 1, generator=g) for _ in range(args.n_critic)]
+    zi, ai = iter(zs), iter(alphas)
+    tr.draw_z = lambda: next(zi).to(DEV)
+    tr.draw_alpha = lambda: next(ai).to(DEV)
+    real = Batch.from_data_list(padded)
+    real.sample_ids = list(range(batch))
+    step_batch = Batch.from_data_list(padded).to(DEV)
+    step_batch.sample_ids = list(range(batch))
+    got = {k: float(v) for k, v in tr.step(step_batch).items()}
+    cpu_tr = CpuTrainer(gs, dparams, 16, max_nodes, max_edges)
+    templates = [unpad_data(d) for d in real.to_data_list()]
+    ref = cpu_tr.step(real, templates, zs[:batch], zs[batch:], alphas, validate=True)
+    for k in ("D_real", "D_fake", "gap", "gp", "grad_norm", "loss_D", "loss_G", "pen"):
+        assert rel(got[k], ref[k]) <= 1e-4, (k, got[k], ref[k])
+    assert tr.edges_last_step == ref["edges"]
+
+
 @pytest.mark.parametrize("gp", ["closed_form", "autograd"])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_rotating_minibatches_share_one_recording(batch, gp):
