@@ -283,6 +283,14 @@ __global__ __launch_bounds__(THREADS) void k_gp_back3(int n, const int* __restri
     block_colsum<H>(red, partial);
 }
 
+// The tile kernels (gp_tile.hip) win where the chain is bound by its launches: over the distinct rows of a penalty
+// (a device-side row count, a few hundred rows as a rule) and over small inputs.  Over every node of a large graph the
+// chain's six-product kernels are faster (4.47 against 4.91 ms per step at 100k nodes): it keeps those calls.
+constexpr int64_t GP_TILES_MAX_PLAIN_ROWS = 16384;
+bool use_tiles(int64_t n, const int32_t* n_rows_dev) {
+    return gp_tiles_enabled() && (n_rows_dev != nullptr || n <= GP_TILES_MAX_PLAIN_ROWS);
+}
+
 int gp_blocks(int64_t n) {
     int64_t g = (n + 63) / 64;
     if (g > GP_BLOCKS_MAX) g = GP_BLOCKS_MAX;
@@ -343,7 +351,7 @@ extern "C" int aig_gp_forward_clearing(int64_t n, const int32_t* n_rows_dev, con
                                      clear_bytes / 8 < (size_t)INT_MAX),
                 "aig_gp_forward_clearing: the buffer to clear must be 8-byte aligned and a multiple of 8 bytes long");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (gp_tiles_enabled())
+    if (use_tiles(n, n_rows_dev))
         return launch_gp_tiles_fwd(s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, W2, b2, xhat, h1, h2, clear, clear_bytes);
     if (clear_bytes) AIG_HIP_CHECK(fill_words(clear, 0u, clear_bytes, s));
     hipLaunchKernelGGL(k_gp_enc, dim3(gp_blocks(n)), dim3(THREADS), 0, s, (int)n, n_rows_dev, x_real, x_fake, alpha, W1, b1, xhat, h1);
@@ -388,7 +396,7 @@ extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
     if (ws_bytes < aig_gp_input_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_input_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* partial = static_cast<float*>(ws);
-    if (gp_tiles_enabled()) {
+    if (use_tiles(n, n_rows_dev)) {
         int blocks = 0;
         int rc = launch_gp_tiles_input_grad(s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w, argmax, W1, W2, h1, h2,
                                             g_z2, g_h1, g_z1, g_x, partial, &blocks);
@@ -416,7 +424,8 @@ extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
     const size_t chain = 5 * align_up(N * H * 4) + align_up(N * 2 * 4) + align_up((size_t)GP_BLOCKS_MAX * 3 * H * 4) +
                          align_up(wg > wg2 ? wg : wg2) + 1024;
     const size_t tiles = gp_tiles_partial_bytes() + 256;
-    return gp_tiles_enabled() ? tiles : chain;
+    if (!gp_tiles_enabled()) return chain;
+    return n <= GP_TILES_MAX_PLAIN_ROWS ? tiles : (chain > tiles ? chain : tiles);      // (large n: either may run)
 }
 
 extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
@@ -431,7 +440,7 @@ extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
                 "aig_gp_param_grad: null pointer");
     if (ws_bytes < aig_gp_param_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_param_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (gp_tiles_enabled())
+    if (use_tiles(n, n_rows_dev))
         return launch_gp_tiles_param_grad(s, (int)n, n_rows_dev, (int)L, lvl_meta, coef, g_r, node_level, w, argmax, W1, W2, xhat,
                                           h1, h2, g_z2, g_h1, g_z1, g_x, dW1, db1, dW2, db2, ubar_gr, static_cast<float*>(ws));
     const size_t NH = (size_t)n * H;
