@@ -84,12 +84,15 @@ SIGNATURES = {
     "aig_gp_input_grad": (INT, [I64, P, I64] + [P] * 14 + [P, SZ, P]),
     "aig_gp_param_grad_ws_bytes": (SZ, [I64]),
     "aig_gp_param_grad": (INT, [I64, P, I64] + [P] * 20 + [P, SZ, P]),
+    "aig_gp_param_grad_scaled": (INT, [I64, P, I64] + [P] * 20 + [C.c_float, P, SZ, P]),
+    "aig_gp_input_grad_scalars": (INT, [I64, P, I64] + [P] * 14 + [C.c_float, P, P, SZ, P]),
     "aig_linear128": (INT, [I64, P, P, INT, P, INT, P, P]),
     "aig_linear128_node_terms": (INT, [I64, P, P, INT, P, P, P, P, P, P, P, P, P]),
     "aig_linear_in2": (INT, [I64, P, P, P, P]),
     "aig_head_fwd": (INT, [P] * 9 + [P]),
     "aig_head_bwd": (INT, [P] * 13 + [P]),
     "aig_head_input_grad_wgrad": (INT, [P] * 8 + [P]),
+    "aig_head_input_grad_wgrad_scaled": (INT, [P] * 8 + [C.c_float, P]),
     "aig_wgrad_ws_bytes": (SZ, [I64, I64]),
     "aig_wgrad": (INT, [I64, I64, P, P, P, P, SZ, P]),
     "aig_level_plan_ws_bytes": (SZ, [I64, I64]),

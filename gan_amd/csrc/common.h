@@ -142,7 +142,7 @@ int launch_gp_tiles_param_grad(hipStream_t s, int n, const int* row_limit, int L
                                const float* g_r, const int* node_level, const float* w, const int* argmax, const float* W1,
                                const float* W2, const float* xhat, const float* h1, const float* h2, const float* g_z2,
                                const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1, float* dW2,
-                               float* db2, float* ubar_gr, float* partial);
+                               float* db2, float* ubar_gr, float* partial, float out_scale);
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -374,6 +374,41 @@ __global__ void k_gp_scalars(const float* __restrict__ norm_sq, float scale, flo
     out3[2] = norm > 0.f ? scale * (2.0f * d / norm) : 0.f;
 }
 
+// norm_sq = sum_b partial[b] (k_sum_cols' order: strided partial sums, then a fixed-shape tree) and the three scalars
+// of k_gp_scalars behind it, in one launch
+__global__ __launch_bounds__(256) void k_gp_norm_scalars(int nb, const float* __restrict__ partial, float scale,
+                                                         float* __restrict__ norm_sq, float* __restrict__ out3) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    float s = 0.f;
+    for (int b = t; b < nb; b += 256) s += partial[b];
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float nsq = red[0];
+        norm_sq[0] = nsq;
+        const float norm = sqrtf(nsq);
+        const float d = norm - 1.0f;
+        out3[0] = norm;
+        out3[1] = d * d;
+        out3[2] = norm > 0.f ? scale * (2.0f * d / norm) : 0.f;
+    }
+}
+
+// out[i] *= scale over four arrays (the chain's parameter gradients, scaled after the fact)
+__global__ void k_gp_scale4(float* __restrict__ a, int na, float* __restrict__ b, int nb, float* __restrict__ c, int nc,
+                            float* __restrict__ d, int nd, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] *= scale;
+    else if (i < na + nb) b[i - na] *= scale;
+    else if (i < na + nb + nc) c[i - na - nb] *= scale;
+    else if (i < na + nb + nc + nd) d[i - na - nb - nc] *= scale;
+}
+
 extern "C" int aig_gp_scalars(const float* norm_sq, float scale, float* out3, void* stream) {
     AIG_REQUIRE(norm_sq && out3, "aig_gp_scalars: null pointer");
     hipLaunchKernelGGL(k_gp_scalars, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), norm_sq, scale, out3);
@@ -386,36 +421,57 @@ extern "C" size_t aig_gp_input_grad_ws_bytes(int64_t n) {
     return align_up((size_t)GP_BLOCKS_MAX * 4) + 256;
 }
 
-extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r,
-                                 const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1,
-                                 const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
-                                 void* ws, size_t ws_bytes, void* stream) {
+namespace {
+int gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                  const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1,
+                  const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq, const float* grad_scale,
+                  float* out3, void* ws, size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX && L >= 0 && L < INT_MAX, "aig_gp_input_grad: bad sizes");
     AIG_REQUIRE(g_r && node_level && w && argmax && W1 && W2 && h1 && h2 && g_z2 && g_h1 && g_z1 && g_x && norm_sq && ws,
                 "aig_gp_input_grad: null pointer");
     if (ws_bytes < aig_gp_input_grad_ws_bytes(n)) return fail(AIG_EWORKSPACE, "aig_gp_input_grad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* partial = static_cast<float*>(ws);
+    int blocks = 0;
     if (use_tiles(n, n_rows_dev)) {
-        int blocks = 0;
         int rc = launch_gp_tiles_input_grad(s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w, argmax, W1, W2, h1, h2,
                                             g_z2, g_h1, g_z1, g_x, partial, &blocks);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(256), 0, s, blocks, 1, partial, norm_sq);
+    } else {
+        RowLimitScope limit(n_rows_dev);
+        blocks = gp_blocks(n);
+        hipLaunchKernelGGL(k_gp_gz2, dim3(blocks), dim3(THREADS), 0, s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w,
+                           argmax, h2, g_z2);
         AIG_LAUNCH_CHECK();
-        return AIG_OK;
+        int rc = aig_linear128(n, g_z2, W2, 1, nullptr, 0, g_h1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gp_gx, dim3(blocks), dim3(THREADS), 0, s, (int)n, n_rows_dev, g_h1, h1, W1, g_z1, g_x, partial);
     }
-    RowLimitScope limit(n_rows_dev);
-    const int g = gp_blocks(n);
-    hipLaunchKernelGGL(k_gp_gz2, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, (int)L, lvl_meta, g_r, node_level, w, argmax,
-                       h2, g_z2);
-    AIG_LAUNCH_CHECK();
-    int rc = aig_linear128(n, g_z2, W2, 1, nullptr, 0, g_h1, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_gx, dim3(g), dim3(THREADS), 0, s, (int)n, n_rows_dev, g_h1, h1, W1, g_z1, g_x, partial);
-    hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(256), 0, s, g, 1, partial, norm_sq);
+    if (out3)
+        hipLaunchKernelGGL(k_gp_norm_scalars, dim3(1), dim3(256), 0, s, blocks, partial, *grad_scale, norm_sq, out3);
+    else
+        hipLaunchKernelGGL(k_sum_cols, dim3(1), dim3(256), 0, s, blocks, 1, partial, norm_sq);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+}  // namespace
+
+extern "C" int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                                 const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1,
+                                 const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    return gp_input_grad(n, n_rows_dev, L, lvl_meta, g_r, node_level, w, argmax, W1, W2, h1, h2, g_z2, g_h1, g_z1, g_x, norm_sq,
+                         nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int aig_gp_input_grad_scalars(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                                         const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1,
+                                         const float* W2, const float* h1, const float* h2, float* g_z2, float* g_h1, float* g_z1,
+                                         float* g_x, float* norm_sq, float grad_scale, float* out3, void* ws, size_t ws_bytes,
+                                         void* stream) {
+    AIG_REQUIRE(out3, "aig_gp_input_grad_scalars: null output");
+    return gp_input_grad(n, n_rows_dev, L, lvl_meta, g_r, node_level, w, argmax, W1, W2, h1, h2, g_z2, g_h1, g_z1, g_x, norm_sq,
+                         &grad_scale, out3, ws, ws_bytes, stream);
 }
 
 extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
@@ -428,12 +484,29 @@ extern "C" size_t aig_gp_param_grad_ws_bytes(int64_t n) {
     return n <= GP_TILES_MAX_PLAIN_ROWS ? tiles : (chain > tiles ? chain : tiles);      // (large n: either may run)
 }
 
+extern "C" int aig_gp_param_grad_scaled(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
+                                        const float* g_r, const int32_t* node_level, const float* w, const int32_t* argmax,
+                                        const float* W1, const float* W2, const float* xhat, const float* h1, const float* h2,
+                                        const float* g_z2, const float* g_h1, const float* g_z1, const float* g_x, float* dW1,
+                                        float* db1, float* dW2, float* db2, float* ubar_gr, float out_scale, void* ws,
+                                        size_t ws_bytes, void* stream);
+
 extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
                                  const float* g_r,
                                  const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2,
                                  const float* xhat, const float* h1, const float* h2, const float* g_z2,
                                  const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1,
                                  float* dW2, float* db2, float* ubar_gr, void* ws, size_t ws_bytes, void* stream) {
+    return aig_gp_param_grad_scaled(n, n_rows_dev, L, lvl_meta, coef, g_r, node_level, w, argmax, W1, W2, xhat, h1, h2, g_z2, g_h1,
+                                    g_z1, g_x, dW1, db1, dW2, db2, ubar_gr, 1.0f, ws, ws_bytes, stream);
+}
+
+extern "C" int aig_gp_param_grad_scaled(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
+                                        const float* g_r, const int32_t* node_level, const float* w, const int32_t* argmax,
+                                        const float* W1, const float* W2, const float* xhat, const float* h1, const float* h2,
+                                        const float* g_z2, const float* g_h1, const float* g_z1, const float* g_x, float* dW1,
+                                        float* db1, float* dW2, float* db2, float* ubar_gr, float out_scale, void* ws,
+                                        size_t ws_bytes, void* stream) {
     AIG_REQUIRE(n > 0 && n < INT_MAX && L >= 0 && L < INT_MAX, "aig_gp_param_grad: bad sizes");
     AIG_REQUIRE(coef && g_r && node_level && w && argmax && W1 && W2 && xhat && h1 && h2 && g_z2 && g_h1 && g_z1 && g_x &&
                     dW1 && db1 && dW2 && db2 && ubar_gr && ws,
@@ -442,7 +515,7 @@ extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_tiles(n, n_rows_dev))
         return launch_gp_tiles_param_grad(s, (int)n, n_rows_dev, (int)L, lvl_meta, coef, g_r, node_level, w, argmax, W1, W2, xhat,
-                                          h1, h2, g_z2, g_h1, g_z1, g_x, dW1, db1, dW2, db2, ubar_gr, static_cast<float*>(ws));
+                                          h1, h2, g_z2, g_h1, g_z1, g_x, dW1, db1, dW2, db2, ubar_gr, static_cast<float*>(ws), out_scale);
     const size_t NH = (size_t)n * H;
     Carver c(ws);
     float* ubar_gh1 = c.take<float>(NH);
@@ -476,5 +549,10 @@ extern "C" int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L
     AIG_LAUNCH_CHECK();
     // dW1 = g_z1^T u + dz1^T x^
     if ((rc = wgrad_sum2(n, 2, g_z1, u, dz1, xhat, dW1, wg, wg_bytes, s))) return rc;
+    if (out_scale != 1.0f) {
+        hipLaunchKernelGGL(k_gp_scale4, dim3((H * H + 2 * H + 2 * H + 255) / 256), dim3(256), 0, s, dW2, H * H, dW1, 2 * H, db1, H,
+                           db2, H, out_scale);
+        AIG_LAUNCH_CHECK();
+    }
     return AIG_OK;
 }

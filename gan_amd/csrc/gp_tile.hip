@@ -376,7 +376,7 @@ __global__ __launch_bounds__(THREADS) void k_gpt_param_grad(
 __global__ __launch_bounds__(256) void k_gpt_reduce(int n, const int* __restrict__ row_limit, int grid,
                                                     const float* __restrict__ partial, float* __restrict__ dW2,
                                                     float* __restrict__ db2, float* __restrict__ ubar_gr,
-                                                    float* __restrict__ db1, float* __restrict__ dW1) {
+                                                    float* __restrict__ db1, float* __restrict__ dW1, float out_scale) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= P_ROW) return;
     n = limited_rows(n, row_limit);
@@ -391,11 +391,13 @@ __global__ __launch_bounds__(256) void k_gpt_reduce(int n, const int* __restrict
     }
     for (; b < nb; ++b) s0 += partial[(size_t)b * P_ROW + e];
     const float s = (s0 + s1) + (s2 + s3);
-    if (e < P_DB2) dW2[e] = s;
-    else if (e < P_SM) db2[e - P_DB2] = s;
+    // (the parameter gradients leave multiplied by out_scale - one rounding each, as a multiplication after the fact
+    //  would give; the readout's adjoint is an intermediate of the head's share and stays as it is)
+    if (e < P_DB2) dW2[e] = s * out_scale;
+    else if (e < P_SM) db2[e - P_DB2] = s * out_scale;
     else if (e < P_DB1) ubar_gr[e - P_SM] = s;
-    else if (e < P_DW1) db1[e - P_DB1] = s;
-    else dW1[e - P_DW1] = s;
+    else if (e < P_DW1) db1[e - P_DB1] = s * out_scale;
+    else dW1[e - P_DW1] = s * out_scale;
 }
 
 int tiles_grid(int64_t n) {
@@ -444,7 +446,7 @@ int launch_gp_tiles_param_grad(hipStream_t s, int n, const int* row_limit, int L
                                const float* g_r, const int* node_level, const float* w, const int* argmax, const float* W1,
                                const float* W2, const float* xhat, const float* h1, const float* h2, const float* g_z2,
                                const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1, float* dW2,
-                               float* db2, float* ubar_gr, float* partial) {
+                               float* db2, float* ubar_gr, float* partial, float out_scale) {
     AIG_REQUIRE(((reinterpret_cast<uintptr_t>(g_x) | reinterpret_cast<uintptr_t>(xhat)) & 7) == 0 &&
                     (reinterpret_cast<uintptr_t>(W2) & 15) == 0,
                 "gradient penalty: g_x and x^ are read as 8-byte pairs, the weight as 16-byte vectors");
@@ -453,7 +455,7 @@ int launch_gp_tiles_param_grad(hipStream_t s, int n, const int* row_limit, int L
     hipLaunchKernelGGL(k_gpt_param_grad, dim3(g), dim3(THREADS), LDS_PAR, s, n, row_limit, L, meta, coef, g_r, node_level, w,
                        argmax, W1, W2, xhat, h1, h2, g_z2, g_h1, g_z1, g_x, partial);
     hipLaunchKernelGGL(k_gpt_reduce, dim3((P_ROW + 255) / 256), dim3(256), 0, s, n, row_limit, g, partial, dW2, db2, ubar_gr,
-                       db1, dW1);
+                       db1, dW1, out_scale);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
 }

@@ -127,7 +127,8 @@ constexpr int HD_GR_THREADS = 512;
 __global__ __launch_bounds__(HD_GR_THREADS) void k_head_gr_wgrad(const float* __restrict__ u, const float* __restrict__ W1,
                                                                  const float* __restrict__ W2, const float* __restrict__ W3,
                                                                  const float* __restrict__ act, float* __restrict__ dW1,
-                                                                 float* __restrict__ dW2, float* __restrict__ dW3) {
+                                                                 float* __restrict__ dW2, float* __restrict__ dW3,
+                                                                 float out_scale /* every output times this, rounded once more */) {
     static_assert(HD_H1 == 4 * 4 * (HD_GR_THREADS / 64) && HD_H2 == 2 * 4 * (HD_GR_THREADS / 64), "rows are dealt to eight waves");
     __shared__ __attribute__((aligned(16))) float s_u[HD_IN];
     __shared__ __attribute__((aligned(16))) float s_t1[HD_H1];   // m1 * (W1 u)
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(HD_GR_THREADS) void k_head_gr_wgrad(const float* __
             if (lane == 0) s_t1[row] = s_m1[row] * s;
         }
     __syncthreads();
-    for (int e = tid; e < HD_H1 * HD_IN; e += HD_GR_THREADS) dW1[e] = s_p1[e / HD_IN] * s_u[e % HD_IN];
-    for (int e = tid; e < HD_H2 * HD_H1; e += HD_GR_THREADS) dW2[e] = s_p2[e / HD_H1] * s_t1[e % HD_H1];
+    for (int e = tid; e < HD_H1 * HD_IN; e += HD_GR_THREADS) dW1[e] = (s_p1[e / HD_IN] * s_u[e % HD_IN]) * out_scale;
+    for (int e = tid; e < HD_H2 * HD_H1; e += HD_GR_THREADS) dW2[e] = (s_p2[e / HD_H1] * s_t1[e % HD_H1]) * out_scale;
     const float2 tv = reinterpret_cast<const float2*>(s_t1)[lane];
 #pragma unroll
     for (int it = 0; it < 2; ++it)      // dW3[j] = m2[j] * sum_k W2[j][k] t1[k]
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(HD_GR_THREADS) void k_head_gr_wgrad(const float* __
         for (int q = 0; q < 4; ++q) {
             const float s = wave_sum(w2v[it][q].x * tv.x + w2v[it][q].y * tv.y);
             const int row = 32 * it + 4 * wave + q;
-            if (lane == 0) dW3[row] = s_m2[row] * s;
+            if (lane == 0) dW3[row] = (s_m2[row] * s) * out_scale;
         }
 }
 
@@ -212,14 +213,20 @@ extern "C" int aig_head_bwd(const float* d_score, const float* r, const float* w
     return AIG_OK;
 }
 
-extern "C" int aig_head_input_grad_wgrad(const float* u, const float* w1, const float* w2, const float* w3,
-                                         const float* act, float* d_w1, float* d_w2, float* d_w3, void* stream) {
+extern "C" int aig_head_input_grad_wgrad_scaled(const float* u, const float* w1, const float* w2, const float* w3,
+                                                const float* act, float* d_w1, float* d_w2, float* d_w3, float out_scale,
+                                                void* stream) {
     AIG_REQUIRE(u && w1 && w2 && w3 && act && d_w1 && d_w2 && d_w3, "aig_head_input_grad_wgrad: null pointer");
     AIG_REQUIRE(((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(w1)) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(w2) & 7) == 0,
                 "aig_head_input_grad_wgrad: u and w1 must be 16-byte aligned, w2 8-byte aligned (rows are read as vectors)");
     hipLaunchKernelGGL(k_head_gr_wgrad, dim3(1), dim3(HD_GR_THREADS), 0, static_cast<hipStream_t>(stream), u, w1, w2, w3, act,
-                       d_w1, d_w2, d_w3);
+                       d_w1, d_w2, d_w3, out_scale);
     AIG_LAUNCH_CHECK();
     return AIG_OK;
+}
+
+extern "C" int aig_head_input_grad_wgrad(const float* u, const float* w1, const float* w2, const float* w3,
+                                         const float* act, float* d_w1, float* d_w2, float* d_w3, void* stream) {
+    return aig_head_input_grad_wgrad_scaled(u, w1, w2, w3, act, d_w1, d_w2, d_w3, 1.0f, stream);
 }

@@ -710,7 +710,7 @@ class AIGDiscriminator(nn.Module):
 
     def gradient_penalty_closed_form(self, x_real: torch.Tensor, x_fake: torch.Tensor, alpha: torch.Tensor,
                                      node_depth: Optional[torch.Tensor], plan=None, grad_scale: float = 1.0,
-                                     rows: Optional["GpRows"] = None):
+                                     rows: Optional["GpRows"] = None, out_scale: float = 1.0):
         """``gradient_penalty(use_edges=False)`` of train.py:133-152 and its gradient w.r.t. the critic's
         parameters without autograd on the node tensors: on an empty edge list each attention layer
         is ``elu(x W^T + b)``, which makes the penalty a closed form (four [n,128]x[128,128]
@@ -721,7 +721,9 @@ class AIGDiscriminator(nn.Module):
         multiplies every returned gradient (the loss weights the penalty by gp_lambda).  ``rows``: a ``GpRows``
         whose last ``rebuild`` was made for these very features and levels - the computation then runs over its
         distinct rows (same numbers up to the order of the sums); ``x_real`` / ``x_fake`` / ``plan`` are not read.
-        ``rows=True``: the rows are built here, for this call."""
+        ``rows=True``: the rows are built here, for this call.  ``out_scale`` multiplies every returned gradient
+        AFTER the fact - one more rounding per element, the bits of ``out_scale * gradient`` as train.py:258 forms
+        ``gp_lambda * gp`` - inside the launches that write them."""
         lib = _abi.lib()
         dev = x_real.device
         n = int(x_real.size(0))
@@ -782,32 +784,34 @@ class AIGDiscriminator(nn.Module):
                                     _abi.ptr(g_r_c), None, None, None, None, None, None, st), "aig_head_bwd")
         g_z2, g_h1, g_z1 = (torch.empty((n, HIDDEN), **f32) for _ in range(3))
         g_x, norm_sq = torch.empty((n, 2), **f32), torch.empty(1, **f32)
-        ws = _abi.workspace(lib.aig_gp_input_grad_ws_bytes(n), dev)
-        _abi.check(lib.aig_gp_input_grad(n, _abi.ptr(n_dev), plan.L, _abi.ptr(plan.meta), _abi.ptr(g_r_c), _abi.ptr(plan.node_level), _abi.ptr(w_bwd),
-                                         _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(h1), _abi.ptr(h2),
-                                         _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(norm_sq),
-                                         _abi.ptr(ws), ws.numel(), st), "aig_gp_input_grad")
-        # norm, gp = (norm - 1)^2 and coef = grad_scale * d gp / d norm / norm in one launch.  d gp / d g_x =
-        # coef * g_x; at norm = 0 autograd's torch.norm has the zero subgradient (train.py:150), so the penalty's
-        # gradient vanishes there instead of becoming 0 * inf (decided on the device, no host read)
+        # norm, gp = (norm - 1)^2 and coef = grad_scale * d gp / d norm / norm come out of the launch that adds up
+        # |g_x|^2.  d gp / d g_x = coef * g_x; at norm = 0 autograd's torch.norm has the zero subgradient
+        # (train.py:150), so the penalty's gradient vanishes there instead of becoming 0 * inf (decided on the
+        # device, no host read)
         sc = torch.empty(3, **f32)
-        _abi.check(lib.aig_gp_scalars(_abi.ptr(norm_sq), float(grad_scale), _abi.ptr(sc), st), "aig_gp_scalars")
+        ws = _abi.workspace(lib.aig_gp_input_grad_ws_bytes(n), dev)
+        _abi.check(lib.aig_gp_input_grad_scalars(n, _abi.ptr(n_dev), plan.L, _abi.ptr(plan.meta), _abi.ptr(g_r_c),
+                                                 _abi.ptr(plan.node_level), _abi.ptr(w_bwd), _abi.ptr(argmax), _abi.ptr(W1),
+                                                 _abi.ptr(W2), _abi.ptr(h1), _abi.ptr(h2), _abi.ptr(g_z2), _abi.ptr(g_h1),
+                                                 _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(norm_sq), float(grad_scale),
+                                                 _abi.ptr(sc), _abi.ptr(ws), ws.numel(), st), "aig_gp_input_grad_scalars")
         norm, gp, coef = sc[0], sc[1], sc[2:3]
         dW1, db1 = torch.empty((HIDDEN, 2), **f32), torch.empty(HIDDEN, **f32)
         dW2, db2 = torch.empty((HIDDEN, HIDDEN), **f32), torch.empty(HIDDEN, **f32)
         u_gr = torch.empty((1, 2 * HIDDEN), **f32)
         ws = _abi.workspace(lib.aig_gp_param_grad_ws_bytes(n), dev)
-        _abi.check(lib.aig_gp_param_grad(n, _abi.ptr(n_dev), plan.L, _abi.ptr(plan.meta), _abi.ptr(coef), _abi.ptr(g_r_c), _abi.ptr(plan.node_level),
-                                         _abi.ptr(w_bwd), _abi.ptr(argmax), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(xhat),
-                                         _abi.ptr(h1), _abi.ptr(h2), _abi.ptr(g_z2), _abi.ptr(g_h1), _abi.ptr(g_z1),
-                                         _abi.ptr(g_x), _abi.ptr(dW1), _abi.ptr(db1), _abi.ptr(dW2), _abi.ptr(db2),
-                                         _abi.ptr(u_gr), _abi.ptr(ws), ws.numel(), st), "aig_gp_param_grad")
+        _abi.check(lib.aig_gp_param_grad_scaled(n, _abi.ptr(n_dev), plan.L, _abi.ptr(plan.meta), _abi.ptr(coef), _abi.ptr(g_r_c),
+                                                _abi.ptr(plan.node_level), _abi.ptr(w_bwd), _abi.ptr(argmax), _abi.ptr(W1),
+                                                _abi.ptr(W2), _abi.ptr(xhat), _abi.ptr(h1), _abi.ptr(h2), _abi.ptr(g_z2),
+                                                _abi.ptr(g_h1), _abi.ptr(g_z1), _abi.ptr(g_x), _abi.ptr(dW1), _abi.ptr(db1),
+                                                _abi.ptr(dW2), _abi.ptr(db2), _abi.ptr(u_gr), float(out_scale), _abi.ptr(ws),
+                                                ws.numel(), st), "aig_gp_param_grad_scaled")
         grads = {self.gat1.lin.weight: dW1, self.gat1.bias: db1, self.gat2.lin.weight: dW2, self.gat2.bias: db2}
         # the head's share: gradient of <g_r, u_gr> w.r.t. its weights (its biases only move the ReLU masks)
         dhw1, dhw2, dhw3 = torch.empty((128, 256), **f32), torch.empty((64, 128), **f32), torch.empty((1, 64), **f32)
-        _abi.check(lib.aig_head_input_grad_wgrad(_abi.ptr(u_gr), _abi.ptr(hw1), _abi.ptr(hw2), _abi.ptr(hw3), _abi.ptr(act),
-                                                 _abi.ptr(dhw1), _abi.ptr(dhw2), _abi.ptr(dhw3), st),
-                   "aig_head_input_grad_wgrad")
+        _abi.check(lib.aig_head_input_grad_wgrad_scaled(_abi.ptr(u_gr), _abi.ptr(hw1), _abi.ptr(hw2), _abi.ptr(hw3), _abi.ptr(act),
+                                                        _abi.ptr(dhw1), _abi.ptr(dhw2), _abi.ptr(dhw3), float(out_scale), st),
+                   "aig_head_input_grad_wgrad_scaled")
         grads[self.mlp[0].weight], grads[self.mlp[2].weight], grads[self.out.weight] = dhw1, dhw2, dhw3
         return gp.detach(), norm.detach(), grads
 

@@ -349,13 +349,12 @@ class CapturedCriticTerms:
 
         def compute_gp():
             if closed_form_gp:
+                # (scaled after the fact - ``out_scale``, inside the launches that write the gradients - not through
+                #  ``grad_scale``: the same roundings as lambda * autograd's gradient; Adam turns a last-bit
+                #  difference in a near-zero gradient element into a full step)
                 gp, gn, gp_grads = D.gradient_penalty_closed_form(self.x_real, self.x_fake, self.alpha, self.depth,
-                                                                  plan=self.plan, rows=self.gp_rows)
-                # (scaled after the fact, not through ``grad_scale``: the same roundings as lambda * autograd's
-                #  gradient - Adam turns a last-bit difference in a near-zero gradient element into a full step)
-                scaled = dict(zip([p for p in params if p in gp_grads],
-                                  torch._foreach_mul([gp_grads[p] for p in params if p in gp_grads], gp_lambda)))
-                return gp, gn, [scaled.get(p) for p in params]
+                                                                  plan=self.plan, rows=self.gp_rows, out_scale=gp_lambda)
+                return gp, gn, [gp_grads.get(p) for p in params]
             gp, gn = gradient_penalty(D, real_pad, fake_pad, device, use_edges=False, alpha=self.alpha, plan=self.plan)
             return gp.detach(), gn, torch.autograd.grad(gp_lambda * gp, params, allow_unused=True)
 

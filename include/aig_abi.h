@@ -285,6 +285,10 @@ int aig_head_bwd(const float* d_score, const float* r, const float* w1, const fl
                  float* d_b3, void* stream);
 int aig_head_input_grad_wgrad(const float* u, const float* w1, const float* w2, const float* w3, const float* act,
                               float* d_w1, float* d_w2, float* d_w3, void* stream);
+/* The same with every output multiplied by out_scale after the fact (one more f32 rounding per element - what
+ * `gp_lambda * gradient` of train.py:258 does to autograd's gradient - without a launch for it). */
+int aig_head_input_grad_wgrad_scaled(const float* u, const float* w1, const float* w2, const float* w3, const float* act,
+                                     float* d_w1, float* d_w2, float* d_w3, float out_scale, void* stream);
 
 /* Weight gradient of a dense projection xw = x W^T over the nodes (the reduction torch.nn.functional.linear's
  * backward performs for gat{1,2}.lin at discriminator.py:60-61): dW[j][f] = sum_n g[n][j] * x[n][f],
@@ -447,12 +451,25 @@ int aig_gp_input_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int
                       const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* h1, const float* h2,
                       float* g_z2, float* g_h1, float* g_z1, float* g_x, float* norm_sq,
                       void* ws, size_t ws_bytes, void* stream);
+/* aig_gp_input_grad followed by aig_gp_scalars(norm_sq, grad_scale, out3) with one launch less: the launch that adds
+ * up |g_x|^2 also forms the three scalars (same sums, same order, same bits; train.py:150-151). */
+int aig_gp_input_grad_scalars(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* g_r,
+                              const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2,
+                              const float* h1, const float* h2, float* g_z2, float* g_h1, float* g_z1, float* g_x,
+                              float* norm_sq, float grad_scale, float* out3, void* ws, size_t ws_bytes, void* stream);
 size_t aig_gp_param_grad_ws_bytes(int64_t n);
 int aig_gp_param_grad(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef, const float* g_r,
                       const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1, const float* W2, const float* xhat,
                       const float* h1, const float* h2, const float* g_z2, const float* g_h1, const float* g_z1,
                       const float* g_x, float* dW1, float* db1, float* dW2, float* db2, float* ubar_gr,
                       void* ws, size_t ws_bytes, void* stream);
+/* The same with dW1, db1, dW2, db2 multiplied by out_scale after the fact (one more f32 rounding per element, as
+ * `gp_lambda * gradient` of train.py:258 gives; ubar_gr, an intermediate of the head's share, is not scaled). */
+int aig_gp_param_grad_scaled(int64_t n, const int32_t* n_rows_dev, int64_t L, const int32_t* lvl_meta, const float* coef,
+                             const float* g_r, const int32_t* node_level, const float* w, const int32_t* argmax, const float* W1,
+                             const float* W2, const float* xhat, const float* h1, const float* h2, const float* g_z2,
+                             const float* g_h1, const float* g_z1, const float* g_x, float* dW1, float* db1, float* dW2,
+                             float* db2, float* ubar_gr, float out_scale, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Structural constraints - models/constraints.py.  One graph per call, n > 0 and E > 0 (the callers

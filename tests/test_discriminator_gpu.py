@@ -810,3 +810,29 @@ def test_readout_over_a_table_cleared_by_the_launch_before(n, levels, dyn):
     got = pool(lib.aig_level_pool_fwd_cleared, ws, h2)
     want = pool(lib.aig_level_pool_fwd, torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev), h2)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1][:levels], want[1][:levels])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_and,rows", [(700, None), (700, True), (30000, None), (30000, True)])
+def test_penalty_gradients_scaled_inside_their_launches(n_and, rows):
+    """``out_scale`` multiplies every returned gradient after the fact, inside the launches that write them: the bits
+    of ``out_scale * gradient`` (the tile kernels' reduction for small inputs and distinct rows, the chain's own
+    scaling launch over every node of a larger graph, the head's weight gradient in both)."""
+    torch.manual_seed(4)
+    g = synth_aig(12, n_and, 9, seed=18, window=60, orientation="dataset")
+    D = AIGDiscriminator().to(DEV)
+    with torch.no_grad():
+        for p in D.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    xr = g.x.to(DEV)
+    xf = g.x.clone()
+    xf[:, 1] = torch.randint(0, 3, (g.x.size(0),), generator=torch.Generator().manual_seed(2)).float()
+    xf = xf.to(DEV)
+    alpha, nd = torch.tensor([[0.41]], device=DEV), g.node_depth.to(DEV)
+    gp1, gn1, plain = D.gradient_penalty_closed_form(xr, xf, alpha, nd, rows=rows)
+    gp2, gn2, scaled = D.gradient_penalty_closed_form(xr, xf, alpha, nd, rows=rows, out_scale=10.0)
+    assert float(gp1) == float(gp2) and float(gn1) == float(gn2) and float(gn1) > 0
+    assert set(plain) == set(scaled) and len(plain) == 7
+    for p in plain:
+        assert float(plain[p].abs().max()) > 0
+        assert torch.equal(scaled[p], plain[p] * 10.0)
