@@ -836,3 +836,34 @@ def test_penalty_gradients_scaled_inside_their_launches(n_and, rows):
     for p in plain:
         assert float(plain[p].abs().max()) > 0
         assert torch.equal(scaled[p], plain[p] * 10.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 65, 97])
+def test_closed_form_penalty_on_partial_tiles(n):
+    """A handful of rows (the penalty's kernels work on tiles of 32): gp, norm and every parameter gradient
+    against autograd, 1e-4 relative."""
+    from gan_amd.train import gradient_penalty
+    torch.manual_seed(n)
+    D = AIGDiscriminator().to(DEV)
+    with torch.no_grad():
+        for p in D.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(100 + n)
+    xr = torch.stack([torch.randint(0, 3, (n,), generator=g).float(), torch.randint(0, 3, (n,), generator=g).float()], 1).to(DEV)
+    xf = (xr.cpu() + torch.rand((n, 2), generator=g)).to(DEV)
+    nd = torch.randint(0, 4, (n,), generator=g).to(DEV)
+    alpha = torch.tensor([[0.7]], device=DEV)
+    gp_ref, gn_ref = gradient_penalty(D, Data(x=xr, node_depth=nd), Data(x=xf), torch.device(DEV), use_edges=False, alpha=alpha)
+    params = list(D.parameters())
+    ref = torch.autograd.grad(gp_ref, params, allow_unused=True)
+    for rows in (None, True):
+        gp, gn, grads = D.gradient_penalty_closed_form(xr, xf, alpha, nd, rows=rows)
+        assert abs(float(gp) - float(gp_ref)) <= 1e-4 * max(abs(float(gp_ref)), 1e-6)
+        assert abs(float(gn) - float(gn_ref)) <= 1e-4 * abs(float(gn_ref))
+        for p, r in zip(params, ref):
+            if r is None or float(r.abs().max()) == 0.0:
+                assert p not in grads or float(grads[p].abs().max()) <= 1e-7
+            else:
+                scale = float(r.abs().max())
+                assert float((grads[p] - r).abs().max()) <= 1e-4 * scale, (rows, tuple(p.shape))
