@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence: everything lands in gpurun_out/r03/ under the names it gets in profiles/.
+# Evidence for profiles/: everything lands in gpurun_out/r03/ under the names it gets in profiles/ (the r03_ prefix is the naming scheme of that directory).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/r03
 mkdir -p $o
