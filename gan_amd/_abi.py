@@ -214,7 +214,20 @@ def ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> C.c_void_p:
+    """The current stream of the current device as the ``hipStream_t`` the entry points take.  Asked for once per
+    entry-point call - a dozen and more times per training step - so it goes through torch's two C calls (current
+    device, its current raw stream: well under a microsecond) where they exist; building a ``torch.cuda.Stream``
+    object to read its handle costs ~9 us a call."""
+    if _raw_stream is not None and _cur_device is not None:
+        try:
+            return C.c_void_p(_raw_stream(_cur_device()))
+        except Exception:       # (no device: the public call below says so in torch's own words)
+            pass
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
