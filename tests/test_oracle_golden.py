@@ -68,6 +68,31 @@ def test_position_independent_generator_oracle_against_reference(case):
         assert np.array_equal(out["x"].numpy(), d["out_x"])
 
 
+@pytest.mark.parametrize("zd", [4, 48, 200])
+def test_position_independent_generator_oracle_at_other_z_widths(zd):
+    """``--z-dim`` other than 128 (train.py:374): the fixed-order form against the restatement of the reference's own
+    formulation (``cat[h, z]`` through the linear layers, models/generator.py:115-117, 94-98) - same windows and
+    targets, h_cond and scores within 1e-4 relative.  No vector of the reference exists at these widths: the two
+    restatements agree with each other, and at width 128 each of them is held to the reference's vectors above."""
+    from gan_amd.generator import AIGGenerator
+    from gan_amd.synth import synth_aig
+    torch.manual_seed(zd)
+    state = {k: v.detach().clone() for k, v in AIGGenerator(z_dim=zd, candidate_k=16).state_dict().items()}
+    assert tuple(state["node_proj.0.weight"].shape) == (128, 128 + zd)
+    g = synth_aig(10, 220, 8, seed=zd, window=60, orientation="dataset")
+    z = torch.randn(zd, generator=torch.Generator().manual_seed(1))
+    fixed = omodel.generator_forward_canonical(state, g.x, g.node_depth, z, 16)
+    plain = omodel.generator_forward(state, g.x, g.node_depth, z, 16, keep=True)
+    np.testing.assert_allclose(fixed["h_cond"], plain["h_cond"].numpy(), rtol=1e-4, atol=1e-6)
+    assert np.array_equal(fixed["edge_index"][1].numpy(), plain["edge_index"][1].numpy())
+    slot = {int(v): t for t, v in enumerate(fixed["tgt"])}
+    for v, cand, logit in zip(plain["rec"]["tgt"], plain["rec"]["cand"], plain["rec"]["logit"]):
+        t = slot[v]
+        c = int(fixed["cnt"][t])
+        assert np.array_equal(fixed["cand"][t, :c], cand)
+        np.testing.assert_allclose(fixed["logits"][t, :c], logit, rtol=1e-4, atol=1e-6)
+
+
 def test_tie_inconsistency_of_reference_scores_is_real():
     """Documents why bit-exact picks need exact scores: in this fixture the reference gave
     candidates with identical features different logits."""
