@@ -12,6 +12,7 @@
 // Stability (equal keys keep their input order) is what the callers rely on: edge lists by target keep the order of
 // the edge slots, which fixes the order of every floating-point sum over a node's edges.
 #pragma once
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
@@ -168,9 +169,17 @@ constexpr size_t scatter_lds_bytes() {
     return (size_t)(THREADS / 64 * RS_BINS + RS_BINS) * 4 + (size_t)THREADS * IPT * (sizeof(K) + sizeof(V));
 }
 
+inline int max_passes() {      // AIG_RS_MAX_PASSES overrides (tuning aid)
+    static const int v = [] {
+        const char* e = getenv("AIG_RS_MAX_PASSES");
+        const int x = e ? atoi(e) : 0;
+        return x >= 1 && x <= 7 ? x : RS_MAX_PASSES;
+    }();
+    return v;
+}
 inline bool takes(size_t items, int bits, size_t key_bytes) {
     // (8-byte keys: a 16384-item tile with its values would not fit the LDS)
-    return items >= RS_MIN_ITEMS && items <= (key_bytes > 4 ? RS_MAX_ITEMS / 2 : RS_MAX_ITEMS) && bits <= RS_DIGIT * RS_MAX_PASSES;
+    return items >= RS_MIN_ITEMS && items <= (key_bytes > 4 ? RS_MAX_ITEMS / 2 : RS_MAX_ITEMS) && bits <= RS_DIGIT * max_passes();
 }
 
 template <typename K, typename V>
