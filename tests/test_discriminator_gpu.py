@@ -867,3 +867,20 @@ def test_closed_form_penalty_on_partial_tiles(n):
             else:
                 scale = float(r.abs().max())
                 assert float((grads[p] - r).abs().max()) <= 1e-4 * scale, (rows, tuple(p.shape))
+
+
+@pytest.mark.gpu
+def test_clearing_launch_on_an_empty_graph_and_bad_arguments():
+    """``aig_gat_fwd_clearing`` with no node still clears what it was asked to; a misaligned or odd-sized buffer is
+    refused."""
+    lib = _abi.lib()
+    dev = torch.device("cuda")
+    ws = torch.full((4096,), 0xFF, dtype=torch.uint8, device=dev)
+    st = _abi.stream()
+    args = [0] + [None] * 12
+    _abi.check(lib.aig_gat_fwd_clearing(*args, _abi.ptr(ws), 1024, st), "aig_gat_fwd_clearing")
+    torch.cuda.synchronize()
+    assert int(ws[:1024].max()) == 0 and int(ws[1024:].min()) == 0xFF
+    assert lib.aig_gat_fwd_clearing(*args, _abi.ptr(ws[4:]), 1024, st) != 0        # not 8-byte aligned
+    assert lib.aig_gat_fwd_clearing(*args, _abi.ptr(ws), 1020, st) != 0           # not a multiple of 8
+    assert lib.aig_gat_fwd_clearing(*args, None, 0, st) == 0                      # nothing to clear: as aig_gat_fwd

@@ -627,3 +627,27 @@ def test_other_z_widths_bf16_projection_and_refusals():
     for bad in (0, 2, 130, 1028):
         with pytest.raises(NotImplementedError):
             AIGGenerator(z_dim=bad)
+
+
+def test_z_width_is_checked_at_the_c_abi():
+    """``aig_gen_weights.z_dim`` outside a multiple of 4 in 4..1024 is refused with a message, not read past."""
+    import ctypes as C
+    lib = _abi.lib()
+    G = AIGGenerator(z_dim=64, candidate_k=8).to(DEV).eval()
+    w = G._weights_uncached()
+    n = 40
+    x = torch.zeros((n, 2), device=DEV)
+    z = torch.zeros(64, device=DEV)
+    proj = torch.empty((4, n, 128), device=DEV)
+    ws = _abi.workspace(lib.aig_gen_node_proj_ws_bytes(n), torch.device(DEV))
+    call = lambda: lib.aig_gen_node_proj(n, _abi.ptr(x), _abi.ptr(z), C.byref(w), None, _abi.ptr(proj), _abi.ptr(ws),
+                                         ws.numel(), _abi.stream())
+    assert call() == 0
+    torch.cuda.synchronize()
+    for bad in (6, 2, 1028, -4):
+        w.z_dim = bad
+        assert call() != 0
+        assert b"z_dim" in lib.aig_last_error()
+    w.z_dim = 64
+    assert call() == 0
+    torch.cuda.synchronize()
