@@ -130,3 +130,37 @@ def test_sampling_cli_on_the_trained_checkpoint(trained, monkeypatch):
         z = torch.randn(128, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9 + i)).cpu()
         ref = oracle_sample(state, tpl0, z, 16)
         assert torch.equal(a["edge_index"], ref.edge_index) and torch.equal(a["node_depth"], ref.node_depth)
+
+
+def test_both_command_lines_with_another_z_width(tmp_path, monkeypatch):
+    """``train.py --z-dim 40`` for one epoch, then ``AIGgan.py --z-dim 40`` on its checkpoint (train.py:374,
+    AIGgan.py:78): the checkpoint carries the wider / narrower layers and the sample is the CPU checker's."""
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    zd = 40
+    ds = tmp_path / "dataset"
+    graphs = [synth_aig(5 + i, 40 + 9 * i, 3, seed=600 + i, window=14, orientation="dataset") for i in range(3)]
+    save_data_list_as_pt(graphs, str(ds), prefix="g")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        train_cli.main(["--dataset-dir", str(ds), "--out-dir", str(tmp_path / "out"), "--epochs", "1", "--batch-size", "1",
+                        "--candidate-k", "16", "--save-every", "100", "--seed", "7", "--no-progress", "--z-dim", str(zd)])
+    finally:
+        os.chdir(cwd)
+    ckpt = tmp_path / "out" / "generator_epoch0.pt"
+    state = {k: v.cpu() for k, v in torch.load(ckpt, weights_only=True).items()}
+    assert tuple(state["node_proj.0.weight"].shape) == (128, 128 + zd)
+    assert tuple(state["edge_scorer.0.weight"].shape) == (128, 256 + zd)
+    with open(tmp_path / "out" / "metrics.csv") as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 3 and all(math.isfinite(float(v)) for r in rows for v in r.values())
+    one = tmp_path / "one" / "sample_0.pt"
+    sample_cli.main(["--dataset-dir", str(ds), "--gen-ckpt", str(ckpt), "--out", str(one), "--candidate-k", "16",
+                     "--template-idx", "1", "--seed", "31", "--z-dim", str(zd)])
+    got = Data(**torch.load(one, weights_only=True))
+    tpl = load_pt_dataset(str(ds))[1]
+    z = torch.randn(zd, device=DEV, generator=torch.Generator(device=DEV).manual_seed(31)).cpu()
+    ref = oracle_sample(state, tpl, z, 16)
+    assert torch.equal(got.edge_index, ref.edge_index) and torch.equal(got.edge_attr.view(-1), ref.edge_attr.view(-1))
+    assert torch.equal(got.x, ref.x) and torch.equal(got.node_depth, ref.node_depth)
