@@ -203,19 +203,32 @@ constexpr int SEL_CAP = 127;  // nth_element rows have c < 64*k <= 128; 127 lets
 // T rows (threads) a block: 128 - two full waves - down to 8, an eighth of one.  A row's replay is a serial walk whose
 // branches differ from row to row, so a wave spends the SUM of its rows' walks: the fewer rows there are in all, the
 // fewer a wave is given (launch_select), as long as the GPU has waves to spare.
+// Scores by class instead of an array of logits (k_score_classes' values, never stored): the value of entry i of
+// slot r is T[cls[cand[r*ld + i]] * C + cls[order[r]]].  T == nullptr: the kernel reads `logits`.
+struct ClassScores {
+    const int* cand;
+    const int* cls;
+    const int* order;
+    const float* T;
+    int C;
+};
+
 template <int T>
 __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
                                                    const int* __restrict__ cnt,
                                                    const int* __restrict__ want, int* __restrict__ sel,
-                                                   int fused, GenSet gs) {
+                                                   int fused, GenSet gs, ClassScores cs) {
     static_assert(T == 128 || T == 32 || T == 16 || T == 8, "two waves, half a wave, a quarter or an eighth");
     constexpr int W = T < 64 ? T : 64;            // rows (lanes) of a wave
     constexpr int PARTS = 128 / W;                // loads that cover a row of fewer than 128 entries
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
         const long long g = blockIdx.y;
-        logits += g * (long long)rows * ld; cnt += g * gs.node; want += g * gs.node; sel += g * 2ll * rows;
+        cnt += g * gs.node; want += g * gs.node; sel += g * 2ll * rows;
+        if (cs.T) { cs.cand += g * gs.cand; cs.cls += g * gs.node; cs.order += g * gs.node; cs.T += g * (long long)cs.C * cs.C; }
+        else logits += g * (long long)rows * ld;
     }
+    const bool by_class = cs.T != nullptr;
     float* val = reinterpret_cast<float*>(smem);                           // [cap][T+1]
     unsigned char* idx = smem + (size_t)cap * (T + 1) * sizeof(float);     // [cap][T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,19 +239,46 @@ __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, co
     const int my_r = row_base + tid;
     const int my_c = my_r < rows ? cnt[my_r] : 0;
     const int my_k = my_r < rows ? min(want[my_r], my_c) : 0;
-    const bool my_need = my_k > 0 && my_k * 64 > my_c;   // replayed on the LDS copy
+    // replayed on the LDS copy (scores by class: every row is staged, the rows std::partial_sort serves included -
+    // a value costs three dependent loads there, which a thread walking its row alone would pay one after the other)
+    const bool my_need = my_k > 0 && (by_class || my_k * 64 > my_c);
+    const int my_ct = (by_class && my_need) ? cs.cls[cs.order[my_r]] : 0;
     const bool any_need = __syncthreads_or(my_need);
     for (int t0 = 0; any_need && t0 < W; t0 += 8) {
         float v[8][PARTS];
         int cc[8];
+        if (by_class) {
+            int ci[8][PARTS], ct[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0 + u;
-            cc[u] = __shfl(my_need ? my_c : 0, t, 64);
-            // unconditional loads at clamped addresses (a load under a condition becomes a branch with a wait)
-            const float* row = logits + static_cast<size_t>(min(row_base + wave * 64 + t, rows - 1)) * ld;
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u;
+                cc[u] = __shfl(my_need ? my_c : 0, t, 64);
+                ct[u] = __shfl(my_ct, t, 64);
+                const int* crow = cs.cand + static_cast<size_t>(min(row_base + wave * 64 + t, rows - 1)) * ld;
 #pragma unroll
-            for (int part = 0; part < PARTS; ++part) v[u][part] = row[min(lane + W * part, ld - 1)];
+                for (int part = 0; part < PARTS; ++part) ci[u][part] = crow[min(lane + W * part, max(cc[u] - 1, 0))];
+            }
+            int cl[8][PARTS];
+            // (entries past a slot's count are not written by anybody: positions are clamped to the count above, and
+            //  what a slot without candidates holds at position 0 is clamped to a node here - its value is not used)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int part = 0; part < PARTS; ++part) cl[u][part] = cs.cls[min(max(ci[u][part], 0), rows - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int part = 0; part < PARTS; ++part) v[u][part] = cs.T[cl[u][part] * cs.C + ct[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u;
+                cc[u] = __shfl(my_need ? my_c : 0, t, 64);
+                // unconditional loads at clamped addresses (a load under a condition becomes a branch with a wait)
+                const float* row = logits + static_cast<size_t>(min(row_base + wave * 64 + t, rows - 1)) * ld;
+#pragma unroll
+                for (int part = 0; part < PARTS; ++part) v[u][part] = row[min(lane + W * part, ld - 1)];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -257,13 +297,15 @@ __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, co
     if (k > 0) {
         if (k * 64 <= c) {
             if (fused) return;   // picked by the kernel that scored the slot
-            const float* row = logits + static_cast<size_t>(r) * ld;
+            // entry i of the row: from the array of logits, or (scores by class) from the block's LDS copy
+            const float* row = by_class ? val + tid : logits + static_cast<size_t>(r) * ld;
+            const int step = by_class ? T + 1 : 1;
             if (k == 1) {
                 // heap of one: an element replaces the top only when strictly ahead of it
                 int top = 0;
                 float tv = row[0];
                 for (int i = 1; i < c; ++i) {
-                    float v = row[i];
+                    float v = row[i * step];
                     if (gt(v, tv)) { top = i; tv = v; }
                 }
                 s0 = top;
@@ -272,12 +314,12 @@ __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, co
                 int top, oth;
                 float tv, ov;
                 {   // make_heap on positions 0,1
-                    float v0 = row[0], v1 = row[1];
+                    float v0 = row[0], v1 = row[step];
                     if (gt(v1, v0)) { top = 0; tv = v0; oth = 1; ov = v1; }
                     else { top = 1; tv = v1; oth = 0; ov = v0; }
                 }
                 for (int i = 2; i < c; ++i) {
-                    float v = row[i];
+                    float v = row[i * step];
                     if (gt(v, tv)) {  // pop_heap: newcomer and the old `other` re-form the heap
                         if (gt(ov, v)) { top = i; tv = v; }
                         else { top = oth; tv = ov; oth = i; ov = v; }
@@ -797,7 +839,7 @@ int launch_score(hipStream_t s, int B, int n, int K, const int* order, const int
 }
 
 int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, const int* cnt, const int* want, int* sel,
-                  bool fused, const GenSet& gs) {
+                  bool fused, const GenSet& gs, const ClassScores& cs = ClassScores{}) {
     const int cap = ld < SEL_CAP ? ld : SEL_CAP;
     // rows a block: the fewest that still leave the GPU with waves to spare (~6,500 in flight: measured 172 -> 72 us
     // with 8 rows a block on 26k rows, where 8 rows a block on 100k rows took 186 us against 56 with 16)
@@ -806,7 +848,7 @@ int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, c
         hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), sel_lds(SEL_CAP, threads));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + threads - 1) / threads), B), dim3(threads), sel_lds(cap, threads), s, rows,
-                           ld, cap, logits, cnt, want, sel, fused ? 1 : 0, gs);
+                           ld, cap, logits, cnt, want, sel, fused ? 1 : 0, gs, cs);
         return hipSuccess;
     };
     static const int forced = [] { const char* e = getenv("AIG_SELECT_ROWS"); return e ? atoi(e) : 0; }();      // (a tuning aid)
@@ -912,9 +954,13 @@ extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
     AIG_REQUIRE(a->B * a->proj_rows < INT_MAX && a->B * a->ecap < INT_MAX && a->n * a->K < INT_MAX,
                 "aig_gen_wire_batch: set too large for 32-bit indices");
     AIG_REQUIRE(a->x && a->order && a->rank && a->want && a->cnt && a->fb && a->eoff && a->cand && a->proj && a->sc2_w &&
-                    a->sc2_b && a->at2_w && a->at2_b && a->logits && a->sel && a->edge_index && a->edge_attr &&
+                    a->sc2_b && a->at2_w && a->at2_b && a->sel && a->edge_index && a->edge_attr &&
                     a->ecount && a->x_out,
                 "aig_gen_wire_batch: null pointer");
+    // (the scores need not be stored when they come from the class table and every row is short enough for the
+    //  selection kernel's LDS copy: it then forms them itself, and the pass that writes n K logits falls away)
+    AIG_REQUIRE(a->logits || (a->cls && a->K <= SEL_CAP),
+                "aig_gen_wire_batch: logits may be NULL only with scores by class (cls) and K <= %d", SEL_CAP);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = (int)a->B, n = (int)a->n, K = (int)a->K;
     GenSet gs{};
@@ -941,16 +987,21 @@ extern "C" int aig_gen_wire_batch(const aig_gen_wire_set* a, void* stream) {
             hipLaunchKernelGGL(k_pair_table<false>, tgrid, dim3(256), 0, s, C, (long long)a->proj_rows, proj, proj + plane,
                                proj + 2 * plane, proj + 3 * plane, a->sc2_w, a->sc2_b, a->at2_w, a->at2_b, a->pair_logit,
                                a->pair_bit);
-        fused = K <= SCORE_K_TILED;
-        hipLaunchKernelGGL(k_score_classes, dim3((unsigned)(((int64_t)n * 64 + 255) / 256), B), dim3(256), 0, s, n, K, C,
-                           a->order, a->cnt, a->want, a->cand, a->cls, a->pair_logit, a->logits, fused ? a->sel : nullptr, gs);
-        AIG_LAUNCH_CHECK();
+        if (!a->logits) {
+            const ClassScores cs{a->cand, a->cls, a->order, a->pair_logit, C};
+            if ((rc = launch_select(s, B, n, K, nullptr, a->cnt, a->want, a->sel, false, gs, cs))) return rc;
+        } else {
+            fused = K <= SCORE_K_TILED;
+            hipLaunchKernelGGL(k_score_classes, dim3((unsigned)(((int64_t)n * 64 + 255) / 256), B), dim3(256), 0, s, n, K, C,
+                               a->order, a->cnt, a->want, a->cand, a->cls, a->pair_logit, a->logits, fused ? a->sel : nullptr, gs);
+            AIG_LAUNCH_CHECK();
+        }
     } else {
         rc = launch_score(s, B, n, K, a->order, a->rank, a->cnt, a->want, a->cand, proj, proj + plane, half, a->sc2_w,
                           a->sc2_b, a->logits, a->sel, &fused, gs);
         if (rc) return rc;
     }
-    if ((rc = launch_select(s, B, n, K, a->logits, a->cnt, a->want, a->sel, fused, gs))) return rc;
+    if (a->logits && (rc = launch_select(s, B, n, K, a->logits, a->cnt, a->want, a->sel, fused, gs))) return rc;
     const dim3 grid((unsigned)((n + 255) / 256), B);
     long long* ei = reinterpret_cast<long long*>(a->edge_index);
     long long* ea = reinterpret_cast<long long*>(a->edge_attr);

@@ -87,6 +87,11 @@ class GeneratorPlan:
 
 
 CLASS_LIMIT = 1024      # distinct feature rows up to which a template is scored per class (pair tables of C x C entries)
+SELECT_FORMS_SCORES_MAX_K = 127     # windows up to which aig_gen_wire_batch takes logits = NULL with scores by class
+# ... and the slots of a call from which on that pays: the selection kernel then runs two full waves a block and forming
+# the scores in it costs less than the pass that stores them (370 against 334 + 242 us for a million slots); below, its
+# blocks are fractions of a wave and the two kernels are faster (89 against 103 us for 100k slots)
+SELECT_FORMS_SCORES_MIN_SLOTS = 262145
 
 
 def _plan_key(x: torch.Tensor, nd: Optional[torch.Tensor], K: int):
@@ -346,9 +351,13 @@ class AIGGenerator(nn.Module):
             a.cls, a.classes, a.pair_logit, a.pair_bit = _abi.ptr(cls), C, _abi.ptr(pair_logit), _abi.ptr(pair_bit)
         a.sc2_w, a.sc2_b = _abi.ptr(self.edge_scorer[2].weight), _abi.ptr(self.edge_scorer[2].bias)
         a.at2_w, a.at2_b = _abi.ptr(self.edge_attr_pred[2].weight), _abi.ptr(self.edge_attr_pred[2].bias)
-        logits = torch.empty((B, n, K), dtype=torch.float32, device=dev)
-        if keep is not None:
-            logits.fill_(float("nan"))
+        # (scores by class and windows short enough for the selection kernel's LDS copy: it forms the scores itself
+        #  and the n K logits are never stored - unless the caller wants to look at them)
+        logits = None
+        if keep is not None or not by_class or K > SELECT_FORMS_SCORES_MAX_K or B * n < SELECT_FORMS_SCORES_MIN_SLOTS:
+            logits = torch.empty((B, n, K), dtype=torch.float32, device=dev)
+            if keep is not None:
+                logits.fill_(float("nan"))
         sel = torch.empty((B, n, 2), dtype=torch.int32, device=dev)
         edge_index = torch.empty((B, 2, ecap), dtype=torch.int64, device=dev)
         edge_attr = torch.empty((B, ecap), dtype=torch.int64, device=dev)

@@ -583,7 +583,8 @@ typedef struct aig_gen_wire_set {
     const void* proj;         /* [4][B proj_rows][128] from aig_gen_node_proj_batch: f32, or IEEE halfs (proj_half) */
     int64_t proj_rows;
     const float *sc2_w, *sc2_b, *at2_w, *at2_b;      /* edge_scorer.2 / edge_attr_pred.2 */
-    float* logits;            /* scratch [B][n][K] */
+    float* logits;            /* scratch [B][n][K]; may be NULL with scores by class (cls) and K <= 127: the selection
+                               * then forms the scores itself and they are never stored */
     int32_t* sel;             /* scratch [B][n][2] */
     int64_t* edge_index;      /* out [B][2][ecap] */
     int64_t* edge_attr;       /* out [B][ecap] */

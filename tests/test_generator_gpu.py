@@ -651,3 +651,27 @@ def test_z_width_is_checked_at_the_c_abi():
     w.z_dim = 64
     assert call() == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n_and,K", [(2500, 16), (2500, 64), (2500, 100), (70000, 64), (150000, 8)])
+def test_selection_that_forms_its_scores_equals_the_two_kernels(n_and, K, monkeypatch):
+    """Scores by class never stored (``aig_gen_wire_batch`` with ``logits = NULL``: the selection kernel forms them -
+    the default from 262,145 slots a call on) against the default below that size (scores written by one kernel,
+    picked by the next): the same graphs, one at a time and as a set; block shapes of 8, 16 and 32 rows."""
+    import gan_amd.generator as gmod
+    torch.manual_seed(K)
+    G = AIGGenerator(candidate_k=K).to(DEV).eval()
+    t = synth_aig(60, n_and, 40, seed=n_and + K, window=max(300, n_and // 30), orientation="dataset")
+    tpl = Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV))
+    zs = torch.randn((3, 128), generator=torch.Generator().manual_seed(2)).to(DEV)
+    assert 3 * t.x.size(0) < gmod.SELECT_FORMS_SCORES_MIN_SLOTS or n_and > 80000
+    monkeypatch.setattr(gmod, "SELECT_FORMS_SCORES_MIN_SLOTS", 1 << 40)
+    want_one = G(tpl, zs[0])
+    want_set = G.forward_set([tpl] * 3, zs).graphs()
+    monkeypatch.setattr(gmod, "SELECT_FORMS_SCORES_MIN_SLOTS", 0)
+    got_one = G(tpl, zs[0])
+    got_set = G.forward_set([tpl] * 3, zs).graphs()
+    for a, b in [(want_one, got_one)] + list(zip(want_set, got_set)):
+        for k in ("x", "edge_index", "edge_attr"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(want_one.edge_index, want_set[0].edge_index)
