@@ -213,7 +213,7 @@ struct ClassScores {
     int C;
 };
 
-template <int T>
+template <int T, bool CLS = false>
 __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, const float* __restrict__ logits,
                                                    const int* __restrict__ cnt,
                                                    const int* __restrict__ want, int* __restrict__ sel,
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, co
     {
         const long long g = blockIdx.y;
         cnt += g * gs.node; want += g * gs.node; sel += g * 2ll * rows;
-        if (cs.T) { cs.cand += g * gs.cand; cs.cls += g * gs.node; cs.order += g * gs.node; cs.T += g * (long long)cs.C * cs.C; }
+        if (CLS) { cs.cand += g * gs.cand; cs.cls += g * gs.node; cs.order += g * gs.node; cs.T += g * (long long)cs.C * cs.C; }
         else logits += g * (long long)rows * ld;
     }
-    const bool by_class = cs.T != nullptr;
+    constexpr bool by_class = CLS;      // (a template parameter: the form that reads logits compiles as if this one did not exist)
     float* val = reinterpret_cast<float*>(smem);                           // [cap][T+1]
     unsigned char* idx = smem + (size_t)cap * (T + 1) * sizeof(float);     // [cap][T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(T) void k_topk_select(int rows, int ld, int cap, co
     for (int t0 = 0; any_need && t0 < W; t0 += 8) {
         float v[8][PARTS];
         int cc[8];
-        if (by_class) {
+        if constexpr (by_class) {
             int ci[8][PARTS], ct[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -857,7 +857,12 @@ int launch_select(hipStream_t s, int B, int rows, int ld, const float* logits, c
     const int threads = forced ? forced
                         : ld >= 128 ? SEL_THREADS
                         : all_rows <= 52000 ? 8 : all_rows <= 104000 ? 16 : all_rows <= 262144 ? 32 : SEL_THREADS;
-    if (threads == 8) AIG_HIP_CHECK(go(&k_topk_select<8>, 8));
+    if (cs.T) {
+        if (threads == 8) AIG_HIP_CHECK(go(&k_topk_select<8, true>, 8));
+        else if (threads == 16) AIG_HIP_CHECK(go(&k_topk_select<16, true>, 16));
+        else if (threads == 32) AIG_HIP_CHECK(go(&k_topk_select<32, true>, 32));
+        else AIG_HIP_CHECK(go(&k_topk_select<SEL_THREADS, true>, SEL_THREADS));
+    } else if (threads == 8) AIG_HIP_CHECK(go(&k_topk_select<8>, 8));
     else if (threads == 16) AIG_HIP_CHECK(go(&k_topk_select<16>, 16));
     else if (threads == 32) AIG_HIP_CHECK(go(&k_topk_select<32>, 32));
     else AIG_HIP_CHECK(go(&k_topk_select<SEL_THREADS>, SEL_THREADS));

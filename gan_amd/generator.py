@@ -89,7 +89,7 @@ class GeneratorPlan:
 CLASS_LIMIT = 1024      # distinct feature rows up to which a template is scored per class (pair tables of C x C entries)
 SELECT_FORMS_SCORES_MAX_K = 127     # windows up to which aig_gen_wire_batch takes logits = NULL with scores by class
 # ... and the slots of a call from which on that pays: the selection kernel then runs two full waves a block and forming
-# the scores in it costs less than the pass that stores them (370 against 334 + 242 us for a million slots); below, its
+# the scores in it costs less than the pass that stores them (370-400 against 334 + 242 us for a million slots); below, its
 # blocks are fractions of a wave and the two kernels are faster (89 against 103 us for 100k slots)
 SELECT_FORMS_SCORES_MIN_SLOTS = 262145
 
