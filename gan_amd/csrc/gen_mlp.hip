@@ -42,7 +42,18 @@ __global__ void k_zbias(const float* __restrict__ z, const float* __restrict__ w
     int ld = v == 0 ? ld0 : (v == 1 ? ld1 : ld2), off = v == 0 ? off0 : (v == 1 ? off1 : off2);
     float acc = 0.f;
     const float* row = w + static_cast<size_t>(j) * ld + off;
-    for (int k = 0; k < zdim; ++k) acc = fmaf(row[k], z[k], acc);
+    // (one chain, k ascending - the checker's order; the loads four at a time and a few groups ahead: with the width a
+    //  run-time number, the plain loop is 128 dependent round trips: 21 us against 6)
+    const float4* row4 = reinterpret_cast<const float4*>(row);
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+#pragma unroll 8
+    for (int q = 0; q < zdim / 4; ++q) {
+        const float4 r = row4[q], zz = z4[q];
+        acc = fmaf(r.x, zz.x, acc);
+        acc = fmaf(r.y, zz.y, acc);
+        acc = fmaf(r.z, zz.z, acc);
+        acc = fmaf(r.w, zz.w, acc);
+    }
     out[v * H + j] = acc + b[j];
 }
 
@@ -796,10 +807,10 @@ int check_gen_weights(const char* who, const float* x, const float* z, const aig
                 "%s: null weight pointer", who);
     // the kernels read weights, biases and rows in 16-byte pieces (x in 8-byte pieces)
     auto aligned = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-    AIG_REQUIRE(aligned(x, 8) && aligned(proj, 16) && aligned(h_cond, 16) && aligned(ws, 16) && aligned(w->enc2_w, 16) &&
+    AIG_REQUIRE(aligned(x, 8) && aligned(z, 16) && aligned(proj, 16) && aligned(h_cond, 16) && aligned(ws, 16) && aligned(w->enc2_w, 16) &&
                     aligned(w->enc2_b, 16) && aligned(w->proj0_w, 16) && aligned(w->proj2_w, 16) &&
                     aligned(w->proj2_b, 16) && aligned(w->sc0_w, 16) && aligned(w->at0_w, 16),
-                "%s: x must be 8-byte aligned, outputs, weights and biases 16-byte aligned", who);
+                "%s: x must be 8-byte aligned, z, outputs, weights and biases 16-byte aligned", who);
     AIG_REQUIRE(w->z_dim == 0 || (w->z_dim >= 4 && w->z_dim <= 1024 && w->z_dim % 4 == 0),
                 "%s: z_dim=%d (a multiple of 4 in 4..1024; 0 = 128)", who, (int)w->z_dim);
     return AIG_OK;

@@ -6,6 +6,6 @@ python3 - <<PY
 import csv, glob
 f = glob.glob('/tmp/pq/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if any(k in r['Name'] for k in ('k_topk_select', 'k_score_classes', 'k_emit', 'k_pair_table')):
+    if any(k in r['Name'] for k in ('k_topk_select', 'k_score_classes', 'k_emit', 'k_pair_table', 'k_zbias')):
         print(r['Name'].replace('aig::(anonymous namespace)::','').replace('void ','')[:60].ljust(60), r['Calls'].rjust(5), f"{float(r['AverageNs'])/1e3:8.1f} us avg", f"min {float(r['MinNs'])/1e3:7.1f} max {float(r['MaxNs'])/1e3:7.1f}")
 PY
