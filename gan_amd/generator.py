@@ -192,6 +192,8 @@ class AIGGenerator(nn.Module):
         zs = zs.to(dev).float().contiguous()
         if zs.dim() != 2 or int(zs.size(1)) != self.z_dim:
             raise _abi.AigAbiError(f"zs must be [samples, z_dim={self.z_dim}], got {tuple(zs.shape)}")
+        if zs.data_ptr() % 16:      # (a view into a larger tensor: the kernels read z as 16-byte vectors)
+            zs = zs.clone()
         S = int(zs.size(0))
         if self.score_dtype != "bf16" or S == 1:
             return [self(template, zs[i]) for i in range(S)]
@@ -274,6 +276,8 @@ class AIGGenerator(nn.Module):
         zs = zs.to(dev).float().contiguous()
         if zs.dim() != 2 or int(zs.size(1)) != self.z_dim:
             raise _abi.AigAbiError(f"zs must be [samples, z_dim={self.z_dim}], got {tuple(zs.shape)}")
+        if zs.data_ptr() % 16:      # (a view into a larger tensor: the kernels read z as 16-byte vectors)
+            zs = zs.clone()
         B = int(zs.size(0))
         K = int(self.candidate_k)
         if shared:
@@ -419,6 +423,8 @@ class AIGGenerator(nn.Module):
         z = z.to(dev).float().contiguous()
         if z.numel() != self.z_dim:
             raise _abi.AigAbiError(f"z must hold z_dim={self.z_dim} values, got {tuple(z.shape)}")
+        if z.data_ptr() % 16:       # (a view into a larger tensor: the kernels read z as 16-byte vectors)
+            z = z.clone()
         x_src = template.x
         x_in = x_src if (x_src.dtype == torch.float32 and x_src.is_contiguous()) else x_src.float().contiguous()
         n = int(x_in.size(0))

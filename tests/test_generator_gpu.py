@@ -675,3 +675,19 @@ def test_selection_that_forms_its_scores_equals_the_two_kernels(n_and, K, monkey
         for k in ("x", "edge_index", "edge_attr"):
             assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert torch.equal(want_one.edge_index, want_set[0].edge_index)
+
+
+def test_z_taken_from_the_middle_of_a_larger_tensor():
+    """A z that is a view at an odd offset (the kernels read z as 16-byte vectors): copied, same graph."""
+    torch.manual_seed(1)
+    G = AIGGenerator(candidate_k=16).to(DEV).eval()
+    t = synth_aig(20, 400, 12, seed=77, window=80, orientation="dataset")
+    tpl = Data(x=t.x.to(DEV), node_depth=t.node_depth.to(DEV))
+    big = torch.randn(3 * 128 + 5, device=DEV)
+    z = big[1:129]
+    assert z.data_ptr() % 16 != 0
+    a, b = G(tpl, z), G(tpl, z.clone())
+    assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.edge_attr, b.edge_attr)
+    zs = big[1:1 + 3 * 128].view(3, 128)
+    for x, y in zip(G.forward_many(tpl, zs), G.forward_many(tpl, zs.clone())):
+        assert torch.equal(x.edge_index, y.edge_index)
